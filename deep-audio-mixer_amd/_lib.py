@@ -1,0 +1,61 @@
+"""ctypes binding of libdam_hip.so (include/dam_hip.h).  There is no CPU fallback: if the
+library is missing or a call fails, the product path raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdam_hip.so')
+
+_STATUS = {0: 'DAM_OK', -1: 'DAM_ERR_BAD_ARG', -2: 'DAM_ERR_UNSUPPORTED', -3: 'DAM_ERR_LAUNCH',
+           -4: 'DAM_ERR_WORKSPACE'}
+
+c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); kept in the order of include/dam_hip.h
+SIGNATURES = {
+    'dam_arch': (ctypes.c_char_p, []),
+    'dam_abi_version': (c_i, []),
+    'dam_stft_twiddle_count': (c_i64, [c_i]),
+    'dam_stft_fill_twiddles_host': (c_i, [c_i, c_p]),
+    'dam_stft_logmag_f32': (c_i, [c_p, c_i, c_i64, c_i64, c_i, c_i64, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libdam_hip.so once; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libdam_hip.so is not built (%s): run `python __graft_entry__.py` or '
+                               '`python deep-audio-mixer_amd/build.py`; there is no CPU fallback' % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError('%s failed: %s (%d)' % (what, _STATUS.get(status, '?'), status))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('deep_audio_mixer_amd kernels run on the GPU only (got a %s tensor); '
+                               'there is no CPU fallback' % t.device)

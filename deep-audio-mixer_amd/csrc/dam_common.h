@@ -1,0 +1,52 @@
+// Shared helpers for the gfx950 kernels of libdam_hip.so (device + launch side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dam_hip.h"
+
+#define DAM_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return DAM_ERR_LAUNCH; \
+    } while (0)
+
+namespace dam {
+
+constexpr int WAVE = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 16-byte vector with 4-byte alignment: global_load_dwordx4 does not need more on gfx950.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// Orders LDS traffic of ONE wave: earlier ds_writes of any lane are visible to later
+// ds_reads of any lane of the same wave (LDS serves a wave's instructions in order).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lanes sharing lane>>4
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+    v = wave_sum16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace dam

@@ -1,0 +1,277 @@
+// dam_stft.hip -- STFT -> |.| -> dB front-end for gfx950 (MI355X).
+//
+// Replaces data/dataset.py:132-162 (compute_features), :181-183 (_stereo_to_mono),
+// :164-168 (_augment_audio) of the reference, for every track of a batch in one launch.
+//
+// Mapping (wave64, no port of a warp-32 design):
+//   * one workgroup = 4 waves = one tile of TF=16 consecutive frames of one track;
+//   * one WAVE owns one frame at a time: the 2048 real samples are packed as 1024
+//     complex points z[n] = x[2n] + i x[2n+1]; lane j keeps the 16 points z[j + 64*n1]
+//     in registers, read with 16 coalesced 16-byte loads straight from the interleaved
+//     stereo PCM (one load = L0 R0 L1 R1 = one complex point after the channel mean).
+//     The 50 % frame overlap is served by L2 (hop = n_fft/2 -> every sample is wanted by
+//     two frames of the same workgroup), so HBM sees each sample once;
+//   * 1024-point complex FFT = radix-16 (registers) x radix-16 (registers) x radix-4
+//     with three exchanges through a private 8.5 KB LDS scratch per wave (padded rows,
+//     conflict-free ds_read_b64); window, all twiddles of the three stages and of the
+//     real-FFT split are lane-invariant, so they live in registers for the whole kernel;
+//   * split post-pass produces bins k and 1024-k from Z[k], Z[1024-k], then
+//     20*log10(max(|X|, amin)) goes into an XOR-swizzled [1025][16] LDS tile;
+//   * the tile is written out with T contiguous (64-byte row segments) in the
+//     reference layout out[track][bin][frame]; optional per-frame max-abs normalise.
+#include "dam_common.h"
+
+namespace dam {
+namespace {
+
+constexpr int NFFT = 2048;
+constexpr int NCPX = NFFT / 2;       // complex points per frame
+constexpr int NBINS = NFFT / 2 + 1;  // 1025
+constexpr int TF = 16;               // frames per workgroup
+constexpr int STFT_WAVES = 4;
+constexpr int ROW = 68;              // float2 per scratch row (64 + 4 pad: 8-dword bank shift per row)
+constexpr int SCRATCH = 16 * ROW;    // float2 per wave (>= 1024)
+
+__device__ __forceinline__ void radix4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    float2 s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = csub(a1, a3);
+    a0 = cadd(s0, s2);
+    a2 = csub(s0, s2);
+    a1 = make_float2(s1.x + s3.y, s1.y - s3.x);   // s1 + (-i) s3
+    a3 = make_float2(s1.x - s3.y, s1.y + s3.x);   // s1 + (+i) s3
+}
+
+// In-register 16-point forward DFT.  Input v[n]; output X[k] is left in v[4*(k&3) + (k>>2)].
+__device__ __forceinline__ void fft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;   // cos/sin(pi/8)
+    constexpr float C2 = 0.70710678118654752f;                             // cos(pi/4)
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) radix4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+    // v[4*k1 + n2] *= W16^(n2*k1),  W16^m = (cos(2 pi m/16), -sin(2 pi m/16))
+    v[5] = cmul(v[5], make_float2(C1, -S1));     // m = 1
+    v[6] = cmul(v[6], make_float2(C2, -C2));     // m = 2
+    v[7] = cmul(v[7], make_float2(S1, -C1));     // m = 3
+    v[9] = cmul(v[9], make_float2(C2, -C2));     // m = 2
+    v[10] = make_float2(v[10].y, -v[10].x);      // m = 4 : * (-i)
+    v[11] = cmul(v[11], make_float2(-C2, -C2));  // m = 6
+    v[13] = cmul(v[13], make_float2(S1, -C1));   // m = 3
+    v[14] = cmul(v[14], make_float2(-C2, -C2));  // m = 6
+    v[15] = cmul(v[15], make_float2(-C1, S1));   // m = 9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) radix4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+__device__ __forceinline__ constexpr int fft16_pos(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <typename PCM, int CH>
+__device__ __forceinline__ float mono_at(const PCM* __restrict__ trk, int64_t p) {
+    if (CH == 1) return (float)trk[p];
+    return (float)((trk[2 * p] + trk[2 * p + 1]) * (PCM)0.5);
+}
+
+// Loads complex point (x[p], x[p+1]) of the reflect-padded mono signal; interior = no mirroring.
+template <typename PCM, int CH>
+__device__ __forceinline__ float2 load_pair_interior(const PCM* __restrict__ trk, int64_t p) {
+    if constexpr (CH == 2 && sizeof(PCM) == 4) {
+        f32x4_u q = *reinterpret_cast<const f32x4_u*>(trk + 2 * p);
+        return make_float2((q.x + q.y) * 0.5f, (q.z + q.w) * 0.5f);
+    } else if constexpr (CH == 1 && sizeof(PCM) == 4) {
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        f2u q = *reinterpret_cast<const f2u*>(trk + p);
+        return make_float2(q.x, q.y);
+    } else {
+        return make_float2(mono_at<PCM, CH>(trk, p), mono_at<PCM, CH>(trk, p + 1));
+    }
+}
+__device__ __forceinline__ int64_t reflect(int64_t p, int64_t n) {
+    p = p < 0 ? -p : p;
+    return p >= n ? 2 * (n - 1) - p : p;
+}
+
+// 20*log10(max(m, amin)); the floor is passed in (computed in double on the host) so that
+// silence maps to exactly 20*log10(amin) = -100 dB as in the reference.
+__device__ __forceinline__ float to_db(float m, float amin, float floor_db) {
+    return m <= amin ? floor_db : 20.0f * log10f(m);
+}
+
+template <typename PCM, int CH>
+__global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
+    const PCM* __restrict__ pcm, int64_t n_samples, int64_t track_stride, const float* __restrict__ window,
+    const float2* __restrict__ tw /* W_2048^k */, const float* __restrict__ gain, int hop, int n_frames,
+    float amin, float floor_db, int normalize, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float2 scratch_all[STFT_WAVES * SCRATCH];
+    __shared__ float tile[NBINS * TF];
+    __shared__ float colmax[TF * TF];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t track = blockIdx.y;
+    const int t0 = blockIdx.x * TF;
+    const PCM* trk = pcm + track * track_stride;
+    float2* S = scratch_all + wave * SCRATCH;
+    const float g = gain ? gain[track] : 1.0f;
+
+    // lane-invariant tables -> registers
+    float2 win[16], tw1[16], tw2[16], tw3[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int n = lane + 64 * n1;
+        win[n1] = make_float2(window[2 * n] * g, window[2 * n + 1] * g);
+        tw1[n1] = tw[(2 * lane * n1) & (NFFT - 1)];          // W_1024^(lane*k1)
+        tw2[n1] = tw[(32 * (lane & 3) * n1) & (NFFT - 1)];   // W_64^(b*c)
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tw3[i] = tw[lane + 64 * i];  // W_2048^k
+
+    for (int q = 0; q < TF / STFT_WAVES; ++q) {
+        const int tl = q * STFT_WAVES + wave;
+        const int t = t0 + tl;
+        if (t >= n_frames) break;   // wave-uniform; no workgroup barrier inside this loop
+        const int64_t p0 = (int64_t)t * hop - NFFT / 2;
+        float2 v[16];
+        if (p0 >= 0 && p0 + NFFT <= n_samples) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = load_pair_interior<PCM, CH>(trk, p0 + 2 * (lane + 64 * n1));
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int64_t p = p0 + 2 * (lane + 64 * n1);
+                v[n1] = make_float2(mono_at<PCM, CH>(trk, reflect(p, n_samples)),
+                                    mono_at<PCM, CH>(trk, reflect(p + 1, n_samples)));
+            }
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(v[n1].x * win[n1].x, v[n1].y * win[n1].y);
+
+        // stage 1: DFT16 over n1 (n = 64 n1 + lane), twiddle W_1024^(lane k1), scatter A[k1][lane]
+        fft16(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            float2 a = v[fft16_pos(k1)];
+            if (k1) a = cmul(a, tw1[k1]);
+            S[k1 * ROW + lane] = a;
+        }
+        wave_lds_sync();
+        // stage 2: lane = (k1, b); DFT16 over a (n2 = 4a + b), twiddle W_64^(b c)
+        {
+            const int k1 = lane >> 2, b = lane & 3;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = S[k1 * ROW + 4 * a + b];
+            fft16(v);
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float2 x = v[fft16_pos(c)];
+                if (c) x = cmul(x, tw2[c]);
+                S[k1 * ROW + 4 * c + b] = x;
+            }
+        }
+        wave_lds_sync();
+        // stage 3: lane handles (k1 = lane&15, c = (lane>>4) + 4i); radix-4 over b; Z[k1 + 16c + 256d]
+        {
+            const int k1 = lane & 15, cq = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = cq + 4 * i;
+                const float4 lo = *reinterpret_cast<const float4*>(&S[k1 * ROW + 4 * c]);
+                const float4 hi = *reinterpret_cast<const float4*>(&S[k1 * ROW + 4 * c + 2]);
+                v[4 * i + 0] = make_float2(lo.x, lo.y);
+                v[4 * i + 1] = make_float2(lo.z, lo.w);
+                v[4 * i + 2] = make_float2(hi.x, hi.y);
+                v[4 * i + 3] = make_float2(hi.z, hi.w);
+                radix4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) S[lane + 64 * i + 256 * d] = v[4 * i + d];
+        }
+        wave_lds_sync();
+        // real-FFT split: bins k and 1024-k from Z[k], Z[1024-k]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = lane + 64 * i;
+            const float2 zk = S[k], zn = S[(NCPX - k) & (NCPX - 1)];
+            const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+            const float2 tt = cmul(tw3[i], o);
+            const float2 xa = cadd(e, tt), xb = csub(e, tt);
+            const float ma = sqrtf(xa.x * xa.x + xa.y * xa.y), mb = sqrtf(xb.x * xb.x + xb.y * xb.y);
+            const int fa = k, fb = NCPX - k;
+            tile[fa * TF + (tl ^ (fa & 15))] = to_db(ma, amin, floor_db);
+            tile[fb * TF + (tl ^ (fb & 15))] = to_db(mb, amin, floor_db);
+        }
+        if (lane == 0) {
+            const float2 z = S[NCPX / 2];
+            const float m = sqrtf(z.x * z.x + z.y * z.y);
+            tile[(NCPX / 2) * TF + (tl ^ ((NCPX / 2) & 15))] = to_db(m, amin, floor_db);
+        }
+        wave_lds_sync();
+    }
+    __syncthreads();
+
+    // write-out: thread -> (frame tl = tid&15, bin f = tid>>4 + 16*it); rows of 16 frames = 64 B
+    const int tl = threadIdx.x & 15, f0 = threadIdx.x >> 4;
+    const bool col_ok = (t0 + tl) < n_frames;
+    float scale = 1.0f;
+    if (normalize) {
+        float m = 0.0f;
+        if (col_ok)
+            for (int f = f0; f < NBINS; f += 16) m = fmaxf(m, fabsf(tile[f * TF + (tl ^ (f & 15))]));
+        colmax[f0 * TF + tl] = m;
+        __syncthreads();
+        m = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, colmax[r * TF + tl]);
+        scale = m;
+    }
+    if (col_ok) {
+        float* o = out + (track * NBINS) * (int64_t)n_frames + t0 + tl;
+        for (int f = f0; f < NBINS; f += 16) {
+            float vdb = tile[f * TF + (tl ^ (f & 15))];
+            if (normalize && scale >= 1.17549435e-38f) vdb = vdb / scale;
+            o[(int64_t)f * n_frames] = vdb;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace dam
+
+extern "C" int64_t dam_stft_twiddle_count(int n_fft) { return n_fft > 0 ? n_fft : 0; }
+
+extern "C" int dam_stft_fill_twiddles_host(int n_fft, float* table_host) {
+    if (n_fft <= 0 || !table_host) return DAM_ERR_BAD_ARG;
+    const double w = -2.0 * 3.14159265358979323846264338327950288 / (double)n_fft;
+    for (int k = 0; k < n_fft; ++k) {
+        table_host[2 * k] = (float)cos(w * k);
+        table_host[2 * k + 1] = (float)sin(w * k);
+    }
+    return DAM_OK;
+}
+
+extern "C" int dam_stft_logmag_f32(const void* pcm, int pcm_dtype, int64_t n_tracks, int64_t n_samples, int channels,
+                                   int64_t pcm_track_stride, const float* window, const float* twiddles,
+                                   const float* gain, int n_fft, int hop, float amin, int normalize, float* out,
+                                   void* stream) {
+    using namespace dam;
+    if (!pcm || !window || !twiddles || !out || n_tracks <= 0 || hop <= 0) return DAM_ERR_BAD_ARG;
+    if (n_samples <= n_fft / 2) return DAM_ERR_BAD_ARG;   // reflect padding needs N > n_fft/2 (torch.stft raises too)
+    if (n_fft != NFFT || (hop & 1) || (channels != 1 && channels != 2)) return DAM_ERR_UNSUPPORTED;
+    if (pcm_dtype != DAM_PCM_F32 && pcm_dtype != DAM_PCM_F64) return DAM_ERR_UNSUPPORTED;
+    if (n_tracks > 65535) return DAM_ERR_UNSUPPORTED;
+    const int n_frames = (int)(1 + n_samples / hop);
+    dim3 grid((unsigned)cdiv(n_frames, TF), (unsigned)n_tracks), block(STFT_WAVES * WAVE);
+    hipStream_t s = (hipStream_t)stream;
+    const float2* tw = reinterpret_cast<const float2*>(twiddles);
+    const float floor_db = (float)(20.0 * log10((double)amin));
+#define DAM_STFT_LAUNCH(T, C)                                                                          \
+    hipLaunchKernelGGL((stft_logmag_kernel<T, C>), grid, block, 0, s, (const T*)pcm, n_samples,        \
+                       pcm_track_stride, window, tw, gain, hop, n_frames, amin, floor_db, normalize, out)
+    if (pcm_dtype == DAM_PCM_F32) {
+        if (channels == 2) DAM_STFT_LAUNCH(float, 2); else DAM_STFT_LAUNCH(float, 1);
+    } else {
+        if (channels == 2) DAM_STFT_LAUNCH(double, 2); else DAM_STFT_LAUNCH(double, 1);
+    }
+#undef DAM_STFT_LAUNCH
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}

@@ -1,0 +1,185 @@
+"""Oracle: the three gain-predicting CNNs on PyTorch-CPU (test infrastructure).
+
+Restates the reference model definitions with the stem count and the head
+width made constructor arguments; with ``n_stems=4`` and the
+reference's input shape the parameter names, shapes and arithmetic are those of
+
+  models/model_resnet.py:6-28     BasicBlock
+  models/model_resnet.py:59-126   ResNet / ResNet18 (:129-130)
+  models/model_scalar_1s.py:151-190, 207-275   ConvBlock2d / MixingModelScalar1s
+  models/model_scalar_2s.py:9-47, 64-132       ConvBlock2d / MixingModelScalar2s
+
+Everything here runs through torch.nn.functional on the CPU.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def conv_out(n, k, s=1, d=1, p=0):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class _Heads(nn.Module):
+    """Shared tail: per stem conv1x1(C->1)+ReLU -> flatten -> Linear(flat->1);
+    masked = sum_s g_s * x[:, s]  (models/model_resnet.py:108-126)."""
+
+    def _make_heads(self, channels, n_stems, flattened_dim):
+        self.n_stems = n_stems
+        for s in range(1, n_stems + 1):
+            setattr(self, 'conv_head%d' % s, nn.Conv2d(channels, 1, kernel_size=(1, 1)))
+            setattr(self, 'fc_head%d' % s, nn.Linear(flattened_dim, 1))
+
+    def _run_heads(self, x, trunk):
+        b = x.size(0)
+        gains = []
+        for s in range(1, self.n_stems + 1):
+            h = F.relu(getattr(self, 'conv_head%d' % s)(trunk))
+            gains.append(getattr(self, 'fc_head%d' % s)(h.view(b, -1)))
+        masked = torch.zeros_like(x[:, 0])
+        for s, g in enumerate(gains):
+            masked = masked + g.unsqueeze(2) * x[:, s]
+        return masked, tuple(gains)
+
+
+class RefBasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or cin != cout:
+            self.shortcut = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False),
+                                          nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + self.shortcut(x))
+
+
+RESNET_WIDTHS = (16, 32, 64, 96, 128, 256)      # models/model_resnet.py:66-71
+RESNET_STRIDES = (1, 2, 2, 2, 2, 2)
+
+
+def resnet_trunk_hw(f, t):
+    for s in RESNET_STRIDES:
+        if s == 2:
+            f, t = conv_out(f, 3, 2, 1, 1), conv_out(t, 3, 2, 1, 1)
+    return f, t
+
+
+class RefResNet18(_Heads):
+    """models/model_resnet.py:59-130; reference defaults n_stems=4, input 1025x216 -> flat 231."""
+
+    def __init__(self, n_stems=4, input_shape=(1025, 216)):
+        super().__init__()
+        self.conv1 = nn.Conv2d(n_stems, 16, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(16)
+        cin = 16
+        for i, (w, s) in enumerate(zip(RESNET_WIDTHS, RESNET_STRIDES), start=1):
+            setattr(self, 'layer%d' % i, nn.Sequential(RefBasicBlock(cin, w, s), RefBasicBlock(w, w, 1)))
+            cin = w
+        fh, ft = resnet_trunk_hw(*input_shape)
+        self._make_heads(256, n_stems, fh * ft)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        for i in range(1, 7):
+            y = getattr(self, 'layer%d' % i)(y)
+        return self._run_heads(x, y)
+
+
+class RefConvBlock2d(nn.Module):
+    """models/model_scalar_1s.py:151-190: valid conv(+bias) -> BN(eps 1e-3, momentum .9)
+    -> ReLU -> Dropout only while training."""
+
+    def __init__(self, cin, cout, k, stride=1, dilation=1, dropout_p=-1.0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, 0, dilation)
+        self.batch_norm = nn.BatchNorm2d(cout, momentum=0.90, eps=0.001)
+        self.dropout_p = dropout_p
+
+    def forward(self, x):
+        y = F.relu(self.batch_norm(self.conv(x)))
+        if self.training and self.dropout_p != -1:
+            y = F.dropout(y, self.dropout_p, True)
+        return y
+
+
+SCALAR_BLOCKS = ((16, 3, 0.2), (32, 5, 0.2), (48, 5, 0.2), (64, 7, 0.2), (128, 9, 0.3))
+
+
+def scalar_trunk_hw(f, t, first_dilation):
+    for i, (_, k, _) in enumerate(SCALAR_BLOCKS):
+        s, d = (2, first_dilation) if i == 0 else (1, 1)
+        f, t = conv_out(f, k, s, d), conv_out(t, k, s, d)
+    return f, t
+
+
+class _RefScalar(_Heads):
+    first_dilation = 1
+
+    def __init__(self, n_stems, input_shape):
+        super().__init__()
+        cin = n_stems
+        for i, (w, k, p) in enumerate(SCALAR_BLOCKS, start=1):
+            s, d = (2, self.first_dilation) if i == 1 else (1, 1)
+            setattr(self, 'conv_b%d' % i, RefConvBlock2d(cin, w, k, s, d, p))
+            cin = w
+        fh, ft = scalar_trunk_hw(*input_shape, self.first_dilation)
+        self._make_heads(128, n_stems, fh * ft)
+
+    def forward(self, x):
+        y = x
+        for i in range(1, 6):
+            y = getattr(self, 'conv_b%d' % i)(y)
+        return self._run_heads(x, y)
+
+
+class RefMixingModelScalar1s(_RefScalar):
+    """models/model_scalar_1s.py:207-275; reference: 4 stems, 1025x87 -> flat 10290."""
+    first_dilation = 1
+
+    def __init__(self, n_stems=4, input_shape=(1025, 87)):
+        super().__init__(n_stems, input_shape)
+
+
+class RefMixingModelScalar2s(_RefScalar):
+    """models/model_scalar_2s.py:64-132; reference: 4 stems, 1025x173 -> flat 30807."""
+    first_dilation = 2
+
+    def __init__(self, n_stems=4, input_shape=(1025, 173)):
+        super().__init__(n_stems, input_shape)
+
+
+def closed_form_fill(model: nn.Module, seed: int = 0):
+    """Deterministic parameter fill shared by the golden generator and the tests, so
+    that no multi-MB weight fixture is needed.  Conv/linear weights get
+    a scaled sinusoid of the flat index (fan-in scaled), BN affine params stay near
+    (1, 0), running stats are left at their defaults."""
+    with torch.no_grad():
+        for k, (name, p) in enumerate(model.named_parameters()):
+            n = p.numel()
+            i = torch.arange(n, dtype=torch.float64)
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                v = torch.sin(0.37 * i + 1.3 * k + seed) * (1.2 / fan_in ** 0.5)
+            elif name.endswith('weight'):          # BN gamma
+                v = 1.0 + 0.1 * torch.sin(0.9 * i + k + seed)
+            else:                                   # biases / BN beta
+                v = 0.05 * torch.cos(0.7 * i + k + seed)
+            p.copy_(v.reshape(p.shape).to(p.dtype))
+    return model
+
+
+def train_step_ref(model, optimizer, x, gt):
+    """One body of model_trainer.py:25-44 (zero_grad, fwd, MSE, backward, step)."""
+    optimizer.zero_grad()
+    masked, gains = model(x)
+    loss = F.mse_loss(masked, gt)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), gains
