@@ -1,0 +1,334 @@
+// dam_conv.hip -- 2-D convolution forward / data-gradient as an implicit GEMM on the gfx950
+// fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains, same numerics as a CPU conv).
+//
+// Replaces the nn.Conv2d calls of models/model_resnet.py:11-21,64 (3x3 pad 1 stride 1/2, 1x1 stride 2,
+// no bias) and models/model_scalar_1s.py:167-172 / model_scalar_2s.py:25-30 (valid 3/5/7/9 kernels,
+// bias, stride 2 / dilation 2 first block), forward and dgrad.
+//
+// Design (MI355X first, not a cuDNN-shaped port):
+//   * activations are NHWC fp32 with C a multiple of 16; GEMM view  D[cout][pixel] = W[cout][k] * X[k][pixel],
+//     so one lane ends up with 4 consecutive output channels of one pixel -> one 16-byte store, and a
+//     16x16 output block is one contiguous 1 KB wave store when Cout == 16;
+//   * the MFMA takes ONE float per operand per lane and is free in the K order, so K is ordered
+//     "channel 4*(lane>>4)+s at step s": a single ds_read_b128 of a lane's 4 consecutive channels feeds four
+//     MFMA steps, and the 64 lanes of a wave read 16 pixels x 64 B = 1 KB contiguous (conflict-free);
+//   * a workgroup (4 waves) owns TM = 64*MB consecutive output pixels (flattened over rows, so odd widths
+//     such as 130 waste nothing) x 16*NB output channels; the input rows those pixels touch are staged once
+//     per channel group into LDS as [chunk][row][col slot][16 ch] (stride-2 convs de-interleave even/odd columns
+//     so that consecutive output pixels stay contiguous), optionally applying the producer's
+//     BatchNorm scale/shift + ReLU on the way in (fused BN-apply);
+//   * weights are pre-packed [tap][k chunk][n block][lane] float4 and go global(L2) -> registers, 1 KB per wave load;
+//   * a "tap grid" (nA x nB taps with signed input steps, weight-tap strides and an output stride/offset)
+//     expresses forward, stride-1 dgrad (negative steps) and the four parity classes of a stride-2 dgrad
+//     with the same kernel.
+#include "dam_common.h"
+
+namespace dam {
+
+struct ConvGeo {
+    int B, H, W, C;          // input tensor dims; C = channel stride of an NHWC pixel (S planes if in_nchw)
+    int Ho, Wo;              // output pixel grid enumerated by this launch
+    int N;                   // output channels (multiple of 16) = channel stride of the output tensor
+    int OHt, OWt;            // output tensor spatial dims
+    int os, oo_h, oo_w;      // output pixel (oh, ow) -> tensor position (oh*os+oo_h, ow*os+oo_w)
+    int s;                   // input stride per output pixel (1 or 2)
+    int nA, nB;              // tap grid
+    int off_h, step_h, off_w, step_w;   // tap (a,b) reads input (oh*s + off_h + a*step_h, ow*s + off_w + b*step_w)
+    int wt_base, wt_sa, wt_sb;          // packed weight tap index = wt_base + a*wt_sa + b*wt_sb
+    int r0, c0;              // min tap offsets: patch origin (row oh_first*s + r0, col c0)
+    int PR, PWin, PWs, PWT;  // patch rows, input columns covered, slots per parity, slots per row (s*PWs)
+    int nchunks, CG;         // 16-channel K chunks in total / per LDS group
+    int NBtot;               // 16-channel output blocks in the packed weights
+    int tiles_m;             // M tiles per image
+    int in_nchw;             // 1: input is [B][C][H][W] with C <= 16 planes (first layer)
+    int relu_in;             // with in_scale: apply relu(x*scale+shift) while staging
+};
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const float* __restrict__ X,
+                                                         const float4* __restrict__ Wp, const float* __restrict__ bias,
+                                                         const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift, float* __restrict__ Y,
+                                                         const float* __restrict__ res, const float* __restrict__ res_mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    constexpr int MW = 16 * MB, TM = 4 * MW;
+    const int img = blockIdx.z, nb0 = blockIdx.y * NB;
+    const int HoWo = g.Ho * g.Wo;
+    const int p0 = blockIdx.x * TM;
+    const int oh_first = p0 / g.Wo;
+    const int chunk_bytes = g.PR * g.PWT * 64;
+
+    // per-lane LDS base of each M block (pixel of column j)
+    int base_b[MB];
+    int pix[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        int p = p0 + wave * MW + mb * 16 + j;
+        pix[mb] = p;
+        p = p < HoWo ? p : HoWo - 1;
+        const int oh = p / g.Wo, ow = p - oh * g.Wo;
+        base_b[mb] = (((oh - oh_first) * g.s) * g.PWT + ow) * 64 + kq * 16;
+    }
+
+    v4f acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    const int ih0 = oh_first * g.s + g.r0;
+    const int ngroups = g.nchunks / g.CG;
+    for (int cg = 0; cg < ngroups; ++cg) {
+        if (cg) __syncthreads();
+        // ---- stage the input patch of this channel group ----
+        if (!g.in_nchw) {
+            const int qpp = g.CG * 4;                       // float4 quads per pixel in this group (power of two)
+            const int qshift = 31 - __builtin_clz(qpp);
+            const int items = g.PWin * qpp;
+            const float* xb = X + (size_t)img * g.H * g.W * g.C + cg * g.CG * 16;
+            for (int pr = wave; pr < g.PR; pr += 4) {
+                const int ih = ih0 + pr;
+                const bool row_ok = ih >= 0 && ih < g.H;
+                const float* xr = xb + (size_t)(row_ok ? ih : 0) * g.W * g.C;
+                for (int e = lane; e < items; e += 64) {
+                    const int pw = e >> qshift, cq = e & (qpp - 1);
+                    const int iw = g.c0 + pw;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row_ok && iw >= 0 && iw < g.W) {
+                        v = *reinterpret_cast<const float4*>(xr + (size_t)iw * g.C + cq * 4);
+                        if (in_scale) {
+                            const int ch = cg * g.CG * 16 + cq * 4;
+                            const float4 sc = *reinterpret_cast<const float4*>(in_scale + ch);
+                            const float4 sh = *reinterpret_cast<const float4*>(in_shift + ch);
+                            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                            if (g.relu_in) {
+                                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                            }
+                        }
+                    }
+                    const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
+                    *reinterpret_cast<float4*>(smem + (cq >> 2) * chunk_bytes + ((pr * g.PWT + slot) * 16 + (cq & 3) * 4) * 4) = v;
+                }
+            }
+        } else {
+            // first layer: planes [C][H][W]; lane gathers 4 channel planes of one pixel, zero-fills C..15
+            const float* xb = X + (size_t)img * g.C * g.H * g.W;
+            const size_t plane = (size_t)g.H * g.W;
+            const int items = g.PWin * 4;
+            for (int pr = wave; pr < g.PR; pr += 4) {
+                const int ih = ih0 + pr;
+                const bool row_ok = ih >= 0 && ih < g.H;
+                for (int e = lane; e < items; e += 64) {
+                    const int q = e / g.PWin, pw = e - q * g.PWin;     // pw fastest across lanes: coalesced plane reads
+                    const int iw = g.c0 + pw;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (row_ok && iw >= 0 && iw < g.W) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ch = q * 4 + r;
+                            if (ch < g.C) v[r] = xb[ch * plane + (size_t)ih * g.W + iw];
+                        }
+                    }
+                    const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
+                    *reinterpret_cast<float4*>(smem + ((pr * g.PWT + slot) * 16 + q * 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMA over taps x chunks of the group ----
+        for (int a = 0; a < g.nA; ++a) {
+            const int roff = g.off_h + a * g.step_h - g.r0;
+            for (int b = 0; b < g.nB; ++b) {
+                const int coff = g.off_w + b * g.step_w - g.c0;
+                const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
+                const int toff = (roff * g.PWT + slotoff) * 64;
+                const int tap = g.wt_base + a * g.wt_sa + b * g.wt_sb;
+                for (int cc = 0; cc < g.CG; ++cc) {
+                    const int chunk = cg * g.CG + cc;
+                    const float4* wp = Wp + ((size_t)(tap * g.nchunks + chunk) * g.NBtot + nb0) * 64 + lane;
+                    float4 wa[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) wa[nb] = wp[nb * 64];
+                    float4 xv[MB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        xv[mb] = *reinterpret_cast<const float4*>(smem + cc * chunk_bytes + base_b[mb] + toff);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].x, xv[mb].x, acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].y, xv[mb].y, acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].z, xv[mb].z, acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].w, xv[mb].w, acc[mb][nb], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds channels 4*kq..+3 of pixel j of every (mb, nb) block ----
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int p = pix[mb];
+        if (p >= HoWo) continue;
+        const int oh = p / g.Wo, ow = p - oh * g.Wo;
+        const size_t opix = ((size_t)img * g.OHt + (oh * g.os + g.oo_h)) * g.OWt + (ow * g.os + g.oo_w);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int ch = (nb0 + nb) * 16 + kq * 4;
+            if (ch >= g.N) continue;
+            v4f v = acc[mb][nb];
+            if (bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            const size_t o = opix * g.N + ch;
+            if (res) {   // dgrad of a residual block: + dOut * (out > 0)
+                const float4 rv = *reinterpret_cast<const float4*>(res + o);
+                if (res_mask) {
+                    const float4 mv = *reinterpret_cast<const float4*>(res_mask + o);
+                    v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;
+                    v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;
+                } else {
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+            }
+            *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
+// OIHW [O][I][KH][KW] -> packed [tap][kchunk][nblk][kq][i][s].
+//   forward (transpose == 0): n = O index, k = I index;  dgrad (transpose == 1): n = I index, k = O index.
+__global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, int KH, int KW, int transpose,
+                                    int nchunks, int nblks, float* __restrict__ out, int64_t total) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int s = e & 3, i = (e >> 2) & 15, kq = (e >> 6) & 3;
+        int64_t r = e >> 8;
+        const int nblk = r % nblks; r /= nblks;
+        const int chunk = r % nchunks;
+        const int tap = r / nchunks;
+        const int n = nblk * 16 + i, k = chunk * 16 + kq * 4 + s;
+        const int o = transpose ? k : n, ii = transpose ? n : k;
+        float v = 0.f;
+        if (o < O && ii < I) v = w[((size_t)o * I + ii) * KH * KW + tap];
+        out[e] = v;
+    }
+}
+
+template <int MB, int NB>
+int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc,
+                const float* sh, float* Y, const float* res, const float* res_mask, hipStream_t st) {
+    constexpr int TM = 64 * MB;
+    if (lds > 64 * 1024) {
+        static bool raised = false;   // per instantiation
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MB, NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return DAM_ERR_LAUNCH;
+            raised = true;
+        }
+    }
+    dim3 grid((unsigned)cdiv((int64_t)g.Ho * g.Wo, TM), (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
+    hipLaunchKernelGGL((conv_igemm_kernel<MB, NB>), grid, dim3(256), lds, st, g, X, reinterpret_cast<const float4*>(Wp),
+                       bias, sc, sh, Y, res, res_mask);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+}  // namespace
+}  // namespace dam
+
+extern "C" int64_t dam_conv_packed_weight_count(int n_out, int k_in, int kh, int kw) {
+    if (n_out <= 0 || k_in <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (int64_t)kh * kw * dam::cdiv(k_in, 16) * dam::cdiv(n_out, 16) * 256;
+}
+
+extern "C" int dam_conv_pack_weights_f32(const float* w_oihw, int O, int I, int KH, int KW, int transpose,
+                                         float* packed, void* stream) {
+    using namespace dam;
+    if (!w_oihw || !packed || O <= 0 || I <= 0 || KH <= 0 || KW <= 0) return DAM_ERR_BAD_ARG;
+    const int n = transpose ? I : O, k = transpose ? O : I;
+    const int nchunks = (int)cdiv(k, 16), nblks = (int)cdiv(n, 16);
+    const int64_t total = (int64_t)KH * KW * nchunks * nblks * 256;
+    const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I, KH, KW,
+                       transpose, nchunks, nblks, packed, total);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+// Generic tap-grid convolution (see dam_hip.h).  The host wrapper derives the patch geometry and picks the tile.
+extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
+                                      int k_chunks, int n_out, const float* bias, const float* in_scale,
+                                      const float* in_shift, int relu_in, float* y, int OHt, int OWt, int Ho, int Wo,
+                                      int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
+                                      int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
+                                      const float* res, const float* res_mask, void* stream) {
+    using namespace dam;
+    if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || nA <= 0 || nB <= 0)
+        return DAM_ERR_BAD_ARG;
+    if (n_out % 16 || (in_stride != 1 && in_stride != 2) || out_stride < 1) return DAM_ERR_UNSUPPORTED;
+    if (in_nchw ? (C > 16 || k_chunks != 1) : (C % 16 || k_chunks != C / 16)) return DAM_ERR_UNSUPPORTED;
+    if (in_scale && !in_shift) return DAM_ERR_BAD_ARG;
+    if (B > 65535) return DAM_ERR_UNSUPPORTED;
+    ConvGeo g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.N = n_out; g.OHt = OHt; g.OWt = OWt;
+    g.os = out_stride; g.oo_h = out_off_h; g.oo_w = out_off_w; g.s = in_stride; g.nA = nA; g.nB = nB;
+    g.off_h = off_h; g.step_h = step_h; g.off_w = off_w; g.step_w = step_w;
+    g.wt_base = wt_base; g.wt_sa = wt_sa; g.wt_sb = wt_sb;
+    g.in_nchw = in_nchw; g.relu_in = relu_in; g.nchunks = k_chunks; g.NBtot = n_out / 16;
+    const int h_lo = off_h + (step_h < 0 ? (nA - 1) * step_h : 0), h_hi = off_h + (step_h > 0 ? (nA - 1) * step_h : 0);
+    const int w_lo = off_w + (step_w < 0 ? (nB - 1) * step_w : 0), w_hi = off_w + (step_w > 0 ? (nB - 1) * step_w : 0);
+    g.r0 = h_lo; g.c0 = w_lo;
+    g.PWin = (Wo - 1) * in_stride + (w_hi - w_lo) + 1;
+    g.PWs = (int)cdiv(g.PWin, in_stride);
+    g.PWT = g.PWs * in_stride;
+
+    // tile choice: fill the chip (>= ~2 workgroups per CU when the layer allows), then prefer big tiles
+    const int64_t npix = (int64_t)Ho * Wo;
+    const int nblk = n_out / 16;
+    int MB = 4, NB = nblk % 4 == 0 ? 4 : (nblk % 2 == 0 ? 2 : 1);   // NB must divide the block count
+    auto wgs = [&](int mb, int nb) { return cdiv(npix, 64 * mb) * cdiv(nblk, nb) * B; };
+    while (wgs(MB, NB) < 512 && (MB > 1 || NB > 1)) {
+        if (MB > 1 && (MB >= NB || NB == 1)) MB >>= 1; else NB >>= 1;
+    }
+    // LDS: shrink the channel group, then the M tile, until the patch fits
+    const size_t LDS_MAX = 64 * 1024;
+    int CG = 1;
+    while (CG * 2 <= 4 && k_chunks % (CG * 2) == 0) CG *= 2;
+    auto patch_rows = [&](int mb) {
+        const int tm = 64 * mb;
+        const int rows_out = (int)((tm + Wo - 2) / Wo + 1);
+        return (rows_out - 1) * in_stride + (h_hi - h_lo) + 1;
+    };
+    for (;;) {
+        g.PR = patch_rows(MB);
+        const size_t bytes = (size_t)CG * g.PR * g.PWT * 64;
+        if (bytes <= LDS_MAX) break;
+        if (CG > 1) CG >>= 1;
+        else if (MB > 1) MB >>= 1;
+        else if (bytes <= 150 * 1024) break;
+        else return DAM_ERR_UNSUPPORTED;
+    }
+    g.CG = CG;
+    g.tiles_m = (int)cdiv(npix, 64 * MB);
+    const size_t lds = (size_t)CG * g.PR * g.PWT * 64;
+    hipStream_t st = (hipStream_t)stream;
+#define DAM_CONV_CASE(M_, N_) \
+    if (MB == M_ && NB == N_) return launch_conv<M_, N_>(g, lds, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, st)
+    DAM_CONV_CASE(4, 4); DAM_CONV_CASE(4, 2); DAM_CONV_CASE(4, 1);
+    DAM_CONV_CASE(2, 4); DAM_CONV_CASE(2, 2); DAM_CONV_CASE(2, 1);
+    DAM_CONV_CASE(1, 4); DAM_CONV_CASE(1, 2); DAM_CONV_CASE(1, 1);
+#undef DAM_CONV_CASE
+    return DAM_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,114 @@
+"""Thin Python wrappers over the C ABI (include/dam_hip.h): shape checks, output allocation through
+torch's caching allocator, launch on the current torch stream.  No arithmetic happens here and
+there is no CPU fallback."""
+import torch
+
+from . import _lib
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError('%s must be a contiguous float32 tensor' % name)
+    return t
+
+
+def conv_out_size(n, k, stride=1, pad=0, dil=1):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ----------------------------------------------------------------------------- convolution
+def pack_weights(w, transpose=False, out=None):
+    """[O,I,KH,KW] -> packed image for the forward (transpose=False) or dgrad operator."""
+    _lib.require_cuda(w)
+    w = _f32c(w.detach(), 'weight')
+    o, i, kh, kw = w.shape
+    n_out, k_in = (i, o) if transpose else (o, i)
+    n = _lib.lib().dam_conv_packed_weight_count(n_out, k_in, kh, kw)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().dam_conv_pack_weights_f32(_lib.ptr(w), o, i, kh, kw, 1 if transpose else 0,
+                                                    _lib.ptr(out), _lib.stream()), 'dam_conv_pack_weights_f32')
+    return out
+
+
+def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shift, relu_in, y, OHt, OWt, Ho, Wo,
+             out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
+             res=None, res_mask=None):
+    st = _lib.lib().dam_conv2d_tapgrid_f32(
+        _lib.ptr(x), B, H, W, C, 1 if in_nchw else 0, _lib.ptr(wp), k_chunks, n_out, _lib.ptr(bias),
+        _lib.ptr(in_scale), _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(y), OHt, OWt, Ho, Wo, out_stride,
+        oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb, _lib.ptr(res),
+        _lib.ptr(res_mask), _lib.stream())
+    _lib.check(st, 'dam_conv2d_tapgrid_f32')
+
+
+def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale=None, in_shift=None,
+               relu_in=False, in_nchw=False):
+    """x: NHWC [B,H,W,C] (C % 16 == 0), or NCHW [B,C,H,W] with C <= 16 if in_nchw.  Returns NHWC
+    [B,Ho,Wo,n_out] with n_out rounded up to a multiple of 16 (extra channels are zero)."""
+    _lib.require_cuda(x, wp)
+    _f32c(x, 'x'), _f32c(bias, 'bias'), _f32c(in_scale, 'in_scale'), _f32c(in_shift, 'in_shift')
+    if in_nchw:
+        B, C, H, W = x.shape
+        k_chunks = 1
+    else:
+        B, H, W, C = x.shape
+        k_chunks = C // 16
+    n16 = (n_out + 15) // 16 * 16
+    Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+    if Ho <= 0 or Wo <= 0:
+        raise ValueError('convolution output would be empty')
+    y = torch.empty((B, Ho, Wo, n16), dtype=torch.float32, device=x.device)
+    _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n16, bias, in_scale, in_shift, relu_in, y, Ho, Wo, Ho, Wo,
+             1, 0, 0, stride, kh, kw, -pad, dil, -pad, dil, 0, kw, 1)
+    return y
+
+
+def _dgrad_axis(parity, pad, dil, k, stride):
+    """Taps of one output-parity class of a strided data gradient along one axis:
+    returns (count, k0, kstep, in_off, in_step) or None if the class receives nothing."""
+    valid = [t for t in range(k) if (parity + pad - t * dil) % stride == 0]
+    if not valid:
+        return None
+    k0 = valid[0]
+    kstep = valid[1] - valid[0] if len(valid) > 1 else 1
+    return len(valid), k0, kstep, (parity + pad - k0 * dil) // stride, -(kstep * dil) // stride
+
+
+def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, res_mask=None, accumulate_into=None):
+    """dy: NHWC [B,Ho,Wo,Cout]; wpt packed with transpose=True.  Returns dx NHWC [B,H,W,n_in16]
+    (+ res * (res_mask > 0) if given).  With accumulate_into=dx0 the result is added to dx0 in place."""
+    _lib.require_cuda(dy, wpt)
+    _f32c(dy, 'dy'), _f32c(res, 'res'), _f32c(res_mask, 'res_mask')
+    B, Ho, Wo, Co = dy.shape
+    n16 = (n_in + 15) // 16 * 16
+    if accumulate_into is not None:
+        dx, res, res_mask = accumulate_into, accumulate_into, None
+    else:
+        dx = torch.empty((B, H, W, n16), dtype=torch.float32, device=dy.device)
+    if stride == 1:
+        _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, H, W, 1, 0, 0, 1,
+                 kh, kw, pad, -dil, pad, -dil, 0, kw, 1, res, res_mask)
+        return dx
+    classes = [(_dgrad_axis(ph, pad, dil, kh, stride), _dgrad_axis(pw, pad, dil, kw, stride))
+               for ph in range(stride) for pw in range(stride)]
+    if any(a is None or b is None for a, b in classes) and accumulate_into is None:
+        if res is not None:
+            raise ValueError('a fused residual needs every output parity class to receive taps')
+        dx.zero_()          # classes without taps get no gradient (e.g. the 1x1 stride-2 shortcut)
+    covered = True
+    for ph in range(stride):
+        for pw in range(stride):
+            ah, aw = _dgrad_axis(ph, pad, dil, kh, stride), _dgrad_axis(pw, pad, dil, kw, stride)
+            nh, nw = (H - ph + stride - 1) // stride, (W - pw + stride - 1) // stride
+            if nh <= 0 or nw <= 0:
+                continue
+            if ah is None or aw is None:
+                covered = False
+                continue
+            _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, nh, nw,
+                     stride, ph, pw, 1, ah[0], aw[0], ah[3], ah[4], aw[3], aw[4], ah[1] * kw + aw[1],
+                     ah[2] * kw, aw[2], res, res_mask)
+    return dx

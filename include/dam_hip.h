@@ -68,6 +68,40 @@ int dam_stft_logmag_f32(const void* pcm, int pcm_dtype, int64_t n_tracks, int64_
                         const float* gain, int n_fft, int hop, float amin, int normalize,
                         float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Convolutions.  Replace nn.Conv2d forward and its autograd data-gradient in
+ * models/model_resnet.py:11-21,64 (BasicBlock / stem convs) and
+ * models/model_scalar_1s.py:167-172, models/model_scalar_2s.py:25-30 (ConvBlock2d.conv).
+ * Implicit GEMM on the fp32 matrix cores; activations NHWC float32.
+ * --------------------------------------------------------------------------------- */
+
+/* Number of floats of the packed weight image for an operator with n_out output and k_in
+ * reduction channels: [kh*kw][ceil(k_in/16)][ceil(n_out/16)][4][16][4]. */
+int64_t dam_conv_packed_weight_count(int n_out, int k_in, int kh, int kw);
+
+/* Pack torch-layout weights [O][I][KH][KW] for the forward (transpose=0: n_out=O, k_in=I)
+ * or the data-gradient operator (transpose=1: n_out=I, k_in=O); channels are zero-padded to 16. */
+int dam_conv_pack_weights_f32(const float* w_oihw, int O, int I, int KH, int KW, int transpose,
+                              float* packed, void* stream);
+
+/* y[b, oh*out_stride+out_off_h, ow*out_stride+out_off_w, :] (+= res [* (res_mask > 0)]) =
+ *     bias + sum_{a<nA, b<nB, k} Wp[wt_base + a*wt_sa + b*wt_sb][k][:] *
+ *            f(x[b, oh*in_stride + off_h + a*step_h, ow*in_stride + off_w + b*step_w, k])
+ * for oh < Ho, ow < Wo, with x = 0 outside [0,H)x[0,W) and f(v) = v, or v*in_scale[k]+in_shift[k]
+ * (then ReLU if relu_in) -- the producer's BatchNorm apply fused into the load.
+ *   x : NHWC [B][H][W][C] (C % 16 == 0, k_chunks == C/16), or with in_nchw=1 the reference's
+ *       [B][C][H][W] planes with C <= 16 (first layer, k_chunks == 1)
+ *   y : NHWC [B][OHt][OWt][n_out], n_out % 16 == 0;  res/res_mask (optional): same shape as y
+ * Forward conv: in_stride=stride, off=-pad, step=dilation, taps (kh,kw) as is.  Stride-1 dgrad:
+ * off=+pad, step=-dilation on dy with transposed packing.  Stride-2 dgrad: one call per output parity
+ * class (out_stride=2).  in_stride must be 1 or 2. */
+int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
+                           int k_chunks, int n_out, const float* bias, const float* in_scale,
+                           const float* in_shift, int relu_in, float* y, int OHt, int OWt, int Ho, int Wo,
+                           int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
+                           int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
+                           const float* res, const float* res_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,117 @@
+"""GPU: implicit-GEMM convolution (forward, data gradient, fused prologue/epilogue) through the C ABI
+against torch's CPU conv2d in float64.  fp32 MFMA is an exact fp32 fma chain, so the tolerance is that
+of fp32 accumulation: 2e-5 relative to the output's max-abs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope='module')
+def ops(dam_lib):
+    from deep_audio_mixer_amd import ops
+    return ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, want, tol=TOL):
+    got, want = got.double().cpu(), want.double()
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, (err, scale)
+
+
+CASES = [  # B, Cin, Cout, H, W, k, stride, pad, dil, bias
+    (2, 16, 16, 37, 23, 3, 1, 1, 1, False),
+    (2, 16, 32, 41, 27, 3, 2, 1, 1, False),
+    (2, 32, 64, 21, 14, 1, 2, 0, 1, False),
+    (1, 96, 96, 19, 17, 3, 1, 1, 1, False),
+    (1, 128, 256, 9, 5, 3, 2, 1, 1, False),
+    (2, 256, 256, 5, 5, 3, 1, 1, 1, False),
+    (1, 48, 64, 40, 33, 7, 1, 0, 1, True),
+    (1, 64, 128, 30, 25, 9, 1, 0, 1, True),
+    (2, 16, 32, 45, 31, 5, 1, 0, 1, True),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_fwd_dgrad(ops, case):
+    B, Ci, Co, H, W, k, s, p, d, use_bias = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g) if use_bias else None
+    want = F.conv2d(x.double(), w.double(), None if b is None else b.double(), s, p, d)
+    wp = ops.pack_weights(w.cuda())
+    y = ops.conv2d_fwd(nhwc(x).cuda(), wp, Co, k, k, s, p, d, bias=None if b is None else b.cuda())
+    assert y.shape == (B, want.shape[2], want.shape[3], Co)
+    close(nchw(y), want)
+    # data gradient: dx = conv_transpose(dy)
+    dy = torch.randn(want.shape, generator=g)
+    want_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, p, d)
+    wpt = ops.pack_weights(w.cuda(), transpose=True)
+    dx = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, Ci, H, W, k, k, s, p, d)
+    close(nchw(dx), want_dx)
+    # residual-fused epilogue: + r * (m > 0)
+    if k == 1 and s == 2:
+        return      # classes without taps: no fused residual (the shortcut path accumulates instead)
+    r, m = torch.randn(B, Ci, H, W, generator=g), torch.randn(B, Ci, H, W, generator=g)
+    dx2 = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, Ci, H, W, k, k, s, p, d, res=nhwc(r).cuda(), res_mask=nhwc(m).cuda())
+    close(nchw(dx2), want_dx + r.double() * (m > 0))
+
+
+@pytest.mark.parametrize('S,k,s,p,d', [(8, 3, 1, 1, 1), (4, 3, 1, 1, 1), (2, 3, 2, 0, 1), (4, 3, 2, 0, 2)])
+def test_first_layer_nchw(ops, S, k, s, p, d):
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(2, S, 67, 45, generator=g) * 20 - 20
+    w = torch.randn(16, S, k, k, generator=g) / (S * k * k) ** 0.5
+    b = torch.randn(16, generator=g)
+    want = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
+    y = ops.conv2d_fwd(x.cuda(), ops.pack_weights(w.cuda()), 16, k, k, s, p, d, bias=b.cuda(), in_nchw=True)
+    close(nchw(y), want)
+
+
+def test_fused_bn_relu_prologue(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 33, 29, generator=g)
+    sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) / 17
+    a = F.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    want = F.conv2d(a, w.double(), None, 1, 1)
+    y = ops.conv2d_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), 32, 3, 3, 1, 1, 1, in_scale=sc.cuda(),
+                       in_shift=sh.cuda(), relu_in=True)
+    close(nchw(y), want)
+
+
+def test_shortcut_dgrad_accumulates(ops):
+    """1x1 stride-2 shortcut: only the even/even input class receives gradient; it is added in place."""
+    g = torch.Generator().manual_seed(9)
+    x_shape = (2, 16, 21, 13)
+    w = torch.randn(32, 16, 1, 1, generator=g)
+    dy = torch.randn(2, 32, 11, 7, generator=g)
+    base = torch.randn(2, 21, 13, 16, generator=g)
+    want = nchw(base).double() + torch.nn.grad.conv2d_input(x_shape, w.double(), dy.double(), 2, 0, 1)
+    dx = base.cuda()
+    ops.conv2d_dgrad(nhwc(dy).cuda(), ops.pack_weights(w.cuda(), transpose=True), 16, 21, 13, 1, 1, 2, 0, 1,
+                     accumulate_into=dx)
+    close(nchw(dx), want)
+
+
+def test_full_resolution_layer1(ops):
+    """ResNet layer1 conv at the BASELINE size (16->16, 1025x130): exact-shape check on a strided sample."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 16, 1025, 130, generator=g)
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12
+    y = nchw(ops.conv2d_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), 16, 3, 3, 1, 1, 1)).cpu()
+    want = F.conv2d(x, w, None, 1, 1)
+    close(y, want, 5e-5)
