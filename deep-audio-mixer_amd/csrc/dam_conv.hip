@@ -22,6 +22,7 @@
 //     expresses forward, stride-1 dgrad (negative steps) and the four parity classes of a stride-2 dgrad
 //     with the same kernel.
 #include "dam_common.h"
+#include "dam_conv_stage.h"
 
 namespace dam {
 
@@ -83,63 +84,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const int ih0 = oh_first * g.s + g.r0;
+    PatchGeo pg;
+    pg.H = g.H; pg.W = g.W; pg.C = g.C; pg.s = g.s; pg.c0 = g.c0; pg.PR = g.PR; pg.PWin = g.PWin; pg.PWs = g.PWs;
+    pg.PWT = g.PWT; pg.in_nchw = g.in_nchw; pg.relu_in = g.relu_in;
     const int ngroups = g.nchunks / g.CG;
     for (int cg = 0; cg < ngroups; ++cg) {
         if (cg) __syncthreads();
         // ---- stage the input patch of this channel group ----
-        if (!g.in_nchw) {
-            const int qpp = g.CG * 4;                       // float4 quads per pixel in this group (power of two)
-            const int qshift = 31 - __builtin_clz(qpp);
-            const int items = g.PWin * qpp;
-            const float* xb = X + (size_t)img * g.H * g.W * g.C + cg * g.CG * 16;
-            for (int pr = wave; pr < g.PR; pr += 4) {
-                const int ih = ih0 + pr;
-                const bool row_ok = ih >= 0 && ih < g.H;
-                const float* xr = xb + (size_t)(row_ok ? ih : 0) * g.W * g.C;
-                for (int e = lane; e < items; e += 64) {
-                    const int pw = e >> qshift, cq = e & (qpp - 1);
-                    const int iw = g.c0 + pw;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row_ok && iw >= 0 && iw < g.W) {
-                        v = *reinterpret_cast<const float4*>(xr + (size_t)iw * g.C + cq * 4);
-                        if (in_scale) {
-                            const int ch = cg * g.CG * 16 + cq * 4;
-                            const float4 sc = *reinterpret_cast<const float4*>(in_scale + ch);
-                            const float4 sh = *reinterpret_cast<const float4*>(in_shift + ch);
-                            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-                            if (g.relu_in) {
-                                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                            }
-                        }
-                    }
-                    const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
-                    *reinterpret_cast<float4*>(smem + (cq >> 2) * chunk_bytes + ((pr * g.PWT + slot) * 16 + (cq & 3) * 4) * 4) = v;
-                }
-            }
-        } else {
-            // first layer: planes [C][H][W]; lane gathers 4 channel planes of one pixel, zero-fills C..15
-            const float* xb = X + (size_t)img * g.C * g.H * g.W;
-            const size_t plane = (size_t)g.H * g.W;
-            const int items = g.PWin * 4;
-            for (int pr = wave; pr < g.PR; pr += 4) {
-                const int ih = ih0 + pr;
-                const bool row_ok = ih >= 0 && ih < g.H;
-                for (int e = lane; e < items; e += 64) {
-                    const int q = e / g.PWin, pw = e - q * g.PWin;     // pw fastest across lanes: coalesced plane reads
-                    const int iw = g.c0 + pw;
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (row_ok && iw >= 0 && iw < g.W) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int ch = q * 4 + r;
-                            if (ch < g.C) v[r] = xb[ch * plane + (size_t)ih * g.W + iw];
-                        }
-                    }
-                    const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
-                    *reinterpret_cast<float4*>(smem + ((pr * g.PWT + slot) * 16 + q * 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
+        {
+            const size_t img_elems = (size_t)g.H * g.W * g.C;
+            stage_patch(smem, chunk_bytes, X + (size_t)img * img_elems, pg, ih0, cg * g.CG, g.CG, in_scale, in_shift, lane, wave);
         }
         __syncthreads();
 
@@ -308,7 +262,8 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     while (CG * 2 <= 4 && k_chunks % (CG * 2) == 0) CG *= 2;
     auto patch_rows = [&](int mb) {
         const int tm = 64 * mb;
-        const int rows_out = (int)((tm + Wo - 2) / Wo + 1);
+        int rows_out = (int)((tm + Wo - 2) / Wo + 1);
+        if (rows_out > Ho) rows_out = Ho;
         return (rows_out - 1) * in_stride + (h_hi - h_lo) + 1;
     };
     for (;;) {

@@ -112,3 +112,37 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
                      stride, ph, pw, 1, ah[0], aw[0], ah[3], ah[4], aw[3], aw[4], ah[1] * kw + aw[1],
                      ah[2] * kw, aw[2], res, res_mask)
     return dx
+
+
+_workspaces = {}
+
+
+def _workspace(device, floats):
+    """One grow-only scratch buffer per device; all users are ordered on the current stream."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(int(floats), dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, relu_in=False,
+                 in_nchw=False, out=None):
+    """dW in torch layout [n_out, C, kh, kw] from x (NHWC, or NCHW first layer) and dy NHWC [B,Ho,Wo,n16]."""
+    _lib.require_cuda(x, dy)
+    _f32c(x, 'x'), _f32c(dy, 'dy')
+    if in_nchw:
+        B, C, H, W = x.shape
+    else:
+        B, H, W, C = x.shape
+    _, Ho, Wo, n_chan = dy.shape
+    L = _lib.lib()
+    ws = _workspace(x.device, L.dam_conv2d_wgrad_workspace_floats(n_out, C, kh, kw))
+    if out is None:
+        out = torch.empty((n_out, C, kh, kw), dtype=torch.float32, device=x.device)
+    _lib.check(L.dam_conv2d_wgrad_f32(_lib.ptr(x), B, H, W, C, 1 if in_nchw else 0, _lib.ptr(in_scale),
+                                      _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(dy), Ho, Wo, n_chan, n_out,
+                                      kh, kw, stride, pad, dil, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                      _lib.stream()), 'dam_conv2d_wgrad_f32')
+    return out

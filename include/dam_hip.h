@@ -102,6 +102,20 @@ int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nc
                            int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                            const float* res, const float* res_mask, void* stream);
 
+/* Weight gradient of the same convolutions (autograd of nn.Conv2d reached from loss.backward(),
+ * model_trainer.py:36):  dw[n][k][kh][kw] = sum_{b,oh,ow} dy[b,oh,ow,n] * f(x[b, oh*stride+kh*dil-pad, ow*stride+kw*dil-pad, k])
+ *   x  : as for dam_conv2d_tapgrid_f32 (NHWC, or in_nchw planes for the first layer), same fused f()
+ *   dy : NHWC [B][Ho][Wo][n_chan], n_chan % 16 == 0; only the first n_out channels are real
+ *   dw : torch layout [n_out][C][kh][kw] (C = real input channels), fully overwritten
+ *   workspace : at least dam_conv2d_wgrad_workspace_floats(...) floats; holds the split-K slabs that a
+ *               second kernel sums in a fixed order (bitwise reproducible, no float atomics)
+ * Supported kernels: 3x3, 1x1, and kw in {5,7,9} with any kh; stride 1 or 2. */
+int64_t dam_conv2d_wgrad_workspace_floats(int n_out, int c_in, int kh, int kw);
+int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* in_scale,
+                         const float* in_shift, int relu_in, const float* dy, int Ho, int Wo, int n_chan,
+                         int n_out, int kh, int kw, int stride, int pad, int dil, float* dw,
+                         float* workspace, int64_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

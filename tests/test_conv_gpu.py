@@ -62,6 +62,11 @@ def test_conv_fwd_dgrad(ops, case):
     wpt = ops.pack_weights(w.cuda(), transpose=True)
     dx = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, Ci, H, W, k, k, s, p, d)
     close(nchw(dx), want_dx)
+    # weight gradient
+    want_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), s, p, d)
+    dw = ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), Co, k, k, s, p, d)
+    assert dw.shape == w.shape
+    close(dw, want_dw, 5e-5)
     # residual-fused epilogue: + r * (m > 0)
     if k == 1 and s == 2:
         return      # classes without taps: no fused residual (the shortcut path accumulates instead)
@@ -79,6 +84,10 @@ def test_first_layer_nchw(ops, S, k, s, p, d):
     want = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
     y = ops.conv2d_fwd(x.cuda(), ops.pack_weights(w.cuda()), 16, k, k, s, p, d, bias=b.cuda(), in_nchw=True)
     close(nchw(y), want)
+    dy = torch.randn(want.shape, generator=g)
+    want_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), s, p, d)
+    dw = ops.conv2d_wgrad(x.cuda(), nhwc(dy).cuda(), 16, k, k, s, p, d, in_nchw=True)
+    close(dw, want_dw, 5e-5)
 
 
 def test_fused_bn_relu_prologue(ops):
@@ -91,6 +100,11 @@ def test_fused_bn_relu_prologue(ops):
     y = ops.conv2d_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), 32, 3, 3, 1, 1, 1, in_scale=sc.cuda(),
                        in_shift=sh.cuda(), relu_in=True)
     close(nchw(y), want)
+    dy = torch.randn(want.shape, generator=g)
+    want_dw = torch.nn.grad.conv2d_weight(a, w.shape, dy.double(), 1, 1)
+    dw = ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), 32, 3, 3, 1, 1, 1, in_scale=sc.cuda(), in_shift=sh.cuda(),
+                          relu_in=True)
+    close(dw, want_dw, 5e-5)
 
 
 def test_shortcut_dgrad_accumulates(ops):
@@ -115,3 +129,6 @@ def test_full_resolution_layer1(ops):
     y = nchw(ops.conv2d_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), 16, 3, 3, 1, 1, 1)).cpu()
     want = F.conv2d(x, w, None, 1, 1)
     close(y, want, 5e-5)
+    dy = torch.randn(2, 16, 1025, 130, generator=g)
+    want_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, 1)
+    close(ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), 16, 3, 3, 1, 1, 1), want_dw, 1e-4)
