@@ -27,6 +27,20 @@ SIGNATURES = {
     'dam_conv2d_wgrad_workspace_floats': (c_i64, [c_i, c_i, c_i, c_i]),
     'dam_conv2d_wgrad_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p] + [c_i] * 9 +
                              [c_p, c_p, c_i64, c_p]),
+    'dam_bn_workspace_floats': (c_i64, [c_i]),
+    'dam_bn_stats_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'dam_bn_eval_affine_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
+    'dam_bn_apply_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    'dam_channel_sum_f32': (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    'dam_heads_fwd_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'dam_heads_bwd_workspace_floats': (c_i64, [c_i, c_i, c_i, c_i]),
+    'dam_heads_bwd_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'dam_masksum_fwd_f32': (c_i, [c_p, c_p, c_i, c_i, c_i64, c_p, c_p]),
+    'dam_masksum_workspace_floats': (c_i64, [c_i, c_i]),
+    'dam_masksum_bwd_f32': (c_i, [c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p]),
+    'dam_masksum_mse_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    'dam_adam_l2_step_f32': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
 }
 
 _lib = None

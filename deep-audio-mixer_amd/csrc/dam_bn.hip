@@ -1,0 +1,361 @@
+// dam_bn.hip -- BatchNorm2d (training and eval mode) forward / backward on NHWC float32, HBM-bound kernels.
+//
+// Replaces nn.BatchNorm2d + F.relu (+ residual add) of models/model_resnet.py:12-27,65,97 (eps 1e-5,
+// momentum 0.1) and models/model_scalar_1s.py:174-186 / model_scalar_2s.py:32-44 (eps 1e-3, momentum 0.9),
+// including the running-statistics update and the autograd backward reached from model_trainer.py:36.
+//
+//   * statistics: every workgroup streams a contiguous pixel range with 16-byte loads (a thread owns 4
+//     channels), keeps SHIFTED sums (x - K, K = first value seen) so that mean^2 >> var cannot cancel,
+//     converts to (n, mean, M2) and the partials are merged with Chan's formula (in double in the finalize
+//     kernel): deterministic, no atomics, matches a two-pass CPU BatchNorm;
+//   * finalize also updates running_mean / running_var (unbiased) / num_batches_tracked exactly like
+//     torch, and emits scale = gamma*invstd, shift = beta - mean*scale for the fused consumers
+//     (bn_apply below, or the convolution kernels' load prologue);
+//   * apply: y = relu?(x*scale + shift (+ r  or  + r*rscale + rshift))  -- the residual variant covers
+//     both BasicBlock shortcuts (identity, or the shortcut conv's own BatchNorm folded in);
+//   * backward: one reduction pass (sum dz, sum dz*xhat; dz = dy * (y > 0)) and one apply pass
+//     dx = c1*dz + c2*x + c3 with per-channel constants.
+#include "dam_common.h"
+
+namespace dam {
+namespace {
+
+constexpr int BN_MAX_PARTS = 1024;
+
+struct BnLaunch { int threads, q, r, parts; int64_t ppb; };
+
+inline BnLaunch bn_plan(int64_t P, int C) {
+    BnLaunch l;
+    l.q = C / 4;
+    l.r = 256 / l.q;
+    if (l.r < 1) l.r = 1;
+    l.threads = l.q * l.r;
+    int64_t parts = cdiv(P, 512);
+    if (parts > BN_MAX_PARTS) parts = BN_MAX_PARTS;
+    if (parts < 1) parts = 1;
+    l.ppb = cdiv(P, parts);
+    l.parts = (int)cdiv(P, l.ppb);
+    return l;
+}
+
+__global__ void bn_stats_partial_kernel(const float* __restrict__ x, int64_t P, int C, int Q, int R, int64_t ppb,
+                                        float* __restrict__ partial /* [parts][C][3] */) {
+    extern __shared__ float sm[];    // [R][C][3]
+    const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
+    const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
+    float k[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    int n = 0;
+    for (int64_t p = lo + pr; p < hi; p += R) {
+        const float4 v = *reinterpret_cast<const float4*>(x + p * C + cq * 4);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        if (n == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) k[i] = e[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = e[i] - k[i];
+            s1[i] += d;
+            s2[i] = fmaf(d, d, s2[i]);
+        }
+        ++n;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* o = sm + ((size_t)pr * C + cq * 4 + i) * 3;
+        const float md = n ? s1[i] / n : 0.f;
+        o[0] = (float)n;
+        o[1] = k[i] + md;
+        o[2] = n ? fmaxf(s2[i] - s1[i] * md, 0.f) : 0.f;
+    }
+    __syncthreads();
+    if (pr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cq * 4 + i;
+            float na = 0.f, ma = 0.f, qa = 0.f;
+            for (int r = 0; r < R; ++r) {
+                const float* o = sm + ((size_t)r * C + c) * 3;
+                const float nb = o[0];
+                if (nb == 0.f) continue;
+                const float nn = na + nb, d = o[1] - ma;
+                ma += d * (nb / nn);
+                qa += o[2] + d * d * (na * nb / nn);
+                na = nn;
+            }
+            float* out = partial + ((size_t)blockIdx.x * C + c) * 3;
+            out[0] = na; out[1] = ma; out[2] = qa;
+        }
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int parts, int C,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         long long* __restrict__ num_batches, float momentum, float eps,
+                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                         float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches) *num_batches += 1;
+    if (c >= C) return;
+    double na = 0, ma = 0, qa = 0;
+    for (int p = 0; p < parts; ++p) {
+        const float* o = partial + ((size_t)p * C + c) * 3;
+        const double nb = o[0];
+        if (nb == 0) continue;
+        const double nn = na + nb, d = (double)o[1] - ma;
+        ma += d * (nb / nn);
+        qa += (double)o[2] + d * d * (na * nb / nn);
+        na = nn;
+    }
+    const double var = qa / na;
+    const float mean = (float)ma;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (running_mean) {
+        const double unbiased = na > 1 ? qa / (na - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float sc = gamma[c] * invstd;
+    save_mean[c] = running_mean[c];
+    save_invstd[c] = invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, int64_t nquads, int Q, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const float* __restrict__ res,
+                                const float* __restrict__ rscale, const float* __restrict__ rshift, int relu,
+                                float* __restrict__ y) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nquads; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(e % Q);
+        const float4 v = reinterpret_cast<const float4*>(x)[e];
+        const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sh = reinterpret_cast<const float4*>(shift)[cq];
+        float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+        if (res) {
+            float4 r = reinterpret_cast<const float4*>(res)[e];
+            if (rscale) {
+                const float4 a = reinterpret_cast<const float4*>(rscale)[cq], b = reinterpret_cast<const float4*>(rshift)[cq];
+                r = make_float4(fmaf(r.x, a.x, b.x), fmaf(r.y, a.y, b.y), fmaf(r.z, a.z, b.z), fmaf(r.w, a.w, b.w));
+            }
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[e] = o;
+    }
+}
+
+// partial[blk][c] = (sum dz, sum dz*xhat)
+__global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y_mask,
+                                      const float* __restrict__ x, int64_t P, int C, int Q, int R, int64_t ppb,
+                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      float* __restrict__ partial /* [parts][C][2] */) {
+    extern __shared__ float sm[];    // [R][C][2]
+    const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
+    const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
+    const float4 mu = reinterpret_cast<const float4*>(mean)[cq], is = reinterpret_cast<const float4*>(invstd)[cq];
+    float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    for (int64_t p = lo + pr; p < hi; p += R) {
+        float4 g = *reinterpret_cast<const float4*>(dy + p * C + cq * 4);
+        if (y_mask) {
+            const float4 m = *reinterpret_cast<const float4*>(y_mask + p * C + cq * 4);
+            g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+        }
+        const float4 v = *reinterpret_cast<const float4*>(x + p * C + cq * 4);
+        a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
+        b[0] = fmaf(g.x, (v.x - mu.x) * is.x, b[0]); b[1] = fmaf(g.y, (v.y - mu.y) * is.y, b[1]);
+        b[2] = fmaf(g.z, (v.z - mu.z) * is.z, b[2]); b[3] = fmaf(g.w, (v.w - mu.w) * is.w, b[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* o = sm + ((size_t)pr * C + cq * 4 + i) * 2;
+        o[0] = a[i]; o[1] = b[i];
+    }
+    __syncthreads();
+    if (pr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cq * 4 + i;
+            float sa = 0.f, sb = 0.f;
+            for (int r = 0; r < R; ++r) { sa += sm[((size_t)r * C + c) * 2]; sb += sm[((size_t)r * C + c) * 2 + 1]; }
+            partial[((size_t)blockIdx.x * C + c) * 2] = sa;
+            partial[((size_t)blockIdx.x * C + c) * 2 + 1] = sb;
+        }
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int parts, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int p = 0; p < parts; ++p) { s1 += partial[((size_t)p * C + c) * 2]; s2 += partial[((size_t)p * C + c) * 2 + 1]; }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    const double g = (double)gamma[c] * invstd[c];
+    double c2 = 0, c3 = 0;
+    if (training) {
+        c2 = -g * invstd[c] * s2 / count;
+        c3 = -g * s1 / count - c2 * mean[c];
+    }
+    coef[c] = (float)g; coef[C + c] = (float)c2; coef[2 * C + c] = (float)c3;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y_mask,
+                                    const float* __restrict__ x, int64_t nquads, int Q, int C,
+                                    const float* __restrict__ coef, float* __restrict__ dx) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nquads; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(e % Q);
+        float4 g = reinterpret_cast<const float4*>(dy)[e];
+        if (y_mask) {
+            const float4 m = reinterpret_cast<const float4*>(y_mask)[e];
+            g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+        }
+        const float4 v = reinterpret_cast<const float4*>(x)[e];
+        const float4 c1 = reinterpret_cast<const float4*>(coef)[cq], c2 = reinterpret_cast<const float4*>(coef + C)[cq],
+                     c3 = reinterpret_cast<const float4*>(coef + 2 * C)[cq];
+        float4 o;
+        o.x = fmaf(c1.x, g.x, fmaf(c2.x, v.x, c3.x)); o.y = fmaf(c1.y, g.y, fmaf(c2.y, v.y, c3.y));
+        o.z = fmaf(c1.z, g.z, fmaf(c2.z, v.z, c3.z)); o.w = fmaf(c1.w, g.w, fmaf(c2.w, v.w, c3.w));
+        reinterpret_cast<float4*>(dx)[e] = o;
+    }
+}
+
+// out[c] = sum over pixels of x[p][c] (conv bias gradient); reuses the bwd partial layout with one column.
+__global__ void channel_sum_partial_kernel(const float* __restrict__ x, int64_t P, int C, int Q, int R, int64_t ppb,
+                                           float* __restrict__ partial) {
+    extern __shared__ float sm[];
+    const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
+    const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
+    float a[4] = {0, 0, 0, 0};
+    for (int64_t p = lo + pr; p < hi; p += R) {
+        const float4 v = *reinterpret_cast<const float4*>(x + p * C + cq * 4);
+        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[(size_t)pr * C + cq * 4 + i] = a[i];
+    __syncthreads();
+    if (pr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += sm[(size_t)r * C + cq * 4 + i];
+            partial[(size_t)blockIdx.x * C + cq * 4 + i] = s;
+        }
+    }
+}
+__global__ void channel_sum_finalize_kernel(const float* __restrict__ partial, int parts, int C, int n_real,
+                                            float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_real) return;
+    double s = 0;
+    for (int p = 0; p < parts; ++p) s += partial[(size_t)p * C + c];
+    out[c] = (float)s;
+}
+
+inline int elt_blocks(int64_t n) {
+    int64_t b = cdiv(n, 256);
+    return (int)(b < 4096 ? (b < 1 ? 1 : b) : 4096);
+}
+
+}  // namespace
+}  // namespace dam
+
+using namespace dam;
+
+extern "C" int64_t dam_bn_workspace_floats(int C) { return (int64_t)BN_MAX_PARTS * C * 3; }
+
+extern "C" int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
+                                float* shift, float* workspace, void* stream) {
+    if (!x || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift || !workspace || n_pixels <= 0)
+        return DAM_ERR_BAD_ARG;
+    if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
+    const BnLaunch l = bn_plan(n_pixels, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st,
+                       x, n_pixels, C, l.q, l.r, l.ppb, workspace);
+    DAM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, workspace, l.parts, C,
+                       gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
+                       save_mean, save_invstd, scale, shift);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int dam_bn_eval_affine_f32(int C, const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, float* save_mean, float* save_invstd,
+                                      float* scale, float* shift, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !save_mean || !save_invstd || !scale || !shift || C <= 0)
+        return DAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma, beta,
+                       running_mean, running_var, eps, save_mean, save_invstd, scale, shift);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const float* scale, const float* shift,
+                                const float* res, const float* res_scale, const float* res_shift, int relu, float* y,
+                                void* stream) {
+    if (!x || !scale || !shift || !y || n_pixels <= 0) return DAM_ERR_BAD_ARG;
+    if (C % 16) return DAM_ERR_UNSUPPORTED;
+    if (res_scale && (!res || !res_shift)) return DAM_ERR_BAD_ARG;
+    const int64_t nq = n_pixels * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(elt_blocks(nq)), dim3(256), 0, (hipStream_t)stream, x, nq, C / 4, scale, shift,
+                       res, res_scale, res_shift, relu, y);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
+                                   const float* gamma, const float* save_mean, const float* save_invstd, int training,
+                                   float* dx, float* dgamma, float* dbeta, float* workspace, void* stream) {
+    if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || n_pixels <= 0)
+        return DAM_ERR_BAD_ARG;
+    if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
+    const BnLaunch l = bn_plan(n_pixels, C);
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = workspace + (size_t)BN_MAX_PARTS * C * 2;    // workspace holds [parts][C][2] then [3][C]
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 2 * sizeof(float), st, dy,
+                       y_mask, x, n_pixels, C, l.q, l.r, l.ppb, save_mean, save_invstd, workspace);
+    DAM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, workspace, l.parts, C,
+                       (double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef);
+    DAM_CHECK_LAUNCH();
+    const int64_t nq = n_pixels * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elt_blocks(nq)), dim3(256), 0, st, dy, y_mask, x, nq, C / 4, C, coef, dx);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int dam_channel_sum_f32(const float* x, int64_t n_pixels, int C, int n_real, float* out, float* workspace,
+                                   void* stream) {
+    if (!x || !out || !workspace || n_pixels <= 0 || n_real <= 0 || n_real > C) return DAM_ERR_BAD_ARG;
+    if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
+    const BnLaunch l = bn_plan(n_pixels, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * sizeof(float), st, x,
+                       n_pixels, C, l.q, l.r, l.ppb, workspace);
+    DAM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((unsigned)cdiv(n_real, 64)), dim3(64), 0, st, workspace, l.parts, C,
+                       n_real, out);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}

@@ -1,0 +1,358 @@
+// dam_head.hip -- per-stem gain heads, gain-weighted spectrogram sum, fused MSE.
+//
+// Replaces models/model_resnet.py:75-85,108-126 (identical code in models/model_scalar_1s.py:222-232,244-273
+// and models/model_scalar_2s.py:79-132):  for every stem s
+//     h_s = relu(conv1x1_s(trunk) + cb_s)          [B, P]      (P = flattened_dim, NCHW flatten == pixel order)
+//     g_s = fc_s(h_s) + fcb_s                       [B, 1]
+//     masked = sum_s g_s * x[:, s]                  [B, F, T]
+// and the MSELoss the trainer applies to `masked` (model_trainer.py:35), forward and backward.
+// All S heads are evaluated together: the trunk is read once (one wave per pixel, 16-byte loads),
+// instead of S separate 1x1 convolutions + S Linear layers + S+1 element-wise launches.
+#include "dam_common.h"
+
+namespace dam {
+namespace {
+
+constexpr int MAX_STEMS = 16;
+
+// h[b][s][p] = relu(cb[s] + sum_c trunk[b][p][c] * cw[s][c]);  one wave per pixel.
+__global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ trunk, int P, int C, int S,
+                                                        const float* __restrict__ cw, const float* __restrict__ cb,
+                                                        float* __restrict__ h) {
+    extern __shared__ float w_s[];   // [S][C]
+    for (int e = threadIdx.x; e < S * C; e += blockDim.x) w_s[e] = cw[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int Q = C / 4;
+    for (int p = blockIdx.x * 4 + wave; p < P; p += gridDim.x * 4) {
+        float acc[MAX_STEMS];
+#pragma unroll
+        for (int s = 0; s < MAX_STEMS; ++s) acc[s] = 0.f;
+        const float4* row = reinterpret_cast<const float4*>(trunk + ((size_t)b * P + p) * C);
+        for (int q = lane; q < Q; q += 64) {
+            const float4 v = row[q];
+#pragma unroll
+            for (int s = 0; s < MAX_STEMS; ++s) {
+                if (s < S) {
+                    const float4 w = reinterpret_cast<const float4*>(w_s + s * C)[q];
+                    acc[s] = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, acc[s]))));
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < MAX_STEMS; ++s) {
+            if (s < S) {
+                const float t = wave_sum64(acc[s]);
+                if (lane == 0) h[((size_t)b * S + s) * P + p] = fmaxf(t + cb[s], 0.f);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {   // blockDim.x == 256
+    v = wave_sum64(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// g[b][s] = fcb[s] + sum_p fcw[s][p] * h[b][s][p];  grid (S, B)
+__global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ h, int P, int S,
+                                                      const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                                      float* __restrict__ g) {
+    __shared__ float red[4];
+    const int s = blockIdx.x, b = blockIdx.y;
+    const float* hr = h + ((size_t)b * S + s) * P;
+    const float* wr = fcw + (size_t)s * P;
+    float a = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) a = fmaf(hr[p], wr[p], a);
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) g[b * S + s] = a + fcb[s];
+}
+
+// e[b][s][p] = dg[b][s] * fcw[s][p] * (h > 0);  dtrunk[b][p][:] = sum_s e * cw[s][:]
+__global__ __launch_bounds__(256) void head_bwd_pixel_kernel(const float* __restrict__ dg, const float* __restrict__ h,
+                                                             int P, int C, int S, const float* __restrict__ cw,
+                                                             const float* __restrict__ fcw, float* __restrict__ e_out,
+                                                             float* __restrict__ dtrunk) {
+    extern __shared__ float w_s[];   // [S][C]
+    for (int e = threadIdx.x; e < S * C; e += blockDim.x) w_s[e] = cw[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int Q = C / 4;
+    for (int p = blockIdx.x * 4 + wave; p < P; p += gridDim.x * 4) {
+        float ev[MAX_STEMS];
+#pragma unroll
+        for (int s = 0; s < MAX_STEMS; ++s) {
+            ev[s] = 0.f;
+            if (s < S) {
+                const size_t i = ((size_t)b * S + s) * P + p;
+                ev[s] = h[i] > 0.f ? dg[b * S + s] * fcw[(size_t)s * P + p] : 0.f;
+                if (lane == 0) e_out[i] = ev[s];
+            }
+        }
+        float4* row = reinterpret_cast<float4*>(dtrunk + ((size_t)b * P + p) * C);
+        for (int q = lane; q < Q; q += 64) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < MAX_STEMS; ++s) {
+                if (s < S) {
+                    const float4 w = reinterpret_cast<const float4*>(w_s + s * C)[q];
+                    o.x = fmaf(ev[s], w.x, o.x); o.y = fmaf(ev[s], w.y, o.y);
+                    o.z = fmaf(ev[s], w.z, o.z); o.w = fmaf(ev[s], w.w, o.w);
+                }
+            }
+            row[q] = o;
+        }
+    }
+}
+
+// dfcw[s][p] = sum_b dg[b][s] * h[b][s][p];  dfcb[s] = sum_b dg[b][s]
+__global__ void head_bwd_fc_kernel(const float* __restrict__ dg, const float* __restrict__ h, int B, int P, int S,
+                                   float* __restrict__ dfcw, float* __restrict__ dfcb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S * P) {
+        const int s = i / P, p = i - s * P;
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a = fmaf(dg[b * S + s], h[((size_t)b * S + s) * P + p], a);
+        dfcw[i] = a;
+    }
+    if (i < S) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dg[b * S + i];
+        dfcb[i] = a;
+    }
+}
+
+// partial[blk][s][c] = sum over the block's (b,p) range of e[b][s][p] * trunk[b][p][c]; last column: sum e
+__global__ void head_bwd_cw_partial_kernel(const float* __restrict__ e, const float* __restrict__ trunk, int B, int P,
+                                           int C, int S, int Q, int R, int64_t ppb, float* __restrict__ partial) {
+    extern __shared__ float sm[];    // [R][S][C]
+    const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
+    const int64_t BP = (int64_t)B * P;
+    const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < BP) ? lo + ppb : BP;
+    float acc[MAX_STEMS][4];
+#pragma unroll
+    for (int s = 0; s < MAX_STEMS; ++s) { acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0.f; }
+    for (int64_t bp = lo + pr; bp < hi; bp += R) {
+        const int b = (int)(bp / P), p = (int)(bp - (int64_t)b * P);
+        const float4 v = *reinterpret_cast<const float4*>(trunk + bp * C + cq * 4);
+#pragma unroll
+        for (int s = 0; s < MAX_STEMS; ++s) {
+            if (s < S) {
+                const float ev = e[((size_t)b * S + s) * P + p];
+                acc[s][0] = fmaf(ev, v.x, acc[s][0]); acc[s][1] = fmaf(ev, v.y, acc[s][1]);
+                acc[s][2] = fmaf(ev, v.z, acc[s][2]); acc[s][3] = fmaf(ev, v.w, acc[s][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < MAX_STEMS; ++s)
+        if (s < S)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sm[((size_t)pr * S + s) * C + cq * 4 + i] = acc[s][i];
+    __syncthreads();
+    if (pr == 0) {
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = 0.f;
+                for (int r = 0; r < R; ++r) a += sm[((size_t)r * S + s) * C + cq * 4 + i];
+                partial[((size_t)blockIdx.x * S + s) * C + cq * 4 + i] = a;
+            }
+    }
+}
+__global__ void head_bwd_cw_finalize_kernel(const float* __restrict__ partial, int parts, int C, int S,
+                                            float* __restrict__ dcw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S * C) {
+        double a = 0;
+        for (int p = 0; p < parts; ++p) a += partial[(size_t)p * S * C + i];
+        dcw[i] = (float)a;
+    }
+}
+// dcb[s] = sum_{b,p} e[b][s][p];  grid S
+__global__ __launch_bounds__(256) void head_bwd_cb_kernel(const float* __restrict__ e, int B, int P, int S,
+                                                          float* __restrict__ dcb) {
+    __shared__ float red[4];
+    const int s = blockIdx.x;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* er = e + ((size_t)b * S + s) * P;
+        for (int p = threadIdx.x; p < P; p += 256) a += er[p];
+    }
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) dcb[s] = a;
+}
+
+// masked[b][i] = sum_s g[b][s] * x[b][s][i]
+__global__ void masksum_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, int S, int64_t FT,
+                                   float* __restrict__ masked) {
+    const int b = blockIdx.y;
+    float gv[MAX_STEMS];
+#pragma unroll
+    for (int s = 0; s < MAX_STEMS; ++s) gv[s] = s < S ? g[b * S + s] : 0.f;
+    const float* xb = x + (size_t)b * S * FT;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < FT; i += (int64_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAX_STEMS; ++s)
+            if (s < S) a = fmaf(gv[s], xb[(size_t)s * FT + i], a);
+        masked[(size_t)b * FT + i] = a;
+    }
+}
+
+// partial[b][blk][s] = sum_i d[b][i] * x[b][s][i]  where d = dmasked (MODE 0) or (masked - gt) (MODE 1, also sum d^2)
+template <int MODE>
+__global__ __launch_bounds__(256) void masksum_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                  const float* __restrict__ d_or_gt, int S, int64_t FT,
+                                                                  float* __restrict__ masked_out,
+                                                                  float* __restrict__ partial /* [B][nblk][S+1] */) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    float gv[MAX_STEMS], acc[MAX_STEMS + 1];
+#pragma unroll
+    for (int s = 0; s < MAX_STEMS; ++s) { gv[s] = (MODE == 1 && s < S) ? g[b * S + s] : 0.f; acc[s] = 0.f; }
+    acc[MAX_STEMS] = 0.f;
+    const float* xb = x + (size_t)b * S * FT;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < FT; i += (int64_t)gridDim.x * blockDim.x) {
+        float xv[MAX_STEMS];
+#pragma unroll
+        for (int s = 0; s < MAX_STEMS; ++s) xv[s] = s < S ? xb[(size_t)s * FT + i] : 0.f;
+        float d;
+        if (MODE == 1) {
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < MAX_STEMS; ++s) m = fmaf(gv[s], xv[s], m);
+            if (masked_out) masked_out[(size_t)b * FT + i] = m;
+            d = m - d_or_gt[(size_t)b * FT + i];
+            acc[MAX_STEMS] = fmaf(d, d, acc[MAX_STEMS]);
+        } else {
+            d = d_or_gt[(size_t)b * FT + i];
+        }
+#pragma unroll
+        for (int s = 0; s < MAX_STEMS; ++s) acc[s] = fmaf(d, xv[s], acc[s]);
+    }
+    float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (S + 1);
+    for (int s = 0; s < S; ++s) {
+        const float t = block_sum(acc[s], red);
+        if (threadIdx.x == 0) out[s] = t;
+    }
+    const float t = block_sum(acc[MAX_STEMS], red);
+    if (threadIdx.x == 0) out[S] = t;
+}
+// dg[b][s] = scale * sum_blk partial;  loss = sum of squared error / count   (MODE 1)
+__global__ void masksum_bwd_finalize_kernel(const float* __restrict__ partial, int B, int nblk, int S, double scale,
+                                            double inv_count, float* __restrict__ dg, float* __restrict__ loss) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * S) {
+        const int b = i / S, s = i - b * S;
+        double a = 0;
+        for (int k = 0; k < nblk; ++k) a += partial[((size_t)b * nblk + k) * (S + 1) + s];
+        dg[i] = (float)(a * scale);
+    }
+    if (i == 0 && loss) {
+        double a = 0;
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < nblk; ++k) a += partial[((size_t)b * nblk + k) * (S + 1) + S];
+        *loss = (float)(a * inv_count);
+    }
+}
+
+}  // namespace
+}  // namespace dam
+
+using namespace dam;
+
+extern "C" int dam_heads_fwd_f32(const float* trunk, int B, int P, int C, int S, const float* conv_w, const float* conv_b,
+                                 const float* fc_w, const float* fc_b, float* h, float* gains, void* stream) {
+    if (!trunk || !conv_w || !conv_b || !fc_w || !fc_b || !h || !gains || B <= 0 || P <= 0) return DAM_ERR_BAD_ARG;
+    if (C % 4 || S < 1 || S > MAX_STEMS || B > 65535) return DAM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = (int)(cdiv(P, 4) < 1024 ? cdiv(P, 4) : 1024);
+    hipLaunchKernelGGL(head_conv_kernel, dim3(gx, B), dim3(256), (size_t)S * C * sizeof(float), st, trunk, P, C, S, conv_w, conv_b, h);
+    DAM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_fc_kernel, dim3(S, B), dim3(256), 0, st, h, P, S, fc_w, fc_b, gains);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int64_t dam_heads_bwd_workspace_floats(int B, int P, int C, int S) {
+    return (int64_t)B * S * P + (int64_t)1024 * S * C;
+}
+
+extern "C" int dam_heads_bwd_f32(const float* dgains, const float* h, const float* trunk, int B, int P, int C, int S,
+                                 const float* conv_w, const float* fc_w, float* dtrunk, float* dconv_w, float* dconv_b,
+                                 float* dfc_w, float* dfc_b, float* workspace, void* stream) {
+    if (!dgains || !h || !trunk || !conv_w || !fc_w || !dtrunk || !dconv_w || !dconv_b || !dfc_w || !dfc_b || !workspace)
+        return DAM_ERR_BAD_ARG;
+    if (C % 16 || S < 1 || S > MAX_STEMS || B > 65535 || C > 1024) return DAM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    float* e = workspace;
+    float* partial = workspace + (size_t)B * S * P;
+    const int gx = (int)(cdiv(P, 4) < 1024 ? cdiv(P, 4) : 1024);
+    hipLaunchKernelGGL(head_bwd_pixel_kernel, dim3(gx, B), dim3(256), (size_t)S * C * sizeof(float), st, dgains, h, P, C, S,
+                       conv_w, fc_w, e, dtrunk);
+    DAM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_bwd_fc_kernel, dim3((unsigned)cdiv((int64_t)S * P, 256)), dim3(256), 0, st, dgains, h, B, P, S, dfc_w, dfc_b);
+    DAM_CHECK_LAUNCH();
+    const int Q = C / 4;
+    int R = 256 / Q; if (R < 1) R = 1;
+    while ((size_t)R * S * C * sizeof(float) > 60 * 1024 && R > 1) R >>= 1;
+    const int64_t BP = (int64_t)B * P;
+    int64_t parts = cdiv(BP, 256); if (parts > 1024) parts = 1024;
+    const int64_t ppb = cdiv(BP, parts);
+    parts = cdiv(BP, ppb);
+    hipLaunchKernelGGL(head_bwd_cw_partial_kernel, dim3((unsigned)parts), dim3(Q * R), (size_t)R * S * C * sizeof(float), st, e,
+                       trunk, B, P, C, S, Q, R, ppb, partial);
+    DAM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_bwd_cw_finalize_kernel, dim3((unsigned)cdiv((int64_t)S * C, 256)), dim3(256), 0, st, partial, (int)parts,
+                       C, S, dconv_w);
+    DAM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_bwd_cb_kernel, dim3(S), dim3(256), 0, st, e, B, P, S, dconv_b);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int dam_masksum_fwd_f32(const float* x, const float* gains, int B, int S, int64_t FT, float* masked, void* stream) {
+    if (!x || !gains || !masked || B <= 0 || FT <= 0) return DAM_ERR_BAD_ARG;
+    if (S < 1 || S > MAX_STEMS || B > 65535) return DAM_ERR_UNSUPPORTED;
+    const int gx = (int)(cdiv(FT, 256) < 512 ? cdiv(FT, 256) : 512);
+    hipLaunchKernelGGL(masksum_fwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, gains, S, FT, masked);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int64_t dam_masksum_workspace_floats(int B, int S) { return (int64_t)B * 256 * (S + 1); }
+
+extern "C" int dam_masksum_bwd_f32(const float* dmasked, const float* x, int B, int S, int64_t FT, float* dgains,
+                                   float* workspace, void* stream) {
+    if (!dmasked || !x || !dgains || !workspace || B <= 0 || FT <= 0) return DAM_ERR_BAD_ARG;
+    if (S < 1 || S > MAX_STEMS || B > 65535) return DAM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = (int)(cdiv(FT, 1024) < 256 ? cdiv(FT, 1024) : 256);
+    hipLaunchKernelGGL((masksum_bwd_partial_kernel<0>), dim3(gx, B), dim3(256), 0, st, x, (const float*)nullptr, dmasked, S, FT,
+                       (float*)nullptr, workspace);
+    DAM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(masksum_bwd_finalize_kernel, dim3((unsigned)cdiv(B * S, 64)), dim3(64), 0, st, workspace, B, gx, S, 1.0, 0.0,
+                       dgains, (float*)nullptr);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int dam_masksum_mse_f32(const float* x, const float* gains, const float* gt, int B, int S, int64_t FT,
+                                   float* masked, float* loss, float* dgains, float* workspace, void* stream) {
+    if (!x || !gains || !gt || !loss || !dgains || !workspace || B <= 0 || FT <= 0) return DAM_ERR_BAD_ARG;
+    if (S < 1 || S > MAX_STEMS || B > 65535) return DAM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = (int)(cdiv(FT, 1024) < 256 ? cdiv(FT, 1024) : 256);
+    hipLaunchKernelGGL((masksum_bwd_partial_kernel<1>), dim3(gx, B), dim3(256), 0, st, x, gains, gt, S, FT, masked, workspace);
+    DAM_CHECK_LAUNCH();
+    const double count = (double)B * (double)FT;
+    hipLaunchKernelGGL(masksum_bwd_finalize_kernel, dim3((unsigned)cdiv(B * S, 64)), dim3(64), 0, st, workspace, B, gx, S,
+                       2.0 / count, 1.0 / count, dgains, loss);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}

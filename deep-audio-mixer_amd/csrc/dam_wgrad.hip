@@ -34,12 +34,12 @@ struct WgradGeo {
     int tiles_n, tiles_k, tap_groups;
     int tiles_m, total_tiles, nsplit;
     int in_nchw, relu_in;
+    int TMW;                 // pixels per tile (256 or 128): 4 waves x TMW/4 pixels
 };
 
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int TMW = 256;     // pixels per tile (64 per wave)
 
 template <int TNB, int TKB, int TA, int TB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const float* __restrict__ X,
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
     const int a0 = tg * TA;
     const int HoWo = g.Ho * g.Wo;
     const int chunk_bytes = g.PR * g.PWT * 64;
+    const int TMW = g.TMW, WP = g.TMW >> 2;   // pixels per wave
     unsigned char* dy_s = smem + TKB * chunk_bytes;        // [TNB][TMW][16] floats
 
     PatchGeo pg;
@@ -88,11 +89,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
         __syncthreads();
 
         // this wave's 64 pixels, 4 per MFMA step; lane group kq owns pixel 4*t + kq
-        int p = p0 + wave * 64 + kq;
+        int p = p0 + wave * WP + kq;
         int pc = p < HoWo ? p : HoWo - 1;
         int oh = pc / g.Wo, ow = pc - oh * g.Wo;
-        for (int t = 0; t < 16; ++t) {
-            const int pl = wave * 64 + 4 * t + kq;
+        for (int t = 0; t < (WP >> 2); ++t) {
+            const int pl = wave * WP + 4 * t + kq;
             float av[TNB];
 #pragma unroll
             for (int nb = 0; nb < TNB; ++nb)
@@ -186,7 +187,7 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
     while (nsplit > 1 && (int64_t)nsplit * nx * NBLK * 256 > ws_floats) --nsplit;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
     g.nsplit = nsplit;
-    size_t lds = (size_t)TKB * g.PR * g.PWT * 64 + (size_t)TNB * TMW * 64;
+    size_t lds = (size_t)TKB * g.PR * g.PWT * 64 + (size_t)TNB * g.TMW * 64;
     if (lds < (size_t)NBLK * 1024) lds = (size_t)NBLK * 1024;
     if (lds > 160 * 1024) return DAM_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
@@ -234,17 +235,31 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     g.PWin = (Wo - 1) * stride + (kw - 1) * dil + 1;
     g.PWs = (int)cdiv(g.PWin, stride);
     g.PWT = g.PWs * stride;
-    int rows_out = (TMW + Wo - 2) / Wo + 1;
-    if (rows_out > Ho) rows_out = Ho;
-    g.PR = (rows_out - 1) * stride + (kh - 1) * dil + 1;
+    auto set_tile = [&](int tmw) {
+        int rows_out = (tmw + Wo - 2) / Wo + 1;
+        if (rows_out > Ho) rows_out = Ho;
+        g.TMW = tmw;
+        g.PR = (rows_out - 1) * stride + (kh - 1) * dil + 1;
+        g.tiles_m = (int)cdiv((int64_t)Ho * Wo, tmw);
+        g.total_tiles = g.tiles_m * B;
+    };
+    auto lds_bytes = [&](int tnb, int tkb) { return (size_t)tkb * g.PR * g.PWT * 64 + (size_t)tnb * g.TMW * 64; };
     g.nchunks = in_nchw ? 1 : C / 16;
     g.nblk = n_chan / 16;
-    g.tiles_m = (int)cdiv((int64_t)Ho * Wo, TMW);
-    g.total_tiles = g.tiles_m * B;
     g.in_nchw = in_nchw; g.relu_in = relu_in;
     const int k_real = C;
     hipStream_t st = (hipStream_t)stream;
-    const bool small = g.nchunks == 1 || g.nblk == 1;
+    // tile choice: 2x2 channel blocks when both sides have them and LDS allows two workgroups per CU
+    bool small = g.nchunks == 1 || g.nblk == 1;
+    set_tile(256);
+    if (!small && lds_bytes(2, 2) > 72 * 1024) {
+        set_tile(128);
+        if (lds_bytes(2, 2) > 72 * 1024) small = true;
+    }
+    if (small) {
+        set_tile(256);
+        if (lds_bytes(1, 1) > 72 * 1024) set_tile(128);
+    }
 #define DAM_WG(TN_, TK_, TA_, TB_) \
     return launch_wgrad<TN_, TK_, TA_, TB_>(g, x, dy, in_scale, in_shift, workspace, workspace_floats, dw, n_out, k_real, st)
     if (kw == 3 && kh == 3) { if (small) DAM_WG(1, 1, 3, 3); else DAM_WG(2, 2, 3, 3); }

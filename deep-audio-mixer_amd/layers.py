@@ -1,0 +1,304 @@
+"""Building blocks shared by the three models: autograd Functions whose forward AND backward are
+sequences of libdam_hip.so kernels (no torch arithmetic on the path), plus the nn.Modules that own
+the parameters under the reference's state_dict names.
+
+Granularity: one Function per conv+BN+ReLU block, per residual BasicBlock and for the gain heads, so
+that the backward pass can use the fused forms (BatchNorm backward -> dgrad with the residual
+gradient added in its epilogue, shortcut dgrad accumulated in place, one pass for all S heads).
+Activations between Functions are NHWC float32.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class ConvSpec:
+    """Static description of one convolution (not a tensor)."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, in_nchw=False):
+        self.cin, self.cout, self.k, self.stride, self.pad, self.dil, self.in_nchw = cin, cout, k, stride, pad, dil, in_nchw
+
+    def fwd(self, x, w, bias=None):
+        return ops.conv2d_fwd(x, ops.pack_weights(w), self.cout, self.k, self.k, self.stride, self.pad, self.dil,
+                              bias=bias, in_nchw=self.in_nchw)
+
+    def wgrad(self, x, dy):
+        return ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil, in_nchw=self.in_nchw)
+
+    def dgrad(self, dy, w, hw, **kw):
+        return ops.conv2d_dgrad(dy, ops.pack_weights(w, transpose=True), self.cin, hw[0], hw[1], self.k, self.k,
+                                self.stride, self.pad, self.dil, **kw)
+
+
+def _bn_fwd_stats(c, bn, training):
+    """(save_mean, save_invstd, scale, shift) for conv output c under nn.BatchNorm2d semantics."""
+    if training or bn.running_mean is None:
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        track = training and bn.track_running_stats
+        return ops.bn_stats(c, bn.weight, bn.bias, bn.running_mean if track else None,
+                            bn.running_var if track else None, bn.num_batches_tracked if track else None, mom, bn.eps)
+    return ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def _hw(x, in_nchw):
+    return (x.shape[2], x.shape[3]) if in_nchw else (x.shape[1], x.shape[2])
+
+
+class ConvBnReluFn(torch.autograd.Function):
+    """a = relu(bn(conv(x) [+ bias]))  -- ResNet stem (models/model_resnet.py:97) and
+    ConvBlock2d (models/model_scalar_1s.py:179-190 without the dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, spec, bn, training):
+        c = spec.fwd(x, w.detach(), None if bias is None else bias.detach())
+        mean, invstd, scale, shift = _bn_fwd_stats(c, bn, training)
+        a = ops.bn_apply(c, scale, shift, relu=True)
+        ctx.save_for_backward(x, w, c, a, gamma, mean, invstd)
+        ctx.spec, ctx.training, ctx.has_bias = spec, training, bias is not None
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, w, c, a, gamma, mean, invstd = ctx.saved_tensors
+        spec = ctx.spec
+        dc, dgamma, dbeta = ops.bn_backward(da.contiguous(), a, c, gamma, mean, invstd, ctx.training)
+        dw = spec.wgrad(x, dc)
+        dbias = ops.channel_sum(dc, spec.cout) if ctx.has_bias else None
+        dx = spec.dgrad(dc, w, _hw(x, spec.in_nchw)) if ctx.needs_input_grad[0] else None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None
+
+
+class BasicBlockFn(torch.autograd.Function):
+    """models/model_resnet.py:23-28: relu(bn2(conv2(relu(bn1(conv1(x))))) + shortcut(x))."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wsc, gsc, bsc, blk, training):
+        c1 = blk.spec1.fwd(x, w1.detach())
+        m1, i1, sc1, sh1 = _bn_fwd_stats(c1, blk.bn1, training)
+        a1 = ops.bn_apply(c1, sc1, sh1, relu=True)
+        c2 = blk.spec2.fwd(a1, w2.detach())
+        m2, i2, sc2, sh2 = _bn_fwd_stats(c2, blk.bn2, training)
+        if wsc is not None:
+            cs = blk.spec_sc.fwd(x, wsc.detach())
+            ms, is_, scs, shs = _bn_fwd_stats(cs, blk.shortcut[1], training)
+            out = ops.bn_apply(c2, sc2, sh2, relu=True, res=cs, res_scale=scs, res_shift=shs)
+            ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, wsc, gsc, cs, ms, is_)
+        else:
+            out = ops.bn_apply(c2, sc2, sh2, relu=True, res=x)
+            ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2)
+        ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk, tr = ctx.blk, ctx.training
+        if ctx.has_sc:
+            x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, wsc, gsc, cs, ms, is_ = ctx.saved_tensors
+        else:
+            x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2 = ctx.saved_tensors
+        dout = dout.contiguous()
+        hw = (x.shape[1], x.shape[2])
+        dc2, dg2, db2 = ops.bn_backward(dout, out, c2, g2, m2, i2, tr)
+        dw2 = blk.spec2.wgrad(a1, dc2)
+        da1 = blk.spec2.dgrad(dc2, w2, (a1.shape[1], a1.shape[2]))
+        dc1, dg1, db1 = ops.bn_backward(da1, a1, c1, g1, m1, i1, tr)
+        dw1 = blk.spec1.wgrad(x, dc1)
+        if ctx.has_sc:
+            dcs, dgs, dbs = ops.bn_backward(dout, out, cs, gsc, ms, is_, tr)
+            dws = blk.spec_sc.wgrad(x, dcs)
+            dx = blk.spec1.dgrad(dc1, w1, hw)
+            blk.spec_sc.dgrad(dcs, wsc, hw, accumulate_into=dx)
+            return dx, dw1, dg1, db1, dw2, dg2, db2, dws, dgs, dbs, None, None
+        dx = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out)      # + dout * (out > 0): identity shortcut
+        return dx, dw1, dg1, db1, dw2, dg2, db2, None, None, None, None, None
+
+
+class HeadsFn(torch.autograd.Function):
+    """All S heads + the gain-weighted sum (models/model_resnet.py:108-126)."""
+
+    @staticmethod
+    def forward(ctx, trunk, x, cw, cb, fw, fb):
+        h, g = ops.heads_fwd(trunk, cw.detach(), cb.detach(), fw.detach(), fb.detach())
+        masked = ops.masksum_fwd(x, g)
+        ctx.save_for_backward(trunk, x, h, cw, fw)
+        ctx.set_materialize_grads(False)
+        return masked, g
+
+    @staticmethod
+    def backward(ctx, dmasked, dg_out):
+        trunk, x, h, cw, fw = ctx.saved_tensors
+        dg = None
+        if dmasked is not None:
+            dg = ops.masksum_bwd(dmasked.contiguous(), x)
+        if dg_out is not None:
+            dg = dg_out.contiguous() if dg is None else dg + dg_out
+        if dg is None:
+            return None, None, None, None, None, None
+        dtrunk, dcw, dcb, dfw, dfb = ops.heads_bwd(dg, h, trunk, cw, fw)
+        return dtrunk, None, dcw, dcb, dfw, dfb
+
+
+class HeadsMseFn(torch.autograd.Function):
+    """Heads + masked sum + MSELoss(masked, gt) in one Function: the loss and d loss/d gains come out of a
+    single pass over x (dam_masksum_mse_f32).  Returns (loss, masked, gains); only loss carries gradient."""
+
+    @staticmethod
+    def forward(ctx, trunk, x, gt, cw, cb, fw, fb):
+        h, g = ops.heads_fwd(trunk, cw.detach(), cb.detach(), fw.detach(), fb.detach())
+        masked, loss, dg = ops.masksum_mse(x, g, gt.contiguous())
+        ctx.save_for_backward(trunk, h, cw, fw, dg)
+        ctx.mark_non_differentiable(masked, g)
+        return loss.reshape(()), masked, g
+
+    @staticmethod
+    def backward(ctx, dloss, _dm, _dg):
+        trunk, h, cw, fw, dg = ctx.saved_tensors
+        dtrunk, dcw, dcb, dfw, dfb = ops.heads_bwd(dg * dloss, h, trunk, cw, fw)
+        return dtrunk, None, None, dcw, dcb, dfw, dfb
+
+
+class BasicBlock(nn.Module):
+    """Parameter container with the reference's names (models/model_resnet.py:6-21); forward = BasicBlockFn."""
+    expansion = 1
+
+    def __init__(self, in_channels, out_channels, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_channels != self.expansion * out_channels:
+            self.shortcut = nn.Sequential(
+                nn.Conv2d(in_channels, self.expansion * out_channels, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(self.expansion * out_channels))
+        self.spec1 = ConvSpec(in_channels, out_channels, 3, stride, 1)
+        self.spec2 = ConvSpec(out_channels, out_channels, 3, 1, 1)
+        self.spec_sc = ConvSpec(in_channels, out_channels, 1, stride, 0) if len(self.shortcut) else None
+
+    def forward(self, x):
+        if self.spec_sc is not None:
+            sc, sbn = self.shortcut[0], self.shortcut[1]
+            return BasicBlockFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                      self.bn2.weight, self.bn2.bias, sc.weight, sbn.weight, sbn.bias, self, self.training)
+        return BasicBlockFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                  self.bn2.weight, self.bn2.bias, None, None, None, self, self.training)
+
+
+class ConvBlock2d(nn.Module):
+    """models/model_scalar_1s.py:151-190: Conv2D(valid, bias) -> BatchNorm(momentum .9, eps 1e-3) -> ReLU -> Dropout
+    (dropout only while self.training, as in the reference)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, dropout_p=-1.0, in_nchw=False):
+        super().__init__()
+        self.add_padding = None
+        self.conv = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size,
+                              stride=stride, padding=0, dilation=dilation)
+        self.batch_norm = nn.BatchNorm2d(num_features=out_channels, momentum=0.90, eps=0.001)
+        self.activation = nn.ReLU()
+        self.dropout = nn.Dropout(dropout_p) if dropout_p != -1 else None
+        self.spec = ConvSpec(in_channels, out_channels, kernel_size, stride, 0, dilation, in_nchw=in_nchw)
+
+    def forward(self, x):
+        out = ConvBnReluFn.apply(x, self.conv.weight, self.conv.bias, self.batch_norm.weight, self.batch_norm.bias,
+                                 self.spec, self.batch_norm, self.training)
+        if self.training and self.dropout:
+            out = self.dropout(out)
+        return out
+
+
+class GainHeads(nn.Module):
+    """The S (conv1x1 -> ReLU -> Linear) heads, stored stacked ([S,C], [S], [S,P], [S]) so that one kernel serves all
+    stems; state_dict()/load_state_dict() speak the reference's per-stem keys conv_head{i}.weight [1,C,1,1],
+    conv_head{i}.bias [1], fc_head{i}.weight [1,P], fc_head{i}.bias [1] (models/model_resnet.py:75-85)."""
+
+    def __init__(self, channels, n_stems, flattened_dim):
+        super().__init__()
+        self.n_stems, self.channels, self.flattened_dim = n_stems, channels, flattened_dim
+        cw, cb, fw, fb = [], [], [], []
+        for _ in range(n_stems):   # same construction order (and RNG draws) as the reference
+            conv, fc = nn.Conv2d(channels, 1, kernel_size=(1, 1)), nn.Linear(flattened_dim, 1)
+            cw.append(conv.weight.detach().view(1, channels)), cb.append(conv.bias.detach())
+            fw.append(fc.weight.detach()), fb.append(fc.bias.detach())
+        self.conv_w, self.conv_b = nn.Parameter(torch.cat(cw)), nn.Parameter(torch.cat(cb))
+        self.fc_w, self.fc_b = nn.Parameter(torch.cat(fw)), nn.Parameter(torch.cat(fb))
+
+    # --- reference-named views of the stacked parameters
+    def reference_items(self):
+        for i in range(self.n_stems):
+            yield 'conv_head%d.weight' % (i + 1), self.conv_w[i].view(1, self.channels, 1, 1)
+            yield 'conv_head%d.bias' % (i + 1), self.conv_b[i:i + 1]
+            yield 'fc_head%d.weight' % (i + 1), self.fc_w[i:i + 1]
+            yield 'fc_head%d.bias' % (i + 1), self.fc_b[i:i + 1]
+
+    def forward(self, trunk, x):
+        return HeadsFn.apply(trunk, x, self.conv_w, self.conv_b, self.fc_w, self.fc_b)
+
+    def forward_mse(self, trunk, x, gt):
+        return HeadsMseFn.apply(trunk, x, gt, self.conv_w, self.conv_b, self.fc_w, self.fc_b)
+
+
+class MixingNet(nn.Module):
+    """Common shell of the three models: a trunk producing NHWC features, GainHeads registered as `_heads`
+    with the reference's flat key names in state_dict, forward(x) -> (masked, (g_1..g_S))."""
+
+    def _init_heads(self, channels, n_stems, flattened_dim):
+        self._heads = GainHeads(channels, n_stems, flattened_dim)
+        self.n_stems = n_stems
+        self._register_state_dict_hook(MixingNet._sd_hook)
+        self._register_load_state_dict_pre_hook(self._load_hook)
+
+    @staticmethod
+    def _sd_hook(module, state_dict, prefix, local_metadata):
+        for k in ('conv_w', 'conv_b', 'fc_w', 'fc_b'):
+            state_dict.pop(prefix + '_heads.' + k, None)
+        for name, view in module._heads.reference_items():
+            state_dict[prefix + name] = view.detach()
+        return state_dict
+
+    def _load_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        h = self._heads
+        parts = {}
+        for i in range(h.n_stems):
+            for kind in ('conv_head%d.weight', 'conv_head%d.bias', 'fc_head%d.weight', 'fc_head%d.bias'):
+                key = prefix + kind % (i + 1)
+                if key in state_dict:
+                    parts.setdefault(kind, []).append(state_dict.pop(key))
+        if not parts:
+            return
+        if any(len(v) != h.n_stems for v in parts.values()) or len(parts) != 4:
+            error_msgs.append('incomplete per-stem head parameters in state_dict')
+            return
+        dev = h.conv_w.device
+        state_dict[prefix + '_heads.conv_w'] = torch.cat([t.reshape(1, h.channels) for t in parts['conv_head%d.weight']]).to(dev)
+        state_dict[prefix + '_heads.conv_b'] = torch.cat([t.reshape(1) for t in parts['conv_head%d.bias']]).to(dev)
+        state_dict[prefix + '_heads.fc_w'] = torch.cat([t.reshape(1, -1) for t in parts['fc_head%d.weight']]).to(dev)
+        state_dict[prefix + '_heads.fc_b'] = torch.cat([t.reshape(1) for t in parts['fc_head%d.bias']]).to(dev)
+
+    def trunk(self, x):
+        raise NotImplementedError
+
+    @staticmethod
+    def _check_input(x):
+        if x.dim() != 4:
+            raise ValueError('expected x of shape [B, S, F, T]')
+        if not x.is_cuda:
+            raise RuntimeError('deep_audio_mixer_amd models run on the GPU only (got a %s tensor); there is no CPU '
+                               'fallback' % x.device)
+        if x.dtype != torch.float32:
+            # the reference raises too ("expected scalar type Double but found Float")
+            raise RuntimeError('expected scalar type Float but found %s' % str(x.dtype).replace('torch.', '').capitalize())
+        return x.contiguous()
+
+    def forward(self, x):
+        x = self._check_input(x)
+        masked, g = self._heads(self.trunk(x), x)
+        return masked, tuple(g[:, s:s + 1] for s in range(self.n_stems))
+
+    def forward_mse(self, x, gt):
+        """Fused fast path for criterion == nn.MSELoss(): returns (loss, masked, gains tuple); masked and the
+        gains are detached outputs, loss carries the gradient."""
+        x = self._check_input(x)
+        loss, masked, g = self._heads.forward_mse(self.trunk(x), x, gt)
+        return loss, masked, tuple(g[:, s:s + 1] for s in range(self.n_stems))

@@ -146,3 +146,141 @@ def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in
                                       kh, kw, stride, pad, dil, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                       _lib.stream()), 'dam_conv2d_wgrad_f32')
     return out
+
+
+# ----------------------------------------------------------------------------- batch norm
+def _bn_ws(device, C):
+    return _workspace(device, _lib.lib().dam_bn_workspace_floats(C))
+
+
+def bn_stats(x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps):
+    """Training-mode statistics of NHWC x.  Returns (save_mean, save_invstd, scale, shift), updates the running buffers."""
+    _lib.require_cuda(x)
+    C = x.shape[-1]
+    P = x.numel() // C
+    out = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    ws = _bn_ws(x.device, C)
+    _lib.check(_lib.lib().dam_bn_stats_f32(_lib.ptr(x), P, C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                           _lib.ptr(running_var), _lib.ptr(num_batches_tracked), float(momentum), float(eps),
+                                           _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
+                                           _lib.ptr(ws), _lib.stream()), 'dam_bn_stats_f32')
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
+    _lib.require_cuda(gamma)
+    C = gamma.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    _lib.check(_lib.lib().dam_bn_eval_affine_f32(C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                                 _lib.ptr(running_var), float(eps), _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                                 _lib.ptr(out[2]), _lib.ptr(out[3]), _lib.stream()), 'dam_bn_eval_affine_f32')
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_apply(x, scale, shift, relu=True, res=None, res_scale=None, res_shift=None):
+    _lib.require_cuda(x)
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().dam_bn_apply_f32(_lib.ptr(x), x.numel() // C, C, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res),
+                                           _lib.ptr(res_scale), _lib.ptr(res_shift), 1 if relu else 0, _lib.ptr(y),
+                                           _lib.stream()), 'dam_bn_apply_f32')
+    return y
+
+
+def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True):
+    """Returns (dx, dgamma, dbeta) for y = [relu](bn(x) + ...); y_mask (the post-ReLU output) may be None."""
+    _lib.require_cuda(dy, x)
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    ws = _bn_ws(x.device, C)
+    _lib.check(_lib.lib().dam_bn_backward_f32(_lib.ptr(dy), _lib.ptr(y_mask), _lib.ptr(x), x.numel() // C, C, _lib.ptr(gamma),
+                                              _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0, _lib.ptr(dx),
+                                              _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(ws), _lib.stream()),
+               'dam_bn_backward_f32')
+    return dx, dgb[0], dgb[1]
+
+
+def channel_sum(x, n_real):
+    _lib.require_cuda(x)
+    C = x.shape[-1]
+    out = torch.empty(n_real, dtype=torch.float32, device=x.device)
+    ws = _bn_ws(x.device, C)
+    _lib.check(_lib.lib().dam_channel_sum_f32(_lib.ptr(x), x.numel() // C, C, n_real, _lib.ptr(out), _lib.ptr(ws),
+                                              _lib.stream()), 'dam_channel_sum_f32')
+    return out
+
+
+# ----------------------------------------------------------------------------- heads / mask-sum / loss
+def heads_fwd(trunk, conv_w, conv_b, fc_w, fc_b):
+    """trunk NHWC [B,h,w,C]; conv_w [S,C]; conv_b [S]; fc_w [S,P]; fc_b [S] -> (h [B,S,P], gains [B,S])."""
+    _lib.require_cuda(trunk)
+    B, C = trunk.shape[0], trunk.shape[-1]
+    P = trunk.numel() // (B * C)
+    S = conv_w.shape[0]
+    if fc_w.shape != (S, P):
+        raise ValueError('fc_head expects %d inputs but the trunk gives %d (flattened_dim mismatch)' % (fc_w.shape[1], P))
+    h = torch.empty((B, S, P), dtype=torch.float32, device=trunk.device)
+    g = torch.empty((B, S), dtype=torch.float32, device=trunk.device)
+    _lib.check(_lib.lib().dam_heads_fwd_f32(_lib.ptr(trunk), B, P, C, S, _lib.ptr(conv_w), _lib.ptr(conv_b), _lib.ptr(fc_w),
+                                            _lib.ptr(fc_b), _lib.ptr(h), _lib.ptr(g), _lib.stream()), 'dam_heads_fwd_f32')
+    return h, g
+
+
+def heads_bwd(dgains, h, trunk, conv_w, fc_w):
+    B, S, P = h.shape
+    C = trunk.shape[-1]
+    dev = trunk.device
+    dtrunk = torch.empty_like(trunk)
+    dcw, dcb = torch.empty((S, C), dtype=torch.float32, device=dev), torch.empty(S, dtype=torch.float32, device=dev)
+    dfw, dfb = torch.empty((S, P), dtype=torch.float32, device=dev), torch.empty(S, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    ws = _workspace(dev, L.dam_heads_bwd_workspace_floats(B, P, C, S))
+    _lib.check(L.dam_heads_bwd_f32(_lib.ptr(dgains), _lib.ptr(h), _lib.ptr(trunk), B, P, C, S, _lib.ptr(conv_w), _lib.ptr(fc_w),
+                                   _lib.ptr(dtrunk), _lib.ptr(dcw), _lib.ptr(dcb), _lib.ptr(dfw), _lib.ptr(dfb), _lib.ptr(ws),
+                                   _lib.stream()), 'dam_heads_bwd_f32')
+    return dtrunk, dcw, dcb, dfw, dfb
+
+
+def masksum_fwd(x, gains):
+    """x [B,S,F,T], gains [B,S] -> masked [B,F,T]."""
+    _lib.require_cuda(x, gains)
+    B, S, F, T = x.shape
+    masked = torch.empty((B, F, T), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().dam_masksum_fwd_f32(_lib.ptr(x), _lib.ptr(gains), B, S, F * T, _lib.ptr(masked), _lib.stream()),
+               'dam_masksum_fwd_f32')
+    return masked
+
+
+def masksum_bwd(dmasked, x):
+    B, S, F, T = x.shape
+    dg = torch.empty((B, S), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = _workspace(x.device, L.dam_masksum_workspace_floats(B, S))
+    _lib.check(L.dam_masksum_bwd_f32(_lib.ptr(dmasked), _lib.ptr(x), B, S, F * T, _lib.ptr(dg), _lib.ptr(ws), _lib.stream()),
+               'dam_masksum_bwd_f32')
+    return dg
+
+
+def masksum_mse(x, gains, gt, want_masked=True):
+    """Fused masked-sum + MSE: returns (masked or None, loss [1], dloss/dgains [B,S])."""
+    _lib.require_cuda(x, gains, gt)
+    B, S, F, T = x.shape
+    dev = x.device
+    masked = torch.empty((B, F, T), dtype=torch.float32, device=dev) if want_masked else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dg = torch.empty((B, S), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    ws = _workspace(dev, L.dam_masksum_workspace_floats(B, S))
+    _lib.check(L.dam_masksum_mse_f32(_lib.ptr(x), _lib.ptr(gains), _lib.ptr(gt), B, S, F * T, _lib.ptr(masked), _lib.ptr(loss),
+                                     _lib.ptr(dg), _lib.ptr(ws), _lib.stream()), 'dam_masksum_mse_f32')
+    return masked, loss, dg
+
+
+# ----------------------------------------------------------------------------- optimizer
+def adam_l2_step(params, grads, exp_avg, exp_avg_sq, step, derived, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    _lib.require_cuda(params, grads)
+    _lib.check(_lib.lib().dam_adam_l2_step_f32(_lib.ptr(params), _lib.ptr(grads), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                               params.numel(), _lib.ptr(step), _lib.ptr(derived), float(lr), float(beta1),
+                                               float(beta2), float(eps), float(weight_decay), float(grad_scale),
+                                               _lib.stream()), 'dam_adam_l2_step_f32')

@@ -116,6 +116,73 @@ int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, int in_nchw
                          int n_out, int kh, int kw, int stride, int pad, int dil, float* dw,
                          float* workspace, int64_t workspace_floats, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * BatchNorm2d on NHWC float32 [n_pixels][C], C % 16 == 0.  Replaces nn.BatchNorm2d + F.relu (+ the
+ * residual add) of models/model_resnet.py:12-27,65,97 and models/model_scalar_1s.py:174-186,
+ * models/model_scalar_2s.py:32-44, forward and backward.
+ * --------------------------------------------------------------------------------- */
+int64_t dam_bn_workspace_floats(int C);
+
+/* Training-mode statistics of x: save_mean, save_invstd = 1/sqrt(biased var + eps), the fused affine
+ * scale = gamma*invstd, shift = beta - mean*scale, and torch's running-stat update
+ * (running = (1-momentum)*running + momentum*stat, unbiased variance; ++*num_batches_tracked).
+ * running_mean/running_var/num_batches_tracked may be NULL. */
+int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
+                     float* shift, float* workspace, void* stream);
+
+/* Eval-mode equivalent: the same four outputs from the running statistics. */
+int dam_bn_eval_affine_f32(int C, const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, float* save_mean, float* save_invstd,
+                           float* scale, float* shift, void* stream);
+
+/* y = relu?( x*scale + shift  [+ res]  or  [+ res*res_scale + res_shift] ). */
+int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const float* scale, const float* shift,
+                     const float* res, const float* res_scale, const float* res_shift, int relu, float* y,
+                     void* stream);
+
+/* Backward of y = [relu](bn(x) [+ ...]): dz = dy * (y_mask > 0) (y_mask NULL: dz = dy);
+ * dgamma = sum dz*xhat, dbeta = sum dz, dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
+ * (training) or gamma*invstd*dz (training == 0, running statistics). */
+int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
+                        const float* gamma, const float* save_mean, const float* save_invstd, int training,
+                        float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
+
+/* out[c] = sum_p x[p][c] for c < n_real (gradient of a convolution bias, models/model_scalar_1s.py:167). */
+int dam_channel_sum_f32(const float* x, int64_t n_pixels, int C, int n_real, float* out, float* workspace,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Gain heads, gain-weighted sum and MSE.  Replace models/model_resnet.py:75-85,108-126 (same code in
+ * models/model_scalar_1s.py:222-273, models/model_scalar_2s.py:79-132) and nn.MSELoss at
+ * model_trainer.py:21,35.  trunk: NHWC [B][P][C]; conv_w [S][C], conv_b [S], fc_w [S][P], fc_b [S];
+ * h [B][S][P] (post-ReLU head activations, kept for backward); gains [B][S]; x [B][S][FT]; masked/gt [B][FT].
+ * --------------------------------------------------------------------------------- */
+int dam_heads_fwd_f32(const float* trunk, int B, int P, int C, int S, const float* conv_w, const float* conv_b,
+                      const float* fc_w, const float* fc_b, float* h, float* gains, void* stream);
+int64_t dam_heads_bwd_workspace_floats(int B, int P, int C, int S);
+int dam_heads_bwd_f32(const float* dgains, const float* h, const float* trunk, int B, int P, int C, int S,
+                      const float* conv_w, const float* fc_w, float* dtrunk, float* dconv_w, float* dconv_b,
+                      float* dfc_w, float* dfc_b, float* workspace, void* stream);
+int dam_masksum_fwd_f32(const float* x, const float* gains, int B, int S, int64_t FT, float* masked, void* stream);
+int64_t dam_masksum_workspace_floats(int B, int S);
+int dam_masksum_bwd_f32(const float* dmasked, const float* x, int B, int S, int64_t FT, float* dgains,
+                        float* workspace, void* stream);
+/* Fused: masked (optional output), loss = mean((masked-gt)^2), dgains = d loss / d gains, one pass over x. */
+int dam_masksum_mse_f32(const float* x, const float* gains, const float* gt, int B, int S, int64_t FT,
+                        float* masked, float* loss, float* dgains, float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Optimizer.  Replaces optimizer.step() at model_trainer.py:37 for torch.optim.Adam(params,
+ * weight_decay=wd) (training.ipynb cell 11; L2 folded into the gradient, not AdamW) over one flat
+ * parameter buffer.  step: device int64 counter (incremented here); derived2: device float[2] scratch.
+ * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce).
+ * --------------------------------------------------------------------------------- */
+int dam_adam_l2_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         int64_t* step, float* derived2, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,22 +156,29 @@ class RefMixingModelScalar2s(_RefScalar):
 
 
 def closed_form_fill(model: nn.Module, seed: int = 0):
-    """Deterministic parameter fill shared by the golden generator and the tests, so
-    that no multi-MB weight fixture is needed.  Conv/linear weights get
-    a scaled sinusoid of the flat index (fan-in scaled), BN affine params stay near
-    (1, 0), running stats are left at their defaults."""
+    """Deterministic parameter fill shared by the golden generator and the tests, so that no multi-MB
+    weight fixture is needed.  Values are an integer hash of (tensor index, flat
+    index) mapped to U(-0.5, 0.5) -- white-noise-like, portable (numpy integer arithmetic only).  Conv /
+    linear weights are scaled like Kaiming-uniform, BN gammas are 1 +- 0.1, biases / betas +- 0.05.
+    (A smooth closed form such as sin(a*i) gives near-degenerate filters: with it the reference's OWN float32
+    and float64 training-mode outputs differ by 2e-2; with this fill they agree to 2e-5.)"""
+    import numpy as np
+    u32 = np.uint64(0xffffffff)
     with torch.no_grad():
         for k, (name, p) in enumerate(model.named_parameters()):
-            n = p.numel()
-            i = torch.arange(n, dtype=torch.float64)
+            i = np.arange(p.numel(), dtype=np.uint64)
+            h = (i * np.uint64(2654435761) + np.uint64(k * 40503 + seed * 7919 + 12345)) & u32
+            h = ((h ^ (h >> np.uint64(15))) * np.uint64(2246822519)) & u32
+            h = ((h ^ (h >> np.uint64(13))) * np.uint64(3266489917)) & u32
+            h = h ^ (h >> np.uint64(16))
+            u = h.astype(np.float64) / 4294967296.0 - 0.5
             if p.dim() >= 2:
-                fan_in = p[0].numel()
-                v = torch.sin(0.37 * i + 1.3 * k + seed) * (1.2 / fan_in ** 0.5)
+                v = u * 2.0 * (3.0 / p[0].numel()) ** 0.5
             elif name.endswith('weight'):          # BN gamma
-                v = 1.0 + 0.1 * torch.sin(0.9 * i + k + seed)
+                v = 1.0 + 0.2 * u
             else:                                   # biases / BN beta
-                v = 0.05 * torch.cos(0.7 * i + k + seed)
-            p.copy_(v.reshape(p.shape).to(p.dtype))
+                v = 0.1 * u
+            p.copy_(torch.from_numpy(v).reshape(p.shape).to(p.dtype))
     return model
 
 

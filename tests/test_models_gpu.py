@@ -1,0 +1,158 @@
+"""GPU: the three models (all-HIP forward and backward through the C ABI) against
+  (a) the golden vectors produced by the reference itself in float64 (tests/golden/models.*), and
+  (b) the CPU oracle for the non-reference shapes of BASELINE.json's configs (S = 2 / 8 stems, 3 s clips).
+north_star tolerance: gains within 1e-4 relative (fp32); gradients are checked per parameter tensor."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _inputs import model_input
+from oracle import models_ref
+
+pytestmark = pytest.mark.gpu
+GAIN_RTOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dam(dam_lib):
+    import deep_audio_mixer_amd.models.model_resnet as mr
+    import deep_audio_mixer_amd.models.model_scalar_1s as m1
+    import deep_audio_mixer_amd.models.model_scalar_2s as m2
+    return {'resnet18': (mr.ResNet18, models_ref.RefResNet18),
+            'scalar1s': (m1.MixingModelScalar1s, models_ref.RefMixingModelScalar1s),
+            'scalar2s': (m2.MixingModelScalar2s, models_ref.RefMixingModelScalar2s)}
+
+
+def ref_named_grads(model):
+    """Gradients of the product model keyed by the REFERENCE parameter names."""
+    out = {}
+    for n, p in model.named_parameters():
+        if not n.startswith('_heads.'):
+            out[n] = p.grad
+    h = model._heads
+    for i in range(h.n_stems):
+        out['conv_head%d.weight' % (i + 1)] = h.conv_w.grad[i]
+        out['conv_head%d.bias' % (i + 1)] = h.conv_b.grad[i:i + 1]
+        out['fc_head%d.weight' % (i + 1)] = h.fc_w.grad[i]
+        out['fc_head%d.bias' % (i + 1)] = h.fc_b.grad[i:i + 1]
+    return out
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+
+
+def no_dropout(m):
+    for mod in m.modules():
+        if hasattr(mod, 'dropout_p'):
+            mod.dropout_p = -1          # oracle blocks
+        elif getattr(mod, 'dropout', None) is not None and not isinstance(mod, torch.nn.Dropout):
+            mod.dropout = None          # product blocks
+    return m
+
+
+@pytest.mark.parametrize('name', ['resnet18', 'scalar1s', 'scalar2s'])
+def test_against_reference_golden(dam, name, golden_dir):
+    data = np.load(os.path.join(golden_dir, 'models.npz'))
+    meta = json.load(open(os.path.join(golden_dir, 'models.json')))
+    ctor, ref_ctor = dam[name]
+    x, gt = model_input(*meta[name]['shape'], seed=meta[name]['seed'])
+    ref = models_ref.closed_form_fill(ref_ctor())
+    model = no_dropout(ctor())
+    model.load_state_dict(ref.state_dict())            # reference-keyed checkpoint loads
+    model = model.cuda().train()
+    xc, gtc = torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda()
+    masked, gains = model(xc)
+    assert masked.shape == gtc.shape and len(gains) == 4 and gains[0].shape == (x.shape[0], 1)
+    loss = torch.nn.functional.mse_loss(masked, gtc)
+    loss.backward()
+    key = name + '_f64_train'
+    g = torch.cat(gains, 1).detach().cpu().numpy()
+    assert rel_err(g, data[key + '_gains']) <= GAIN_RTOL
+    assert rel_err(masked.detach().cpu().numpy()[:, ::41, ::7], data[key + '_masked_sample']) <= GAIN_RTOL
+    assert abs(loss.item() - data[key + '_loss']) <= 2e-4 * abs(data[key + '_loss'])
+    grads = ref_named_grads(model)
+    names = meta[name + '_param_names']
+    norms = np.array([grads[n].double().norm().item() for n in names])
+    want = data[key + '_gradnorm']
+    # gradient tolerances are calibrated on the reference itself: its own float32 and float64 runs differ by
+    # 4e-3 in per-tensor gradient norms and 1.7e-2 (of the tensor's max) in sampled entries (ReLU decisions flip);
+    # conv biases in front of a training-mode BatchNorm have an exactly-zero true gradient, hence the absolute term
+    bad = [(n, a, b) for n, a, b in zip(names, norms, want) if abs(a - b) > 1e-2 * b + 1e-4 * want.max()]
+    assert not bad, bad[:5]
+    samples = np.array([[grads[n].flatten()[(j * grads[n].numel()) // 5].item() for j in range(5)] for n in names])
+    scale = np.abs(data[key + '_gradsample']).max(axis=1, keepdims=True) + 1e-4 * want.max()
+    assert np.max(np.abs(samples - data[key + '_gradsample']) / scale) <= 4e-2
+    sd = model.state_dict()
+    bn = np.concatenate([sd[k].double().cpu().numpy().ravel() for k in meta[name + '_bn_names']])
+    np.testing.assert_allclose(bn, data[key + '_bn_running'], rtol=2e-4, atol=1e-5)
+    # eval mode uses the running statistics
+    model2 = no_dropout(ctor())
+    model2.load_state_dict(ref.state_dict())
+    model2 = model2.cuda().eval()
+    with torch.no_grad():
+        _, gains = model2(xc)
+    assert rel_err(torch.cat(gains, 1).cpu().numpy(), data[name + '_f64_eval_gains']) <= GAIN_RTOL
+    # the state_dict written back is reference-shaped
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == meta[name]['state_dict']
+
+
+@pytest.mark.parametrize('name,n_stems,shape', [('resnet18', 8, (1025, 130)), ('scalar2s', 4, (1025, 130)),
+                                                 ('scalar1s', 2, (1025, 63))])
+def test_baseline_configs_against_oracle(dam, name, n_stems, shape):
+    """BASELINE.json configs C1-C3 (stem counts / clip lengths the reference cannot express)."""
+    ctor, ref_ctor = dam[name]
+    torch.manual_seed(3)
+    ref = no_dropout(ref_ctor(n_stems=n_stems, input_shape=shape)).double().train()
+    model = no_dropout(ctor(n_stems=n_stems, input_shape=shape))
+    model.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    model = model.cuda().train()
+    x, gt = model_input(2, n_stems, shape[0], shape[1], seed=21)
+    torch.set_num_threads(16)
+    masked_r, gains_r = ref(torch.from_numpy(x).double())
+    loss_r = torch.nn.functional.mse_loss(masked_r, torch.from_numpy(gt).double())
+    loss_r.backward()
+    loss, masked, gains = model.forward_mse(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda())
+    loss.backward()
+    assert rel_err(torch.cat(gains, 1).detach().cpu().numpy(), torch.cat(gains_r, 1).detach().numpy()) <= GAIN_RTOL
+    assert abs(loss.item() - loss_r.item()) <= 2e-4 * loss_r.item()
+    assert rel_err(masked.cpu().numpy(), masked_r.detach().numpy()) <= GAIN_RTOL
+    grads = ref_named_grads(model)
+    gmax = max(p.grad.norm().item() for p in ref.parameters())
+    for n, p in ref.named_parameters():
+        a, b = grads[n].double().cpu().flatten(), p.grad.flatten()
+        assert (a - b).norm().item() <= 2e-2 * b.norm().item() + 1e-5 * gmax, n
+
+
+def test_forward_mse_equals_unfused(dam):
+    ctor, _ = dam['resnet18']
+    torch.manual_seed(0)
+    m = ctor(n_stems=4, input_shape=(257, 64)).cuda().train()
+    x, gt = model_input(2, 4, 257, 64, seed=2)
+    xc, gtc = torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    masked, _ = m(xc)
+    torch.nn.functional.mse_loss(masked, gtc).backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    m.load_state_dict(state)
+    m.zero_grad()
+    loss, masked2, _ = m.forward_mse(xc, gtc)
+    loss.backward()
+    assert torch.equal(masked, masked2)
+    for a, p in zip(g1, m.parameters()):
+        assert (a - p.grad).norm() <= 1e-5 * a.norm() + 1e-12
+
+
+def test_wrong_inputs_fail_loudly(dam):
+    ctor, _ = dam['resnet18']
+    m = ctor().cuda()
+    with pytest.raises(RuntimeError, match='expected scalar type Float'):     # reference behaviour, SURVEY F4
+        m(torch.zeros(1, 4, 1025, 216, dtype=torch.float64, device='cuda'))
+    with pytest.raises(RuntimeError, match='GPU only'):
+        m(torch.zeros(1, 4, 1025, 216))
+    with pytest.raises(ValueError, match='flattened_dim'):                     # wrong clip length for this head width
+        m(torch.zeros(1, 4, 1025, 130, device='cuda'))
