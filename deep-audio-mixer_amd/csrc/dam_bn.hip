@@ -89,17 +89,17 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ x, int64_t P, 
     }
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int parts, int C,
+// One wave per channel: lanes merge a strided subset of the partials (Chan), then a shuffle tree merges the lanes.
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __restrict__ partial, int parts, int C,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ running_mean, float* __restrict__ running_var,
                                          long long* __restrict__ num_batches, float momentum, float eps,
                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                          float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches) *num_batches += 1;
-    if (c >= C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c == 0 && lane == 0 && num_batches) *num_batches += 1;
     double na = 0, ma = 0, qa = 0;
-    for (int p = 0; p < parts; ++p) {
+    for (int p = lane; p < parts; p += 64) {
         const float* o = partial + ((size_t)p * C + c) * 3;
         const double nb = o[0];
         if (nb == 0) continue;
@@ -108,6 +108,18 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int 
         qa += (double)o[2] + d * d * (na * nb / nn);
         na = nn;
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double nb = __shfl_down(na, off), mb = __shfl_down(ma, off), qb = __shfl_down(qa, off);
+        const double nn = na + nb;
+        if (nb != 0) {
+            const double d = mb - ma;
+            ma += d * (nb / nn);
+            qa += qb + d * d * (na * nb / nn);
+            na = nn;
+        }
+    }
+    if (lane != 0) return;
     const double var = qa / na;
     const float mean = (float)ma;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -198,14 +210,23 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float*
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int parts, int C, double count,
+__device__ __forceinline__ double wave_sum64_f64(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// One wave per channel.
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int parts, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0, s2 = 0;
-    for (int p = 0; p < parts; ++p) { s1 += partial[((size_t)p * C + c) * 2]; s2 += partial[((size_t)p * C + c) * 2 + 1]; }
+    for (int p = lane; p < parts; p += 64) { s1 += partial[((size_t)p * C + c) * 2]; s2 += partial[((size_t)p * C + c) * 2 + 1]; }
+    s1 = wave_sum64_f64(s1);
+    s2 = wave_sum64_f64(s2);
+    if (lane != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     const double g = (double)gamma[c] * invstd[c];
@@ -260,13 +281,13 @@ __global__ void channel_sum_partial_kernel(const float* __restrict__ x, int64_t 
         }
     }
 }
-__global__ void channel_sum_finalize_kernel(const float* __restrict__ partial, int parts, int C, int n_real,
+__global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const float* __restrict__ partial, int parts, int C, int n_real,
                                             float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_real) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s = 0;
-    for (int p = 0; p < parts; ++p) s += partial[(size_t)p * C + c];
-    out[c] = (float)s;
+    for (int p = lane; p < parts; p += 64) s += partial[(size_t)p * C + c];
+    s = wave_sum64_f64(s);
+    if (lane == 0) out[c] = (float)s;
 }
 
 inline int elt_blocks(int64_t n) {
@@ -293,7 +314,7 @@ extern "C" int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const f
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st,
                        x, n_pixels, C, l.q, l.r, l.ppb, workspace);
     DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, workspace, l.parts, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
                        gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
                        save_mean, save_invstd, scale, shift);
     DAM_CHECK_LAUNCH();
@@ -336,7 +357,7 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 2 * sizeof(float), st, dy,
                        y_mask, x, n_pixels, C, l.q, l.r, l.ppb, save_mean, save_invstd, workspace);
     DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, workspace, l.parts, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
                        (double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef);
     DAM_CHECK_LAUNCH();
     const int64_t nq = n_pixels * (C / 4);
@@ -354,7 +375,7 @@ extern "C" int dam_channel_sum_f32(const float* x, int64_t n_pixels, int C, int 
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * sizeof(float), st, x,
                        n_pixels, C, l.q, l.r, l.ppb, workspace);
     DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((unsigned)cdiv(n_real, 64)), dim3(64), 0, st, workspace, l.parts, C,
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(n_real), dim3(64), 0, st, workspace, l.parts, C,
                        n_real, out);
     DAM_CHECK_LAUNCH();
     return DAM_OK;

@@ -243,22 +243,23 @@ __global__ __launch_bounds__(256) void masksum_bwd_partial_kernel(const float* _
     const float t = block_sum(acc[MAX_STEMS], red);
     if (threadIdx.x == 0) out[S] = t;
 }
-// dg[b][s] = scale * sum_blk partial;  loss = sum of squared error / count   (MODE 1)
-__global__ void masksum_bwd_finalize_kernel(const float* __restrict__ partial, int B, int nblk, int S, double scale,
-                                            double inv_count, float* __restrict__ dg, float* __restrict__ loss) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// dg[b][s] = scale * sum_blk partial;  loss = sum of squared error / count   (MODE 1).  One wave per (b, s), last block: loss.
+__global__ __launch_bounds__(64) void masksum_bwd_finalize_kernel(const float* __restrict__ partial, int B, int nblk, int S,
+                                                                  double scale, double inv_count, float* __restrict__ dg,
+                                                                  float* __restrict__ loss) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    double a = 0;
     if (i < B * S) {
         const int b = i / S, s = i - b * S;
-        double a = 0;
-        for (int k = 0; k < nblk; ++k) a += partial[((size_t)b * nblk + k) * (S + 1) + s];
-        dg[i] = (float)(a * scale);
+        for (int k = lane; k < nblk; k += 64) a += partial[((size_t)b * nblk + k) * (S + 1) + s];
+    } else {
+        for (int k = lane; k < B * nblk; k += 64) a += partial[(size_t)k * (S + 1) + S];
     }
-    if (i == 0 && loss) {
-        double a = 0;
-        for (int b = 0; b < B; ++b)
-            for (int k = 0; k < nblk; ++k) a += partial[((size_t)b * nblk + k) * (S + 1) + S];
-        *loss = (float)(a * inv_count);
-    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off);
+    if (lane != 0) return;
+    if (i < B * S) dg[i] = (float)(a * scale);
+    else if (loss) *loss = (float)(a * inv_count);
 }
 
 }  // namespace
@@ -336,7 +337,7 @@ extern "C" int dam_masksum_bwd_f32(const float* dmasked, const float* x, int B, 
     hipLaunchKernelGGL((masksum_bwd_partial_kernel<0>), dim3(gx, B), dim3(256), 0, st, x, (const float*)nullptr, dmasked, S, FT,
                        (float*)nullptr, workspace);
     DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(masksum_bwd_finalize_kernel, dim3((unsigned)cdiv(B * S, 64)), dim3(64), 0, st, workspace, B, gx, S, 1.0, 0.0,
+    hipLaunchKernelGGL(masksum_bwd_finalize_kernel, dim3(B * S), dim3(64), 0, st, workspace, B, gx, S, 1.0, 0.0,
                        dgains, (float*)nullptr);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -351,7 +352,7 @@ extern "C" int dam_masksum_mse_f32(const float* x, const float* gains, const flo
     hipLaunchKernelGGL((masksum_bwd_partial_kernel<1>), dim3(gx, B), dim3(256), 0, st, x, gains, gt, S, FT, masked, workspace);
     DAM_CHECK_LAUNCH();
     const double count = (double)B * (double)FT;
-    hipLaunchKernelGGL(masksum_bwd_finalize_kernel, dim3((unsigned)cdiv(B * S, 64)), dim3(64), 0, st, workspace, B, gx, S,
+    hipLaunchKernelGGL(masksum_bwd_finalize_kernel, dim3(B * S + 1), dim3(64), 0, st, workspace, B, gx, S,
                        2.0 / count, 1.0 / count, dgains, loss);
     DAM_CHECK_LAUNCH();
     return DAM_OK;

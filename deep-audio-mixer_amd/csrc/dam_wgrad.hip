@@ -150,26 +150,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
     for (int e = tid; e < NBLK * 64; e += 256) out[e] = reinterpret_cast<const float4*>(red)[e];
 }
 
-// dW[n][k][kh][kw] = sum over splits of the slabs, in split order.
-__global__ void wgrad_reduce_kernel(const WgradGeo g, int TNB, int TKB, int TA, int TB, int n_real, int k_real,
-                                    const float* __restrict__ partial, float* __restrict__ dw, int nx) {
+// dW[n][k][kh][kw] = sum over splits of the slabs.  Block = 32 elements x 8 split lanes: every thread adds a
+// strided subset of the splits, the 8 subtotals are combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGeo g, int TNB, int TKB, int TA, int TB, int n_real,
+                                                           int k_real, const float* __restrict__ partial,
+                                                           float* __restrict__ dw, int nx) {
+    __shared__ float sub[8][32];
     const int nblk_tile = TNB * TKB * TA * TB;
     const int64_t per_split = (int64_t)nx * nblk_tile * 256;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < per_split; e += (int64_t)gridDim.x * blockDim.x) {
-        const int r = e & 3, lane = (e >> 2) & 63;
-        int64_t q = e >> 8;
-        const int blk = q % nblk_tile;
-        int xt = q / nblk_tile;
-        const int tb = blk % TB, ta = (blk / TB) % TA, kb = (blk / (TB * TA)) % TKB, nb = blk / (TB * TA * TKB);
-        const int tg = xt % g.tap_groups; xt /= g.tap_groups;
-        const int tk = xt % g.tiles_k, tn = xt / g.tiles_k;
-        const int n = (tn * TNB + nb) * 16 + (lane >> 4) * 4 + r;
-        const int k = (tk * TKB + kb) * 16 + (lane & 15);
-        const int kh = tg * TA + ta;
-        if (n >= n_real || k >= k_real || kh >= g.KH) continue;
+    const int el = threadIdx.x & 31, ys = threadIdx.x >> 5;
+    for (int64_t e0 = (int64_t)blockIdx.x * 32; e0 < per_split; e0 += (int64_t)gridDim.x * 32) {
+        const int64_t e = e0 + el;
         float s = 0.f;
-        for (int y = 0; y < g.nsplit; ++y) s += partial[y * per_split + e];
-        dw[(((size_t)n * k_real + k) * g.KH + kh) * g.KW + tb] = s;
+        if (e < per_split)
+            for (int y = ys; y < g.nsplit; y += 8) s += partial[y * per_split + e];
+        sub[ys][el] = s;
+        __syncthreads();
+        if (ys == 0 && e < per_split) {
+            s = ((sub[0][el] + sub[1][el]) + (sub[2][el] + sub[3][el])) + ((sub[4][el] + sub[5][el]) + (sub[6][el] + sub[7][el]));
+            const int r = e & 3, lane = (e >> 2) & 63;
+            int64_t q = e >> 8;
+            const int blk = q % nblk_tile;
+            int xt = q / nblk_tile;
+            const int tb = blk % TB, ta = (blk / TB) % TA, kb = (blk / (TB * TA)) % TKB, nb = blk / (TB * TA * TKB);
+            const int tg = xt % g.tap_groups; xt /= g.tap_groups;
+            const int tk = xt % g.tiles_k, tn = xt / g.tiles_k;
+            const int n = (tn * TNB + nb) * 16 + (lane >> 4) * 4 + r;
+            const int k = (tk * TKB + kb) * 16 + (lane & 15);
+            const int kh = tg * TA + ta;
+            if (n < n_real && k < k_real && kh < g.KH) dw[(((size_t)n * k_real + k) * g.KH + kh) * g.KW + tb] = s;
+        }
+        __syncthreads();
     }
 }
 
@@ -202,7 +213,7 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
     hipLaunchKernelGGL((wgrad_kernel<TNB, TKB, TA, TB>), dim3(nx, nsplit), dim3(256), lds, st, g, X, dY, sc, sh, partial);
     DAM_CHECK_LAUNCH();
     const int64_t per_split = (int64_t)nx * NBLK * 256;
-    const int rb = (int)(cdiv(per_split, 256) < 1024 ? cdiv(per_split, 256) : 1024);
+    const int rb = (int)(cdiv(per_split, 32) < 2048 ? cdiv(per_split, 32) : 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, g, TNB, TKB, TA, TB, n_real, k_real, partial, dw, nx);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
