@@ -1,0 +1,157 @@
+"""MultitrackAudioDataset -- drop-in for the reference's data/dataset.py:16-304 with the feature front-end on
+the GPU (dam_stft_logmag_f32).
+
+Same constructor, ``__getitem__(i) -> (train_features [S,1025,T], gt_features [1025,T])``, ``__len__``,
+``compute_features(audio, window_size=2048, hop_length=1024)``, ``get_tracklist`` / ``get_num_songs`` /
+``get_song_durations`` and the same chunk <-> song index arithmetic (:97-113).  Differences, all explicit:
+  * items are float32 CUDA tensors (the reference yields float64 CPU tensors that its own ModelTrainer cannot
+    consume): use ``DataLoader(..., num_workers=0, pin_memory=False)``;
+  * audio comes from MedleyDB-layout WAV files read with the stdlib (``soundfile`` is not required), or from
+    in-memory arrays via ``MultitrackAudioDataset.from_arrays``;
+  * the per-item prints of the reference (:284,287-289) are behind ``verbose=True``;
+  * ``normalize=True`` enables the per-frame max-abs normalisation that is commented out at :159-160;
+  * ``tracklist`` may name any number of stems (last entry = the target mix).
+"""
+import os
+import random
+import time
+
+import numpy as np
+import torch
+from torch.utils import data
+
+from .. import features
+from .dataset_utils import read_wav, wav_num_frames
+
+
+class MultitrackAudioDataset(data.Dataset):
+    def __init__(self, base_path: str, songlist: list = None, chunk_length: int = 5, sr: int = 44100,
+                 seed: int = None, normalize: bool = False, compute_features: bool = True,
+                 augment_data: bool = False, *, tracklist=None, device=None, verbose=False, _arrays=None):
+        self._base_path = base_path
+        self._chunk_length = chunk_length
+        self._normalize = normalize
+        self._compute_features = compute_features
+        self._augment = augment_data
+        self._sr = sr
+        self._tracklist = list(tracklist) if tracklist else ['bass', 'drums', 'vocals', 'other', 'mix']
+        self._device = torch.device(device) if device is not None else torch.device('cuda')
+        self._verbose = verbose
+        self._arrays = _arrays
+        if _arrays is not None and not songlist:
+            songlist = list(_arrays.keys())
+        if not songlist:
+            songlist = [song_name for song_name in os.listdir(self._base_path)
+                        if os.path.isdir(os.path.join(self._base_path, song_name))]
+        self.songlist = songlist
+        if seed:
+            random.seed(seed)
+        random.shuffle(songlist)
+        self._len, self.song_durations = self._calculate_dataset_length()
+
+    @classmethod
+    def from_arrays(cls, songs: dict, **kwargs):
+        """songs: {song_name: {track_name: ndarray[n, channels] or [n]}} held in memory (no disk)."""
+        return cls(None, _arrays=songs, **kwargs)
+
+    # ---- index arithmetic (data/dataset.py:56-75, 97-113)
+    def _track_frames(self, song_name):
+        if self._arrays is not None:
+            return self._arrays[song_name][self._tracklist[-1]].shape[0], self._sr
+        return wav_num_frames(self._get_track_path(song_name, self._tracklist[-1]))
+
+    def _calculate_dataset_length(self) -> tuple:
+        total, durations = 0, []
+        for song_name in self.songlist:
+            n, sr = self._track_frames(song_name)
+            dur = n / sr
+            durations.append(dur)
+            total += int(dur / self._chunk_length)
+        return total, durations
+
+    def _get_track_path(self, song_name: str, track_name: str) -> str:
+        if track_name == 'mix':
+            return os.path.join(self._base_path, song_name, '{}_MIX.wav'.format(song_name))
+        return os.path.join(self._base_path, song_name, '{}_STEMS_JOINED'.format(song_name),
+                            '{}_STEM_{}.wav'.format(song_name, track_name.upper()))
+
+    def _calculate_song_index(self, chunk_i: int) -> tuple:
+        song_i = 0
+        n_chunks = int(self.song_durations[song_i] / self._chunk_length)
+        while chunk_i >= n_chunks and song_i < len(self.songlist) - 1:
+            chunk_i -= n_chunks
+            song_i += 1
+            n_chunks = int(self.song_durations[song_i] / self._chunk_length)
+        return song_i, chunk_i
+
+    # ---- features (data/dataset.py:132-162) on the GPU
+    def compute_features(self, audio, window_size: int = 2048, hop_length: int = 1024):
+        """audio: mono ndarray/tensor [n] (or [n, channels]: channels are averaged first).
+        Returns the dB spectrogram, float32 CUDA tensor [window_size/2+1, 1 + n // hop_length]."""
+        a = torch.as_tensor(audio)
+        if a.dtype not in (torch.float32, torch.float64):
+            a = a.to(torch.float64)
+        a = a.to(self._device)
+        return features.stft_logmag(a[None], window_size, hop_length, normalize=self._normalize)[0]
+
+    @staticmethod
+    def _augment_audio(audio, gain_from: float = 0.6, gain_to: float = 1.4):
+        """data/dataset.py:164-168."""
+        return np.random.uniform(gain_from, gain_to) * audio
+
+    @staticmethod
+    def _augment_features(feats, gain_from: float = 0.6, gain_to: float = 1.4):
+        """data/dataset.py:170-179: one dB offset per stem."""
+        gains_db = 20 * np.log10(np.random.uniform(gain_from, gain_to, size=len(feats)))
+        return feats + torch.as_tensor(gains_db, dtype=feats.dtype, device=feats.device)[:, None, None]
+
+    @staticmethod
+    def _stereo_to_mono(audio: np.ndarray) -> np.ndarray:
+        """data/dataset.py:181-183 (the GPU path fuses this mean into the STFT kernel's load)."""
+        return np.mean(audio, axis=1)
+
+    def _read_chunk(self, song_name, track_name, lo, hi):
+        if self._arrays is not None:
+            return np.asarray(self._arrays[song_name][track_name][lo:hi])
+        return read_wav(self._get_track_path(song_name, track_name), lo, hi)[0]
+
+    def _process_on_the_fly(self, song_i: int, chunk_i: int) -> tuple:
+        """data/dataset.py:185-210: all S+1 tracks of the chunk go through ONE front-end launch."""
+        song_name = self.songlist[song_i]
+        lo, hi = chunk_i * self._chunk_length * self._sr, (chunk_i + 1) * self._chunk_length * self._sr
+        chunks = [self._read_chunk(song_name, t, lo, hi) for t in self._tracklist]
+        chunks = [c[:, None] if c.ndim == 1 else c for c in chunks]
+        pcm = torch.from_numpy(np.stack(chunks)).to(self._device)          # [S+1, n, channels]
+        gain = None
+        if self._augment:        # one draw per track, the mix included (data/dataset.py:198-199)
+            gain = torch.tensor(np.random.uniform(0.6, 1.4, size=len(chunks)), dtype=torch.float32, device=self._device)
+        feats = features.stft_logmag(pcm, 2048, 1024, gain=gain, normalize=self._normalize)
+        return feats[:-1], feats[-1]
+
+    def __getitem__(self, index: int) -> tuple:
+        song_i, chunk_i = self._calculate_song_index(index)
+        if self._verbose:
+            print('Song {}, chunk {}'.format(self.songlist[song_i], chunk_i))
+        if not self._compute_features:
+            raise NotImplementedError('the pre-computed feature cache (data/dataset.py:213-268) is stale at the reference '
+                                      'HEAD (SURVEY F10) and out of scope')
+        tic = time.time()
+        train_features, gt_features = self._process_on_the_fly(song_i, chunk_i)
+        if self._verbose:
+            print('Features: {}'.format(time.time() - tic))
+        return train_features, gt_features
+
+    def __len__(self) -> int:
+        return self._len
+
+    def get_num_songs(self) -> int:
+        return len(self.songlist)
+
+    def get_song_durations(self) -> list:
+        return self.song_durations
+
+    def get_tracklist(self) -> list:
+        return self._tracklist
+
+    def compute_mean_loudness(self) -> dict:
+        raise NotImplementedError('BS.1770 loudness (pyloudnorm, data/dataset.py:115-130) is off the hot path')

@@ -284,3 +284,17 @@ def adam_l2_step(params, grads, exp_avg, exp_avg_sq, step, derived, lr, beta1, b
                                                params.numel(), _lib.ptr(step), _lib.ptr(derived), float(lr), float(beta1),
                                                float(beta2), float(eps), float(weight_decay), float(grad_scale),
                                                _lib.stream()), 'dam_adam_l2_step_f32')
+
+
+# ----------------------------------------------------------------------------- inference tail
+def gain_ramp_apply(audio, gains):
+    """audio [rows, n] (float32 or float64, CUDA), gains [n_gains] same dtype -> audio * piecewise-constant gain."""
+    _lib.require_cuda(audio, gains)
+    if audio.dtype != gains.dtype or audio.dtype not in (torch.float32, torch.float64):
+        raise TypeError('audio and gains must both be float32 or float64')
+    audio, gains = audio.contiguous(), gains.contiguous()
+    rows, n = audio.shape
+    out = torch.empty_like(audio)
+    _lib.check(_lib.lib().dam_gain_ramp_apply(_lib.ptr(audio), _lib.ptr(gains), 1 if audio.dtype == torch.float64 else 0,
+                                              rows, n, gains.numel(), _lib.ptr(out), _lib.stream()), 'dam_gain_ramp_apply')
+    return out

@@ -183,6 +183,14 @@ int dam_adam_l2_step_f32(float* params, const float* grads, float* exp_avg, floa
                          int64_t* step, float* derived2, float lr, float beta1, float beta2, float eps,
                          float weight_decay, float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Full-song inference tail.  Replaces inference_utils.py:12-41 (interpolate_mask) fused with :143
+ * (loaded_tracks[track] * mask): out[r][n] = audio[r][n] * gains[min(n / (n_samples / n_gains), n_gains-1)]
+ * for rows r (channels) of length n_samples; dtype float64 (is_f64) or float32.
+ * --------------------------------------------------------------------------------- */
+int dam_gain_ramp_apply(const void* audio, const void* gains, int is_f64, int64_t rows, int64_t n_samples,
+                        int n_gains, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,151 @@
+"""GPU: the drop-in API end to end -- Dataset items, ModelTrainer.fit (against the trajectory, stdout and checkpoint
+names recorded from the reference's own ModelTrainer), the fused Adam, full-song inference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _inputs import model_input
+from oracle import features_ref, inference_ref, models_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dam(dam_lib):
+    import deep_audio_mixer_amd as pkg
+    return pkg
+
+
+def test_dataset_items_match_oracle(dam):
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    from _inputs import feature_error
+    rng = np.random.default_rng(4)
+    sr = 16000
+    songs = {'s%d' % i: {t: 0.1 * rng.standard_normal((int(d * sr), 2)) for t in ('bass', 'drums', 'vocals', 'other', 'mix')}
+             for i, d in enumerate([3.2, 2.1])}
+    d = MultitrackAudioDataset.from_arrays(songs, chunk_length=1, sr=sr)
+    assert len(d) == 5
+    loader = torch.utils.data.DataLoader(d, batch_size=2, shuffle=False, num_workers=0)
+    batches = list(loader)
+    assert batches[0][0].shape == (2, 4, 1025, 16) and batches[0][1].shape == (2, 1025, 16) and batches[0][0].is_cuda
+    assert batches[0][0].dtype == torch.float32
+    for index in (0, 4):
+        x, gt = d[index]
+        song_i, chunk_i = d._calculate_song_index(index)
+        name = d.songlist[song_i]
+        pcm = np.stack([songs[name][t][chunk_i * sr:(chunk_i + 1) * sr] for t in d.get_tracklist()])
+        want_x, want_gt = features_ref.clip_features(pcm)
+        for s in range(4):
+            rel, db = feature_error(x[s].cpu().numpy(), want_x[s])
+            assert rel <= 2e-6 and db <= 2e-3
+        rel, db = feature_error(gt.cpu().numpy(), want_gt)
+        assert rel <= 2e-6 and db <= 2e-3
+    f = d.compute_features(songs['s0']['bass'][:sr].mean(1))
+    assert f.shape == (1025, 16)
+
+
+def test_trainer_matches_reference_run(dam, golden_dir, tmp_path, capsys, monkeypatch):
+    """tests/golden/trainer.json was recorded from the reference's ModelTrainer.fit (CPU, torch Adam) on the same
+    seeded batches and the same parameter fill: same stdout format, same checkpoint names, same loss trajectory."""
+    from deep_audio_mixer_amd.model_trainer import ModelTrainer
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    g = json.load(open(os.path.join(golden_dir, 'trainer.json')))
+    ref = models_ref.closed_form_fill(models_ref.RefResNet18())
+    model = ResNet18()
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda()
+    batches = [tuple(torch.from_numpy(a) for a in model_input(*g['shape'], seed=s)) for s in g['seeds']]
+    train, val = batches[:2], batches[2:]
+    monkeypatch.chdir(tmp_path)
+    os.mkdir('weights')
+    opt = Adam(model.parameters(), lr=g['lr'], weight_decay=1e-5)
+    trainer = ModelTrainer(model, torch.nn.MSELoss(), opt, torch.device('cuda'), model_name='resnet')
+    tl, vl = trainer.fit(train, val, g['start_epoch'], g['num_epochs'])
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == len(g['stdout'])
+    for got, want in zip(out, g['stdout']):
+        assert got.split(':')[0] == want.split(':')[0] and got.startswith(want[:10])     # same text, numbers checked below
+    files = sorted(os.listdir('weights'))
+    assert [f[:22] for f in files] == [f[:22] for f in g['files']]                        # mixmodel_resnet_1s_000N_
+    # trajectory over 4 Adam steps (lr 1e-4).  Adam's first updates are ~lr*sign(g): entries whose gradient is
+    # rounding-level flip sign between any two fp32 implementations, so the trajectory is compared at 1e-2
+    np.testing.assert_allclose(tl, g['train_loss'], rtol=1e-2)
+    np.testing.assert_allclose(vl, g['val_loss'], rtol=1e-2)
+    sd = torch.load(os.path.join('weights', files[-1]))
+    assert set(sd.keys()) == set(ref.state_dict().keys())
+    np.testing.assert_allclose(sd['bn1.running_mean'].cpu().numpy(), g['bn1_running_mean'], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(sd['conv1.weight'].flatten()[:8].cpu().numpy(), g['conv1_weight_head'], rtol=0, atol=3e-3)
+
+
+def test_fused_adam_matches_torch_adam(dam):
+    from deep_audio_mixer_amd.optim import Adam
+    torch.manual_seed(0)
+    ps = [torch.randn(257, 33, device='cuda'), torch.randn(1000, device='cuda'), torch.randn(3, 3, 3, 3, device='cuda')]
+    a = [torch.nn.Parameter(p.clone()) for p in ps]
+    b = [torch.nn.Parameter(p.clone()) for p in ps]
+    oa, ob = Adam(a, lr=1e-3, weight_decay=1e-5), torch.optim.Adam(b, lr=1e-3, weight_decay=1e-5)
+    for step in range(5):
+        for pa, pb in zip(a, b):
+            g = torch.randn_like(pa) * (step + 1)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(), ob.step()
+    for pa, pb in zip(a, b):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6)
+    assert int(oa._step.item()) == 5
+
+
+def test_train_step_graph_equals_eager(dam):
+    """The hipGraph-captured step replays the same arithmetic as the eager sequence."""
+    from deep_audio_mixer_amd.engine import TrainStep
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    losses = []
+    for use_graph in (False, True):
+        torch.manual_seed(1)
+        model = ResNet18(n_stems=2, input_shape=(1025, 17)).cuda().train()
+        opt = Adam(model.parameters(), weight_decay=1e-5)
+        step = TrainStep(model, opt, 2, 16 * 1024, 2, batch=2, use_graph=use_graph)
+        g = torch.Generator(device='cuda').manual_seed(3)
+        stems = 0.1 * torch.randn((2, 2, 16 * 1024, 2), generator=g, device='cuda')
+        step.load_batch(stems, stems.sum(1))
+        step.capture(warmup=2)
+        losses.append([step().item() for _ in range(3)])
+    np.testing.assert_allclose(losses[0], losses[1], rtol=1e-4)
+    assert losses[0][-1] < losses[0][0]
+
+
+def test_mix_song_smooth_matches_oracle(dam):
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    from deep_audio_mixer_amd.inference_utils import mix_song_smooth
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    sr, n_chunks = 44100, 12
+    rng = np.random.default_rng(8)
+    tracks = {t: 0.1 * rng.standard_normal((2, sr * n_chunks + 777)) for t in ('bass', 'drums', 'mix')}
+    torch.manual_seed(2)
+    ref = models_ref.RefResNet18(n_stems=2, input_shape=(1025, 44)).eval()
+    model = ResNet18(n_stems=2, input_shape=(1025, 44))
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda().eval()
+    d = MultitrackAudioDataset.from_arrays({'x': {t: v.T for t, v in tracks.items()}}, chunk_length=1, sr=sr,
+                                           tracklist=['bass', 'drums', 'mix'])
+    mixed, raw, smooth = mix_song_smooth(d, model, tracks, chunk_length=1, sr=sr)
+
+    def model_fn(feats):
+        with torch.no_grad():
+            return torch.cat(ref(torch.from_numpy(feats))[1], 1)[0].numpy()
+    torch.set_num_threads(16)
+    mixed_r, raw_r, smooth_r = inference_ref.mix_song_smooth(model_fn, tracks, ['bass', 'drums'], 1, sr)
+    for t in ('bass', 'drums'):
+        assert len(raw[t]) == n_chunks - 1
+        np.testing.assert_allclose(raw[t], raw_r[t], rtol=2e-4)
+        np.testing.assert_allclose(smooth[t], smooth_r[t], rtol=2e-4)
+        assert mixed[t].shape == tracks[t].shape and mixed[t].dtype == np.float64
+        np.testing.assert_allclose(mixed[t], mixed_r[t], rtol=2e-4, atol=1e-9)
+    # training-mode models are applied chunk by chunk, as the reference loop does (per-call batch statistics)
+    model.train()
+    _, raw_t, _ = mix_song_smooth(d, model, tracks, chunk_length=1, sr=sr)
+    assert len(raw_t['bass']) == n_chunks - 1 and not np.allclose(raw_t['bass'], raw['bass'])
