@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdam_hip.so')
+LIB_PATH = os.environ.get('DAM_LIB_PATH') or os.path.join(_HERE, 'libdam_hip.so')   # override: diagnostic builds only
 
 _STATUS = {0: 'DAM_OK', -1: 'DAM_ERR_BAD_ARG', -2: 'DAM_ERR_UNSUPPORTED', -3: 'DAM_ERR_LAUNCH',
            -4: 'DAM_ERR_WORKSPACE'}
@@ -23,12 +23,13 @@ SIGNATURES = {
     'dam_conv_packed_weight_count': (c_i64, [c_i, c_i, c_i, c_i]),
     'dam_conv_pack_weights_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'dam_conv2d_tapgrid_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p] +
-                               [c_i] * 17 + [c_p, c_p, c_p]),
+                               [c_i] * 17 + [c_p, c_p, c_p, c_p, c_p]),
     'dam_conv2d_wgrad_workspace_floats': (c_i64, [c_i, c_i, c_i, c_i]),
     'dam_conv2d_wgrad_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p] + [c_i] * 9 +
                              [c_p, c_p, c_i64, c_p]),
     'dam_bn_workspace_floats': (c_i64, [c_i]),
     'dam_bn_stats_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'dam_bn_finalize_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_eval_affine_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_apply_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libdam_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-mllvm', '-amdgpu-mfma-vgpr-form=1',
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 
 

@@ -30,7 +30,7 @@ inline BnLaunch bn_plan(int64_t P, int C) {
     l.r = 256 / l.q;
     if (l.r < 1) l.r = 1;
     l.threads = l.q * l.r;
-    int64_t parts = cdiv(P, 512);
+    int64_t parts = cdiv(P, (int64_t)l.r * 16);          // ~16 pixels (two batches of 8 loads) per thread
     if (parts > BN_MAX_PARTS) parts = BN_MAX_PARTS;
     if (parts < 1) parts = 1;
     l.ppb = cdiv(P, parts);
@@ -45,20 +45,28 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ x, int64_t P, 
     const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
     float k[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     int n = 0;
-    for (int64_t p = lo + pr; p < hi; p += R) {
-        const float4 v = *reinterpret_cast<const float4*>(x + p * C + cq * 4);
-        const float e[4] = {v.x, v.y, v.z, v.w};
-        if (n == 0) {
+    constexpr int U = 8;      // loads in flight per thread: the kernel is a pure stream, latency must be covered by MLP
+    for (int64_t p = lo + pr; p < hi; p += (int64_t)R * U) {
+        float4 v[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) k[i] = e[i];
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = p + (int64_t)u * R;
+            v[u] = q < hi ? *reinterpret_cast<const float4*>(x + q * C + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (n == 0) { k[0] = v[0].x; k[1] = v[0].y; k[2] = v[0].z; k[3] = v[0].w; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float d = e[i] - k[i];
-            s1[i] += d;
-            s2[i] = fmaf(d, d, s2[i]);
+        for (int u = 0; u < U; ++u) {
+            if (p + (int64_t)u * R < hi) {
+                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = e[i] - k[i];
+                    s1[i] += d;
+                    s2[i] = fmaf(d, d, s2[i]);
+                }
+                ++n;
+            }
         }
-        ++n;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -69,22 +77,33 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ x, int64_t P, 
         o[2] = n ? fmaxf(s2[i] - s1[i] * md, 0.f) : 0.f;
     }
     __syncthreads();
+    // tree merge over the R pixel rows (Chan), all threads active; fixed order -> deterministic
+    int span = 1;
+    while (span < R) span <<= 1;
+    for (int stride = span >> 1; stride >= 1; stride >>= 1) {
+        if (pr < stride && pr + stride < R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float* a = sm + ((size_t)pr * C + cq * 4 + i) * 3;
+                const float* b = sm + ((size_t)(pr + stride) * C + cq * 4 + i) * 3;
+                const float na = a[0], nb = b[0];
+                if (nb != 0.f) {
+                    const float nn = na + nb, d = b[1] - a[1];
+                    a[1] += d * (nb / nn);
+                    a[2] += b[2] + d * d * (na * nb / nn);
+                    a[0] = nn;
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (pr == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = cq * 4 + i;
-            float na = 0.f, ma = 0.f, qa = 0.f;
-            for (int r = 0; r < R; ++r) {
-                const float* o = sm + ((size_t)r * C + c) * 3;
-                const float nb = o[0];
-                if (nb == 0.f) continue;
-                const float nn = na + nb, d = o[1] - ma;
-                ma += d * (nb / nn);
-                qa += o[2] + d * d * (na * nb / nn);
-                na = nn;
-            }
+            const float* a = sm + (size_t)c * 3;
             float* out = partial + ((size_t)blockIdx.x * C + c) * 3;
-            out[0] = na; out[1] = ma; out[2] = qa;
+            out[0] = a[0]; out[1] = a[1]; out[2] = a[2];
         }
     }
 }
@@ -181,16 +200,27 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float*
     const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
     const float4 mu = reinterpret_cast<const float4*>(mean)[cq], is = reinterpret_cast<const float4*>(invstd)[cq];
     float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-    for (int64_t p = lo + pr; p < hi; p += R) {
-        float4 g = *reinterpret_cast<const float4*>(dy + p * C + cq * 4);
-        if (y_mask) {
-            const float4 m = *reinterpret_cast<const float4*>(y_mask + p * C + cq * 4);
-            g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+    constexpr int U = 4;      // 3 streams x 4 loads in flight per thread
+    for (int64_t p = lo + pr; p < hi; p += (int64_t)R * U) {
+        float4 gv[U], mv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = p + (int64_t)u * R;
+            const bool ok = q < hi;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            gv[u] = ok ? *reinterpret_cast<const float4*>(dy + q * C + cq * 4) : z;
+            xv[u] = ok ? *reinterpret_cast<const float4*>(x + q * C + cq * 4) : z;
+            mv[u] = (ok && y_mask) ? *reinterpret_cast<const float4*>(y_mask + q * C + cq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         }
-        const float4 v = *reinterpret_cast<const float4*>(x + p * C + cq * 4);
-        a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
-        b[0] = fmaf(g.x, (v.x - mu.x) * is.x, b[0]); b[1] = fmaf(g.y, (v.y - mu.y) * is.y, b[1]);
-        b[2] = fmaf(g.z, (v.z - mu.z) * is.z, b[2]); b[3] = fmaf(g.w, (v.w - mu.w) * is.w, b[3]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4 g = gv[u];
+            const float4 m = mv[u], v = xv[u];
+            g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+            a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
+            b[0] = fmaf(g.x, (v.x - mu.x) * is.x, b[0]); b[1] = fmaf(g.y, (v.y - mu.y) * is.y, b[1]);
+            b[2] = fmaf(g.z, (v.z - mu.z) * is.z, b[2]); b[3] = fmaf(g.w, (v.w - mu.w) * is.w, b[3]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -198,14 +228,25 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float*
         o[0] = a[i]; o[1] = b[i];
     }
     __syncthreads();
+    int span = 1;
+    while (span < R) span <<= 1;
+    for (int stride = span >> 1; stride >= 1; stride >>= 1) {
+        if (pr < stride && pr + stride < R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float* a2 = sm + ((size_t)pr * C + cq * 4 + i) * 2;
+                const float* b2 = sm + ((size_t)(pr + stride) * C + cq * 4 + i) * 2;
+                a2[0] += b2[0]; a2[1] += b2[1];
+            }
+        }
+        __syncthreads();
+    }
     if (pr == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = cq * 4 + i;
-            float sa = 0.f, sb = 0.f;
-            for (int r = 0; r < R; ++r) { sa += sm[((size_t)r * C + c) * 2]; sb += sm[((size_t)r * C + c) * 2 + 1]; }
-            partial[((size_t)blockIdx.x * C + c) * 2] = sa;
-            partial[((size_t)blockIdx.x * C + c) * 2 + 1] = sb;
+            partial[((size_t)blockIdx.x * C + c) * 2] = sm[(size_t)c * 2];
+            partial[((size_t)blockIdx.x * C + c) * 2 + 1] = sm[(size_t)c * 2 + 1];
         }
     }
 }
@@ -265,20 +306,32 @@ __global__ void channel_sum_partial_kernel(const float* __restrict__ x, int64_t 
     const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
     const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
     float a[4] = {0, 0, 0, 0};
-    for (int64_t p = lo + pr; p < hi; p += R) {
-        const float4 v = *reinterpret_cast<const float4*>(x + p * C + cq * 4);
-        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+    constexpr int U = 8;
+    for (int64_t p = lo + pr; p < hi; p += (int64_t)R * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = p + (int64_t)u * R;
+            v[u] = q < hi ? *reinterpret_cast<const float4*>(x + q * C + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[0] += v[u].x; a[1] += v[u].y; a[2] += v[u].z; a[3] += v[u].w; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) sm[(size_t)pr * C + cq * 4 + i] = a[i];
     __syncthreads();
+    int span = 1;
+    while (span < R) span <<= 1;
+    for (int stride = span >> 1; stride >= 1; stride >>= 1) {
+        if (pr < stride && pr + stride < R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sm[(size_t)pr * C + cq * 4 + i] += sm[(size_t)(pr + stride) * C + cq * 4 + i];
+        }
+        __syncthreads();
+    }
     if (pr == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float s = 0.f;
-            for (int r = 0; r < R; ++r) s += sm[(size_t)r * C + cq * 4 + i];
-            partial[(size_t)blockIdx.x * C + cq * 4 + i] = s;
-        }
+        for (int i = 0; i < 4; ++i) partial[(size_t)blockIdx.x * C + cq * 4 + i] = sm[cq * 4 + i];
     }
 }
 __global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const float* __restrict__ partial, int parts, int C, int n_real,
@@ -317,6 +370,19 @@ extern "C" int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const f
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
                        gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
                        save_mean, save_invstd, scale, shift);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int dam_bn_finalize_f32(const float* partial, int parts, int C, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                   float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
+                                   float* shift, void* stream) {
+    if (!partial || parts <= 0 || C <= 0 || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift)
+        return DAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, C, gamma, beta,
+                       running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, save_mean, save_invstd,
+                       scale, shift);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }

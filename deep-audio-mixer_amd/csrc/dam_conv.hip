@@ -22,28 +22,10 @@
 //     expresses forward, stride-1 dgrad (negative steps) and the four parity classes of a stride-2 dgrad
 //     with the same kernel.
 #include "dam_common.h"
+#include "dam_conv_geo.h"
 #include "dam_conv_stage.h"
 
 namespace dam {
-
-struct ConvGeo {
-    int B, H, W, C;          // input tensor dims; C = channel stride of an NHWC pixel (S planes if in_nchw)
-    int Ho, Wo;              // output pixel grid enumerated by this launch
-    int N;                   // output channels (multiple of 16) = channel stride of the output tensor
-    int OHt, OWt;            // output tensor spatial dims
-    int os, oo_h, oo_w;      // output pixel (oh, ow) -> tensor position (oh*os+oo_h, ow*os+oo_w)
-    int s;                   // input stride per output pixel (1 or 2)
-    int nA, nB;              // tap grid
-    int off_h, step_h, off_w, step_w;   // tap (a,b) reads input (oh*s + off_h + a*step_h, ow*s + off_w + b*step_w)
-    int wt_base, wt_sa, wt_sb;          // packed weight tap index = wt_base + a*wt_sa + b*wt_sb
-    int r0, c0;              // min tap offsets: patch origin (row oh_first*s + r0, col c0)
-    int PR, PWin, PWs, PWT;  // patch rows, input columns covered, slots per parity, slots per row (s*PWs)
-    int nchunks, CG;         // 16-channel K chunks in total / per LDS group
-    int NBtot;               // 16-channel output blocks in the packed weights
-    int tiles_m;             // M tiles per image
-    int in_nchw;             // 1: input is [B][C][H][W] with C <= 16 planes (first layer)
-    int relu_in;             // with in_scale: apply relu(x*scale+shift) while staging
-};
 
 namespace {
 
@@ -93,38 +75,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
         // ---- stage the input patch of this channel group ----
         {
             const size_t img_elems = (size_t)g.H * g.W * g.C;
-            stage_patch(smem, chunk_bytes, X + (size_t)img * img_elems, pg, ih0, cg * g.CG, g.CG, in_scale, in_shift, lane, wave);
+            stage_patch(smem, chunk_bytes, X + (size_t)img * img_elems, pg, ih0, cg * g.CG, g.CG, in_scale, in_shift, tid);
         }
         __syncthreads();
 
-        // ---- MFMA over taps x chunks of the group ----
-        for (int a = 0; a < g.nA; ++a) {
-            const int roff = g.off_h + a * g.step_h - g.r0;
-            for (int b = 0; b < g.nB; ++b) {
+        // ---- MFMA over (tap a, tap b, chunk) items of the group, software-pipelined: the weights (global/L2)
+        //      and the LDS operands of item i+1 are requested before the MFMAs of item i issue ----
+        {
+            const int n_items = g.nA * g.nB * g.CG;
+            int ia = 0, ib = 0, ic = 0;
+            auto item_offsets = [&](int a, int b, int cc, int& lds_off, size_t& w_off) {
+                const int roff = g.off_h + a * g.step_h - g.r0;
                 const int coff = g.off_w + b * g.step_w - g.c0;
                 const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
-                const int toff = (roff * g.PWT + slotoff) * 64;
+                lds_off = cc * chunk_bytes + (roff * g.PWT + slotoff) * 64;
                 const int tap = g.wt_base + a * g.wt_sa + b * g.wt_sb;
-                for (int cc = 0; cc < g.CG; ++cc) {
-                    const int chunk = cg * g.CG + cc;
-                    const float4* wp = Wp + ((size_t)(tap * g.nchunks + chunk) * g.NBtot + nb0) * 64 + lane;
-                    float4 wa[NB];
+                w_off = ((size_t)(tap * g.nchunks + cg * g.CG + cc) * g.NBtot + nb0) * 64 + lane;
+            };
+            float4 wa_n[NB], xv_n[MB];
+            {
+                int lo; size_t wo;
+                item_offsets(0, 0, 0, lo, wo);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) wa[nb] = wp[nb * 64];
-                    float4 xv[MB];
+                for (int nb = 0; nb < NB; ++nb) wa_n[nb] = Wp[wo + nb * 64];
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        xv[mb] = *reinterpret_cast<const float4*>(smem + cc * chunk_bytes + base_b[mb] + toff);
+                for (int mb = 0; mb < MB; ++mb) xv_n[mb] = *reinterpret_cast<const float4*>(smem + base_b[mb] + lo);
+            }
+            for (int it = 0; it < n_items; ++it) {
+                float4 wa[NB], xv[MB];
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
+                for (int nb = 0; nb < NB; ++nb) wa[nb] = wa_n[nb];
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].x, xv[mb].x, acc[mb][nb], 0, 0, 0);
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].y, xv[mb].y, acc[mb][nb], 0, 0, 0);
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].z, xv[mb].z, acc[mb][nb], 0, 0, 0);
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].w, xv[mb].w, acc[mb][nb], 0, 0, 0);
-                        }
+                for (int mb = 0; mb < MB; ++mb) xv[mb] = xv_n[mb];
+                if (++ic == g.CG) { ic = 0; if (++ib == g.nB) { ib = 0; ++ia; } }
+                if (it + 1 < n_items) {
+                    int lo; size_t wo;
+                    item_offsets(ia, ib, ic, lo, wo);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) wa_n[nb] = Wp[wo + nb * 64];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) xv_n[mb] = *reinterpret_cast<const float4*>(smem + base_b[mb] + lo);
                 }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].x, xv[mb].x, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].y, xv[mb].y, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].z, xv[mb].z, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].w, xv[mb].w, acc[mb][nb], 0, 0, 0);
+                    }
             }
         }
     }
@@ -227,8 +227,10 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
                                       const float* in_shift, int relu_in, float* y, int OHt, int OWt, int Ho, int Wo,
                                       int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                                       int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
-                                      const float* res, const float* res_mask, void* stream) {
+                                      const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
+                                      void* stream) {
     using namespace dam;
+    if (bn_parts_host) *bn_parts_host = 0;
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || nA <= 0 || nB <= 0)
         return DAM_ERR_BAD_ARG;
     if (n_out % 16 || (in_stride != 1 && in_stride != 2) || out_stride < 1) return DAM_ERR_UNSUPPORTED;
@@ -248,6 +250,23 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     g.PWs = (int)cdiv(g.PWin, in_stride);
     g.PWT = g.PWs * in_stride;
 
+    hipStream_t st = (hipStream_t)stream;
+    g.PR = 0; g.CG = 1; g.tiles_m = 0;
+    // persistent strip variant (LDS-DMA ring, optional fused BatchNorm statistics) when the layer fits it
+    if (!in_nchw && !in_scale) {
+        int parts = 0;
+        const int rc = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, bn_partial, &parts, st);
+        if (rc == DAM_OK) {
+            if (bn_partial && bn_parts_host) *bn_parts_host = parts;
+            return DAM_OK;
+        }
+        if (rc != DAM_ERR_UNSUPPORTED) return rc;
+        if (bn_partial) {       // maybe only the statistics did not fit: retry without them
+            const int rc2 = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, nullptr, nullptr, st);
+            if (rc2 == DAM_OK) return DAM_OK;
+            if (rc2 != DAM_ERR_UNSUPPORTED) return rc2;
+        }
+    }
     // tile choice: fill the chip (>= ~2 workgroups per CU when the layer allows), then prefer big tiles
     const int64_t npix = (int64_t)Ho * Wo;
     const int nblk = n_out / 16;
@@ -278,7 +297,6 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     g.CG = CG;
     g.tiles_m = (int)cdiv(npix, 64 * MB);
     const size_t lds = (size_t)CG * g.PR * g.PWT * 64;
-    hipStream_t st = (hipStream_t)stream;
 #define DAM_CONV_CASE(M_, N_) \
     if (MB == M_ && NB == N_) return launch_conv<M_, N_>(g, lds, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, st)
     DAM_CONV_CASE(4, 4); DAM_CONV_CASE(4, 2); DAM_CONV_CASE(4, 1);

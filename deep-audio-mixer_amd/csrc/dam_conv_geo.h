@@ -1,0 +1,39 @@
+// Geometry descriptors shared by the convolution kernels (passed by value as kernel arguments).
+#pragma once
+#include "dam_common.h"
+
+namespace dam {
+
+struct ConvGeo {
+    int B, H, W, C;          // input tensor dims; C = channel stride of an NHWC pixel (S planes if in_nchw)
+    int Ho, Wo;              // output pixel grid enumerated by this launch
+    int N;                   // output channels (multiple of 16) = channel stride of the output tensor
+    int OHt, OWt;            // output tensor spatial dims
+    int os, oo_h, oo_w;      // output pixel (oh, ow) -> tensor position (oh*os+oo_h, ow*os+oo_w)
+    int s;                   // input stride per output pixel (1 or 2)
+    int nA, nB;              // tap grid
+    int off_h, step_h, off_w, step_w;   // tap (a,b) reads input (oh*s + off_h + a*step_h, ow*s + off_w + b*step_w)
+    int wt_base, wt_sa, wt_sb;          // packed weight tap index = wt_base + a*wt_sa + b*wt_sb
+    int r0, c0;              // min tap offsets: patch origin (row oh_first*s + r0, col c0)
+    int PR, PWin, PWs, PWT;  // patch rows, input columns covered, slots per parity, slots per row (s*PWs)
+    int nchunks, CG;         // 16-channel K chunks in total / per LDS group
+    int NBtot;               // 16-channel output blocks in the packed weights
+    int tiles_m;             // M tiles per image
+    int in_nchw;             // 1: input is [B][C][H][W] with C <= 16 planes (first layer)
+    int relu_in;             // with in_scale: apply relu(x*scale+shift) while staging
+};
+
+struct StripGeo {
+    int NR;                  // ring rows (power of two)
+    int RH;                  // input rows touched by one output row
+    int tiles_m, tpw, strips;  // M tiles per image, tiles per workgroup, workgroups per image
+    int ring_off;            // multiple of NR added to row indices before masking
+    int w_lds;               // 1: the packed weights of this N tile are resident in LDS behind the ring
+    int w_taps;              // taps held in LDS (max used tap index + 1)
+};
+
+// dam_conv_strip.hip
+int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
+                   const float* res, const float* res_mask, float* stats, int* stats_parts, hipStream_t st);
+
+}  // namespace dam

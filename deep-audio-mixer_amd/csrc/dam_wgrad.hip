@@ -74,16 +74,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
         const int oh_first = p0 / g.Wo;
         __syncthreads();
         stage_patch(smem, chunk_bytes, X + (size_t)img * img_elems, pg, oh_first * g.s + g.r0, tk * TKB, TKB,
-                    in_scale, in_shift, lane, wave);
+                    in_scale, in_shift, tid);
         {   // dY pixels p0 .. p0+TMW-1, channels of this n tile; zero beyond the image / channel count
             constexpr int QPP = TNB * 4;
             const float* dyb = dY + ((size_t)img * HoWo) * g.N + tn * TNB * 16;
-            for (int e = tid; e < TMW * QPP; e += 256) {
-                const int pl = e / QPP, cq = e % QPP;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p0 + pl < HoWo && tn * TNB * 16 + cq * 4 < g.N)
-                    v = *reinterpret_cast<const float4*>(dyb + (size_t)(p0 + pl) * g.N + cq * 4);
-                *reinterpret_cast<float4*>(dy_s + (((cq >> 2) * TMW + pl) * 16 + (cq & 3) * 4) * 4) = v;
+            constexpr int U = 4;
+            for (int base = tid; base < TMW * QPP; base += 256 * U) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + 256 * u, pl = e / QPP, cq = e % QPP;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < TMW * QPP && p0 + pl < HoWo && tn * TNB * 16 + cq * 4 < g.N)
+                        v[u] = *reinterpret_cast<const float4*>(dyb + (size_t)(p0 + pl) * g.N + cq * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + 256 * u, pl = e / QPP, cq = e % QPP;
+                    if (e < TMW * QPP)
+                        *reinterpret_cast<float4*>(dy_s + (((cq >> 2) * TMW + pl) * 16 + (cq & 3) * 4) * 4) = v[u];
+                }
             }
         }
         __syncthreads();

@@ -1,6 +1,8 @@
 """Thin Python wrappers over the C ABI (include/dam_hip.h): shape checks, output allocation through
 torch's caching allocator, launch on the current torch stream.  No arithmetic happens here and
 there is no CPU fallback."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -35,17 +37,20 @@ def pack_weights(w, transpose=False, out=None):
 
 def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shift, relu_in, y, OHt, OWt, Ho, Wo,
              out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
-             res=None, res_mask=None):
+             res=None, res_mask=None, bn_partial=None):
+    parts = ctypes.c_int(0)
     st = _lib.lib().dam_conv2d_tapgrid_f32(
         _lib.ptr(x), B, H, W, C, 1 if in_nchw else 0, _lib.ptr(wp), k_chunks, n_out, _lib.ptr(bias),
         _lib.ptr(in_scale), _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(y), OHt, OWt, Ho, Wo, out_stride,
         oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb, _lib.ptr(res),
-        _lib.ptr(res_mask), _lib.stream())
+        _lib.ptr(res_mask), _lib.ptr(bn_partial), ctypes.byref(parts) if bn_partial is not None else None,
+        _lib.stream())
     _lib.check(st, 'dam_conv2d_tapgrid_f32')
+    return parts.value
 
 
 def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale=None, in_shift=None,
-               relu_in=False, in_nchw=False):
+               relu_in=False, in_nchw=False, bn_partial=None):
     """x: NHWC [B,H,W,C] (C % 16 == 0), or NCHW [B,C,H,W] with C <= 16 if in_nchw.  Returns NHWC
     [B,Ho,Wo,n_out] with n_out rounded up to a multiple of 16 (extra channels are zero)."""
     _lib.require_cuda(x, wp)
@@ -61,8 +66,10 @@ def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale
     if Ho <= 0 or Wo <= 0:
         raise ValueError('convolution output would be empty')
     y = torch.empty((B, Ho, Wo, n16), dtype=torch.float32, device=x.device)
-    _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n16, bias, in_scale, in_shift, relu_in, y, Ho, Wo, Ho, Wo,
-             1, 0, 0, stride, kh, kw, -pad, dil, -pad, dil, 0, kw, 1)
+    parts = _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n16, bias, in_scale, in_shift, relu_in, y, Ho, Wo, Ho, Wo,
+                     1, 0, 0, stride, kh, kw, -pad, dil, -pad, dil, 0, kw, 1, bn_partial=bn_partial)
+    if bn_partial is not None:
+        return y, parts          # parts == 0: the launch could not produce the statistics
     return y
 
 
@@ -164,6 +171,22 @@ def bn_stats(x, gamma, beta, running_mean, running_var, num_batches_tracked, mom
                                            _lib.ptr(running_var), _lib.ptr(num_batches_tracked), float(momentum), float(eps),
                                            _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
                                            _lib.ptr(ws), _lib.stream()), 'dam_bn_stats_f32')
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_partial_buffer(device, C):
+    """Scratch for the BatchNorm partial records a convolution launch can emit (one per device and width)."""
+    return _bn_ws(device, C)
+
+
+def bn_finalize(partial, parts, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps):
+    """Merges `parts` partial records (from conv2d_fwd(..., bn_partial=...)) -> (save_mean, save_invstd, scale, shift)."""
+    C = gamma.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    _lib.check(_lib.lib().dam_bn_finalize_f32(_lib.ptr(partial), parts, C, _lib.ptr(gamma), _lib.ptr(beta),
+                                              _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
+                                              float(momentum), float(eps), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
+                                              _lib.ptr(out[3]), _lib.stream()), 'dam_bn_finalize_f32')
     return out[0], out[1], out[2], out[3]
 
 

@@ -94,13 +94,18 @@ int dam_conv_pack_weights_f32(const float* w_oihw, int O, int I, int KH, int KW,
  *   y : NHWC [B][OHt][OWt][n_out], n_out % 16 == 0;  res/res_mask (optional): same shape as y
  * Forward conv: in_stride=stride, off=-pad, step=dilation, taps (kh,kw) as is.  Stride-1 dgrad:
  * off=+pad, step=-dilation on dy with transposed packing.  Stride-2 dgrad: one call per output parity
- * class (out_stride=2).  in_stride must be 1 or 2. */
+ * class (out_stride=2).  in_stride must be 1 or 2.
+ * bn_partial (optional, >= dam_bn_workspace_floats(n_out) floats): if the launch can also produce the BatchNorm
+ * partial statistics of y (records (n, mean, M2) per workgroup and channel) it does so and stores the record count
+ * in *bn_parts_host (a HOST int); 0 there means "not produced" and the caller runs dam_bn_stats_f32 instead.
+ * Feed the records to dam_bn_finalize_f32. */
 int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
                            int k_chunks, int n_out, const float* bias, const float* in_scale,
                            const float* in_shift, int relu_in, float* y, int OHt, int OWt, int Ho, int Wo,
                            int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                            int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
-                           const float* res, const float* res_mask, void* stream);
+                           const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
+                           void* stream);
 
 /* Weight gradient of the same convolutions (autograd of nn.Conv2d reached from loss.backward(),
  * model_trainer.py:36):  dw[n][k][kh][kw] = sum_{b,oh,ow} dy[b,oh,ow,n] * f(x[b, oh*stride+kh*dil-pad, ow*stride+kw*dil-pad, k])
@@ -131,6 +136,13 @@ int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const float* gamma
                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
                      float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
                      float* shift, float* workspace, void* stream);
+
+/* Second half of dam_bn_stats_f32 on its own: merges `parts` partial records [parts][C][3] = (n, mean, M2) (as written
+ * by dam_conv2d_tapgrid_f32's bn_partial output) and produces the same outputs / running-stat update. */
+int dam_bn_finalize_f32(const float* partial, int parts, int C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                        float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
+                        float* shift, void* stream);
 
 /* Eval-mode equivalent: the same four outputs from the running statistics. */
 int dam_bn_eval_affine_f32(int C, const float* gamma, const float* beta, const float* running_mean,

@@ -132,3 +132,28 @@ def test_full_resolution_layer1(ops):
     dy = torch.randn(2, 16, 1025, 130, generator=g)
     want_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, 1)
     close(ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), 16, 3, 3, 1, 1, 1), want_dw, 1e-4)
+
+
+def test_fused_bn_statistics_epilogue(ops):
+    """The strip kernel's BatchNorm partial records, merged by dam_bn_finalize_f32, equal the two-pass statistics of the
+    conv output (mean far from zero on purpose: dB-valued activations)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 16, 150, 130, generator=g) * 5 + 40
+    w = torch.randn(32, 16, 3, 3, generator=g) / 12
+    want = F.conv2d(x.double(), w.double(), None, 1, 1)
+    buf = ops.bn_partial_buffer(torch.device('cuda'), 32)
+    y, parts = ops.conv2d_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), 32, 3, 3, 1, 1, 1, bn_partial=buf)
+    assert parts > 0
+    close(nchw(y), want)
+    gamma, beta = torch.rand(32, device='cuda') + 0.5, torch.randn(32, device='cuda')
+    rm, rv = torch.zeros(32, device='cuda'), torch.ones(32, device='cuda')
+    nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+    mean, invstd, scale, shift = ops.bn_finalize(buf, parts, gamma, beta, rm, rv, nbt, 0.1, 1e-5)
+    wm, wv = want.mean((0, 2, 3)), want.var((0, 2, 3), unbiased=False)
+    assert (mean.double().cpu() - wm).abs().max() <= 1e-5 * wm.abs().max()
+    assert ((invstd.double().cpu() - 1 / (wv + 1e-5).sqrt()).abs() * (wv + 1e-5).sqrt()).max() <= 2e-5
+    n = want.numel() / 32
+    assert torch.allclose(rv.double().cpu(), 0.9 + 0.1 * wv * n / (n - 1), rtol=1e-4)
+    assert int(nbt.item()) == 1
+    m2, i2, _, _ = ops.bn_stats(y, gamma, beta, None, None, None, 0.1, 1e-5)
+    assert torch.allclose(mean, m2, rtol=1e-5, atol=1e-4) and torch.allclose(invstd, i2, rtol=1e-4)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Runs single kernels of the hot path in isolation at the benchmark's shapes (for rocprofv3 --pmc passes).
+usage: python tools/conv_probe.py [conv1|layer1|layer1_wgrad|layer3|bn|stft] [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deep_audio_mixer_amd  # noqa: E402,F401
+from deep_audio_mixer_amd import features, ops  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'layer1'
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dev = torch.device('cuda', 0)
+B, H, W = 8, 1025, 130
+torch.manual_seed(0)
+if which in ('layer1', 'layer1_wgrad', 'layer1_dgrad'):
+    x = torch.randn((B, H, W, 16), device=dev)
+    wt = torch.randn((16, 16, 3, 3), device=dev) * 0.05
+    wp, wpt = ops.pack_weights(wt), ops.pack_weights(wt, transpose=True)
+    dy = torch.randn((B, H, W, 16), device=dev)
+    if which == 'layer1':
+        fn = lambda: ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1)
+    elif which == 'layer1_dgrad':
+        fn = lambda: ops.conv2d_dgrad(dy, wpt, 16, H, W, 3, 3, 1, 1, 1, res=dy, res_mask=x)
+    else:
+        fn = lambda: ops.conv2d_wgrad(x, dy, 16, 3, 3, 1, 1, 1)
+elif which == 'layer3':
+    x = torch.randn((B, 257, 33, 64), device=dev)
+    wp = ops.pack_weights(torch.randn((64, 64, 3, 3), device=dev) * 0.05)
+    fn = lambda: ops.conv2d_fwd(x, wp, 64, 3, 3, 1, 1, 1)
+elif which == 'conv1':
+    x = torch.randn((B, 8, H, W), device=dev)
+    wp = ops.pack_weights(torch.randn((16, 8, 3, 3), device=dev) * 0.05)
+    fn = lambda: ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1, in_nchw=True)
+elif which == 'bn':
+    x = torch.randn((B, H, W, 16), device=dev)
+    gam, bet = torch.ones(16, device=dev), torch.zeros(16, device=dev)
+    fn = lambda: ops.bn_stats(x, gam, bet, None, None, None, 0.1, 1e-5)
+elif which == 'stft':
+    pcm = 0.1 * torch.randn((72, 132300, 2), device=dev)
+    fn = lambda: features.stft_logmag(pcm, hop=1024)
+else:
+    raise SystemExit('unknown probe')
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(iters):
+    fn()
+b.record()
+torch.cuda.synchronize()
+print('%s: %.1f us per call' % (which, a.elapsed_time(b) * 1e3 / iters))
