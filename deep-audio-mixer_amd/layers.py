@@ -23,6 +23,27 @@ class ConvSpec:
         return ops.conv2d_fwd(x, ops.pack_weights(w), self.cout, self.k, self.k, self.stride, self.pad, self.dil,
                               bias=bias, in_nchw=self.in_nchw)
 
+    def fwd_bn(self, x, w, bn, training, bias=None):
+        """Convolution followed by the statistics of its BatchNorm: (c, save_mean, save_invstd, scale, shift).  In
+        training mode the conv launch emits the per-workgroup partial statistics itself when it can (strip kernel);
+        otherwise a separate statistics pass runs over c."""
+        wp = ops.pack_weights(w)
+        if training and not self.in_nchw:
+            n16 = (self.cout + 15) // 16 * 16
+            buf = ops.bn_partial_buffer(x.device, n16)
+            c, parts = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
+                                      bn_partial=buf)
+            if parts > 0:
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                track = bn.track_running_stats
+                return (c,) + tuple(ops.bn_finalize(buf, parts, bn.weight, bn.bias, bn.running_mean if track else None,
+                                                    bn.running_var if track else None,
+                                                    bn.num_batches_tracked if track else None, mom, bn.eps))
+        else:
+            c = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
+                               in_nchw=self.in_nchw)
+        return (c,) + tuple(_bn_fwd_stats(c, bn, training))
+
     def wgrad(self, x, dy):
         return ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil, in_nchw=self.in_nchw)
 
@@ -51,8 +72,7 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, gamma, beta, spec, bn, training):
-        c = spec.fwd(x, w.detach(), None if bias is None else bias.detach())
-        mean, invstd, scale, shift = _bn_fwd_stats(c, bn, training)
+        c, mean, invstd, scale, shift = spec.fwd_bn(x, w.detach(), bn, training, None if bias is None else bias.detach())
         a = ops.bn_apply(c, scale, shift, relu=True)
         ctx.save_for_backward(x, w, c, a, gamma, mean, invstd)
         ctx.spec, ctx.training, ctx.has_bias = spec, training, bias is not None
@@ -74,14 +94,11 @@ class BasicBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wsc, gsc, bsc, blk, training):
-        c1 = blk.spec1.fwd(x, w1.detach())
-        m1, i1, sc1, sh1 = _bn_fwd_stats(c1, blk.bn1, training)
+        c1, m1, i1, sc1, sh1 = blk.spec1.fwd_bn(x, w1.detach(), blk.bn1, training)
         a1 = ops.bn_apply(c1, sc1, sh1, relu=True)
-        c2 = blk.spec2.fwd(a1, w2.detach())
-        m2, i2, sc2, sh2 = _bn_fwd_stats(c2, blk.bn2, training)
+        c2, m2, i2, sc2, sh2 = blk.spec2.fwd_bn(a1, w2.detach(), blk.bn2, training)
         if wsc is not None:
-            cs = blk.spec_sc.fwd(x, wsc.detach())
-            ms, is_, scs, shs = _bn_fwd_stats(cs, blk.shortcut[1], training)
+            cs, ms, is_, scs, shs = blk.spec_sc.fwd_bn(x, wsc.detach(), blk.shortcut[1], training)
             out = ops.bn_apply(c2, sc2, sh2, relu=True, res=cs, res_scale=scs, res_shift=shs)
             ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, wsc, gsc, cs, ms, is_)
         else:
