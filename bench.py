@@ -82,7 +82,11 @@ def cpu_baseline(seconds_budget=25.0):
     step on a bounded sample (1 warm-up + up to 3 timed steps of batch 8)."""
     import numpy as np
     from oracle import features_ref, models_ref
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 16)          # a 1-GPU box grants a 16-core share; more threads only oversubscribe
     torch.set_num_threads(cores)
     rng = np.random.default_rng(1234)
     stems = (0.1 * rng.standard_normal((BATCH, N_STEMS, N_SAMPLES, CHANNELS))).astype(np.float32)
@@ -128,11 +132,17 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    n_dev = torch.cuda.device_count()
+    local = local % max(n_dev, 1)                      # rehearsal only: more ranks than GPUs share a device (gloo)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('DAM_DIST_BACKEND', 'nccl')     # 'nccl' is RCCL on ROCm; 'gloo' for 1-GPU rehearsals
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
 
     import deep_audio_mixer_amd  # noqa: F401
     from deep_audio_mixer_amd import build
