@@ -68,12 +68,13 @@ __global__ __launch_bounds__(320) void conv_strip_kernel(const ConvGeo g, const 
     for (int e = tid * 16; e < CHB * g.nchunks; e += 320 * 16)
         *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     // thin layers: the packed weights of this N tile are small; keep them in LDS so that the MFMA loop never waits on L2
-    unsigned char* wsm = smem + CHB * g.nchunks;
+    const int w_base = CHB * g.nchunks;       // always address LDS as smem + integer offset (a derived pointer variable
+                                              // degrades to flat_load, which is slower and also counts on vmcnt)
     if (sg.w_lds) {
         const int n4 = sg.w_taps * g.nchunks * NB * 64;          // float4 count: [tap][chunk][nb][lane]
         for (int e = tid; e < n4; e += 320) {
             const int ln = e & 63, nb = (e >> 6) % NB, tc = (e >> 6) / NB;
-            reinterpret_cast<float4*>(wsm)[e] = Wp[((size_t)tc * g.NBtot + nb0 + nb) * 64 + ln];
+            *reinterpret_cast<float4*>(smem + w_base + e * 16) = Wp[((size_t)tc * g.NBtot + nb0 + nb) * 64 + ln];
         }
     }
     __syncthreads();
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(320) void conv_strip_kernel(const ConvGeo g, const 
             auto fetch = [&](int aoff, int coloff, size_t w_off, float4 (&wa)[NB], float4 (&xv)[MB]) {
                 if (sg.w_lds) {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) wa[nb] = reinterpret_cast<const float4*>(wsm)[w_off + nb * 64];
+                    for (int nb = 0; nb < NB; ++nb) wa[nb] = *reinterpret_cast<const float4*>(smem + w_base + (int)(w_off + nb * 64) * 16);
                 } else {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) wa[nb] = Wp[w_off + nb * 64];

@@ -19,10 +19,10 @@ y, parts = ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1, bn_partial=buf)
 torch.cuda.synchronize()
 st = buf.view(torch.int64).cpu().numpy().astype(np.uint64).reshape(-1, 2, 32)
 nwg = 58 * 8
-names = {1: 'start', 2: 'zeroed', 3: 'first-load', 4: 'dma-issued', 5: 'mfma-done', 6: 'epilogue-done', 7: 'barrier-passed', 8: 'end'}
+names = {1: 'start', 2: 'zeroed', 3: 'first-load', 4: 'issued', 5: 'mfma', 6: 'bar+commit', 7: 'epi+bar', 8: 'end'}
 t0all = None
-for wg in (0, 1, 57, 200, 463):
-    for role, rn in ((0, 'compute'), (1, 'loader')):
+for wg in (0, 200, 463):
+    for role, rn in ((0, 'wave0'), (1, 'wave3')):
         v = st[wg, role]
         v = v[v != 0]
         tags = (v >> np.uint64(56)).astype(int)
