@@ -379,7 +379,7 @@ int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* 
         while (nr < rows_tile + rows_new) nr <<= 1;
         lds = (size_t)nr * g.PWT * 64 * g.nchunks;
         if (lds <= LDS_MAX) { sg.NR = nr; break; }
-        if (MB == 1) return DAM_ERR_UNSUPPORTED;
+        if (MB == 2) return DAM_ERR_UNSUPPORTED;     // 64-pixel strips measured slower than the tile kernel (MB = 1)
     }
     const int tm = 64 * MB;
     sg.tiles_m = (int)cdiv(npix, tm);
