@@ -56,8 +56,9 @@ def time_kernel(fn, iters=30, warm=5):
 def roofline_probe(device):
     """Times the dominant kernels in isolation at the benchmark's shapes.
 
-    Dominant kernel: conv_igemm_kernel (forward/dgrad implicit GEMM).  Its heaviest instance is a ResNet layer1
-    convolution: 16 -> 16 channels, 3x3, on 8 x 1025 x 130 pixels.  Algorithmic FLOPs per launch =
+    Dominant kernel: the implicit-GEMM convolution (forward/dgrad; conv_strip_kernel for the thin full-resolution layers,
+    conv_igemm_kernel otherwise).  Its heaviest instance is a ResNet layer1 convolution: 16 -> 16 channels, 3x3, on
+    8 x 1025 x 130 pixels.  Algorithmic FLOPs per launch =
     2 * B*H*W * Cout * 9*Cin; the bound is the fp32 matrix pipe (157.3 TFLOP/s).
     """
     from deep_audio_mixer_amd import ops
@@ -204,12 +205,16 @@ def main():
         probe = roofline_probe(device)
         k = probe['layer1_conv3x3_16x16']
         # fwd+bwd algorithmic FLOPs of the whole step (29.5 GFLOP per clip) over the step time
+        # traffic: HBM bytes per launch from the committed PMC passes on this kernel at this shape
+        # (profiles/r01_conv_layer1_pmc.csv: FETCH_SIZE 38,967 KB x 2 [gfx950 halves wide coalesced reads] + WRITE_SIZE 66,625 KB)
         result['roofline'] = {'bound': 'mfma', 'achieved': k['fwd_tflops'], 'peak': PEAK_F32_MFMA / 1e12,
-                              'unit': 'TFLOP/s', 'frac': k['fwd_tflops'] * 1e12 / PEAK_F32_MFMA, 'traffic': None,
-                              'kernel': 'conv_igemm_kernel<4,1> (ResNet layer1 3x3 conv 16->16, 8x1025x130 px)',
+                              'unit': 'TFLOP/s', 'frac': k['fwd_tflops'] * 1e12 / PEAK_F32_MFMA, 'traffic': 144.6e6,
+                              'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_conv_layer1_pmc.csv)',
+                              'kernel': 'conv_strip_kernel<4,1> (ResNet layer1 3x3 conv 16->16 forward, 8x1025x130 px)',
                               'avg_launch_s': k['fwd_s'], 'flops_per_launch': k['flops_per_launch'],
                               'hbm_alg_bytes_per_launch': k['alg_bytes_per_launch'],
-                              'hbm_alg_GBps': k['alg_bytes_per_launch'] / k['fwd_s'] / 1e9}
+                              'hbm_alg_GBps': k['alg_bytes_per_launch'] / k['fwd_s'] / 1e9,
+                              'hbm_frac_of_8TBps': k['alg_bytes_per_launch'] / k['fwd_s'] / PEAK_HBM}
         result['roofline_extra'] = {
             'whole_step_tflops': 29.5e9 * BATCH * world * args.steps / dt / 1e12 / world,
             'whole_step_frac_of_fp32_mfma_peak': 29.5e9 * BATCH * args.steps / dt / PEAK_F32_MFMA,

@@ -179,6 +179,29 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, i
     }
 }
 
+// All convolution weights of a model in ONE launch: desc[t] = {src, dst, O, I, KH, KW, transpose, total floats}.
+__global__ void pack_weights_multi_kernel(const long long* __restrict__ desc) {
+    const long long* d = desc + (size_t)blockIdx.y * 8;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    float* out = reinterpret_cast<float*>(d[1]);
+    const int O = (int)d[2], I = (int)d[3], KH = (int)d[4], KW = (int)d[5], transpose = (int)d[6];
+    const int64_t total = d[7];
+    const int n = transpose ? I : O, k = transpose ? O : I;
+    const int nchunks = (k + 15) / 16, nblks = (n + 15) / 16;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int s = e & 3, i = (e >> 2) & 15, kq = (e >> 6) & 3;
+        int64_t r = e >> 8;
+        const int nblk = r % nblks; r /= nblks;
+        const int chunk = r % nchunks;
+        const int tap = r / nchunks;
+        const int nn = nblk * 16 + i, kk = chunk * 16 + kq * 4 + s;
+        const int o = transpose ? kk : nn, ii = transpose ? nn : kk;
+        float v = 0.f;
+        if (o < O && ii < I) v = w[((size_t)o * I + ii) * KH * KW + tap];
+        out[e] = v;
+    }
+}
+
 template <int MB, int NB>
 int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc,
                 const float* sh, float* Y, const float* res, const float* res_mask, hipStream_t st) {
@@ -217,6 +240,18 @@ extern "C" int dam_conv_pack_weights_f32(const float* w_oihw, int O, int I, int 
     const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I, KH, KW,
                        transpose, nchunks, nblks, packed, total);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+extern "C" int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int64_t max_total, void* stream) {
+    using namespace dam;
+    if (!desc_dev || n_tensors <= 0 || max_total <= 0) return DAM_ERR_BAD_ARG;
+    if (n_tensors > 65535) return DAM_ERR_UNSUPPORTED;
+    int64_t bx = cdiv(max_total, 256 * 4);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(desc_dev));
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }

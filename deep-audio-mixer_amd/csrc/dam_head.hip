@@ -303,7 +303,7 @@ extern "C" int dam_heads_bwd_f32(const float* dgains, const float* h, const floa
     int R = 256 / Q; if (R < 1) R = 1;
     while ((size_t)R * S * C * sizeof(float) > 60 * 1024 && R > 1) R >>= 1;
     const int64_t BP = (int64_t)B * P;
-    int64_t parts = cdiv(BP, 256); if (parts > 1024) parts = 1024;
+    int64_t parts = cdiv(BP, (int64_t)R * 8); if (parts > 1024) parts = 1024;     // ~8 pixels per thread row
     const int64_t ppb = cdiv(BP, parts);
     parts = cdiv(BP, ppb);
     hipLaunchKernelGGL(head_bwd_cw_partial_kernel, dim3((unsigned)parts), dim3(Q * R), (size_t)R * S * C * sizeof(float), st, e,

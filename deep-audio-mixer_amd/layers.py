@@ -18,16 +18,21 @@ class ConvSpec:
 
     def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, in_nchw=False):
         self.cin, self.cout, self.k, self.stride, self.pad, self.dil, self.in_nchw = cin, cout, k, stride, pad, dil, in_nchw
+        self.wp = self.wpt = None      # packed images kept fresh by a WeightPacker (one launch per forward), if any
+
+    def packed(self, w, transpose=False):
+        cached = self.wpt if transpose else self.wp
+        return cached if cached is not None else ops.pack_weights(w, transpose=transpose)
 
     def fwd(self, x, w, bias=None):
-        return ops.conv2d_fwd(x, ops.pack_weights(w), self.cout, self.k, self.k, self.stride, self.pad, self.dil,
+        return ops.conv2d_fwd(x, self.packed(w), self.cout, self.k, self.k, self.stride, self.pad, self.dil,
                               bias=bias, in_nchw=self.in_nchw)
 
     def fwd_bn(self, x, w, bn, training, bias=None):
         """Convolution followed by the statistics of its BatchNorm: (c, save_mean, save_invstd, scale, shift).  In
         training mode the conv launch emits the per-workgroup partial statistics itself when it can (strip kernel);
         otherwise a separate statistics pass runs over c."""
-        wp = ops.pack_weights(w)
+        wp = self.packed(w)
         if training and not self.in_nchw:
             n16 = (self.cout + 15) // 16 * 16
             buf = ops.bn_partial_buffer(x.device, n16)
@@ -48,8 +53,41 @@ class ConvSpec:
         return ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil, in_nchw=self.in_nchw)
 
     def dgrad(self, dy, w, hw, **kw):
-        return ops.conv2d_dgrad(dy, ops.pack_weights(w, transpose=True), self.cin, hw[0], hw[1], self.k, self.k,
+        return ops.conv2d_dgrad(dy, self.packed(w, transpose=True), self.cin, hw[0], hw[1], self.k, self.k,
                                 self.stride, self.pad, self.dil, **kw)
+
+
+class WeightPacker:
+    """Keeps the packed (forward) and transposed-packed (dgrad) images of every convolution weight of a model up to date
+    with ONE launch per forward pass instead of two small launches per convolution."""
+
+    def __init__(self, pairs):
+        self.pairs = list(pairs)           # (ConvSpec, weight Parameter, needs_dgrad)
+        self._key = None
+
+    def _build(self):
+        rows, dev = [], self.pairs[0][1].device
+        L = ops._lib.lib()
+        for spec, w, need_t in self.pairs:
+            o, i, kh, kw = w.shape
+            for transpose in ((False, True) if need_t else (False,)):
+                n_out, k_in = (i, o) if transpose else (o, i)
+                n = L.dam_conv_packed_weight_count(n_out, k_in, kh, kw)
+                buf = torch.empty(n, dtype=torch.float32, device=dev)
+                if transpose:
+                    spec.wpt = buf
+                else:
+                    spec.wp = buf
+                rows.append([w.data_ptr(), buf.data_ptr(), o, i, kh, kw, int(transpose), n])
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.n, self.max_total = len(rows), max(r[7] for r in rows)
+
+    def pack_all(self):
+        key = tuple(w.data_ptr() for _, w, _ in self.pairs)
+        if key != self._key:               # parameters moved (.to(device), optimizer flattening): rebuild the table
+            self._build()
+            self._key = key
+        ops.pack_weights_multi(self.desc, self.n, self.max_total)
 
 
 def _bn_fwd_stats(c, bn, training):
@@ -308,8 +346,20 @@ class MixingNet(nn.Module):
             raise RuntimeError('expected scalar type Float but found %s' % str(x.dtype).replace('torch.', '').capitalize())
         return x.contiguous()
 
+    def conv_pairs(self):
+        """(ConvSpec, weight, needs_dgrad) of every convolution of the trunk; overridden by the models."""
+        return []
+
+    def _pack_weights(self):
+        if getattr(self, '_packer', None) is None:
+            pairs = self.conv_pairs()
+            self._packer = WeightPacker(pairs) if pairs else False
+        if self._packer:
+            self._packer.pack_all()
+
     def forward(self, x):
         x = self._check_input(x)
+        self._pack_weights()
         masked, g = self._heads(self.trunk(x), x)
         return masked, tuple(g[:, s:s + 1] for s in range(self.n_stems))
 
@@ -317,5 +367,6 @@ class MixingNet(nn.Module):
         """Fused fast path for criterion == nn.MSELoss(): returns (loss, masked, gains tuple); masked and the
         gains are detached outputs, loss carries the gradient."""
         x = self._check_input(x)
+        self._pack_weights()
         loss, masked, g = self._heads.forward_mse(self.trunk(x), x, gt)
         return loss, masked, tuple(g[:, s:s + 1] for s in range(self.n_stems))

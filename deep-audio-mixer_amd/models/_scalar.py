@@ -20,6 +20,9 @@ class ScalarMixingNet(MixingNet):
             raise ValueError('input_shape %r is too small for the five valid convolutions' % (input_shape,))
         self._init_heads(128, n_stems, f * t)
 
+    def conv_pairs(self):
+        return [(getattr(self, 'conv_b%d' % i).spec, getattr(self, 'conv_b%d' % i).conv.weight, i > 1) for i in range(1, 6)]
+
     def trunk(self, x):
         out = x
         for i in range(1, 6):

@@ -42,6 +42,15 @@ class ResNet(MixingNet):
             self.in_planes = planes * block.expansion
         return nn.Sequential(*layers)
 
+    def conv_pairs(self):
+        pairs = [(self._stem, self.conv1.weight, False)]          # the input needs no gradient
+        for i in range(1, 7):
+            for blk in getattr(self, 'layer%d' % i):
+                pairs += [(blk.spec1, blk.conv1.weight, True), (blk.spec2, blk.conv2.weight, True)]
+                if blk.spec_sc is not None:
+                    pairs.append((blk.spec_sc, blk.shortcut[0].weight, True))
+        return pairs
+
     def trunk(self, x):
         out = ConvBnReluFn.apply(x, self.conv1.weight, None, self.bn1.weight, self.bn1.bias, self._stem, self.bn1,
                                  self.training)

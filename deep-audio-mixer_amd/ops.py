@@ -35,6 +35,12 @@ def pack_weights(w, transpose=False, out=None):
     return out
 
 
+def pack_weights_multi(desc, n_tensors, max_total):
+    """desc: CUDA int64 tensor [n,8] = {src ptr, dst ptr, O, I, KH, KW, transpose, count}: all packs in one launch."""
+    _lib.check(_lib.lib().dam_conv_pack_weights_multi_f32(_lib.ptr(desc), n_tensors, max_total, _lib.stream()),
+               'dam_conv_pack_weights_multi_f32')
+
+
 def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shift, relu_in, y, OHt, OWt, Ho, Wo,
              out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
              res=None, res_mask=None, bn_partial=None):

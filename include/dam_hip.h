@@ -84,6 +84,10 @@ int64_t dam_conv_packed_weight_count(int n_out, int k_in, int kh, int kw);
 int dam_conv_pack_weights_f32(const float* w_oihw, int O, int I, int KH, int KW, int transpose,
                               float* packed, void* stream);
 
+/* The same packing for many tensors in one launch.  desc_dev: DEVICE array [n_tensors][8] of int64 =
+ * {w_oihw pointer, packed pointer, O, I, KH, KW, transpose, packed float count}; max_total = largest count. */
+int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int64_t max_total, void* stream);
+
 /* y[b, oh*out_stride+out_off_h, ow*out_stride+out_off_w, :] (+= res [* (res_mask > 0)]) =
  *     bias + sum_{a<nA, b<nB, k} Wp[wt_base + a*wt_sa + b*wt_sb][k][:] *
  *            f(x[b, oh*in_stride + off_h + a*step_h, ow*in_stride + off_w + b*step_w, k])
