@@ -6,7 +6,8 @@
 //   * a workgroup walks `tpw` CONSECUTIVE 64*MB-pixel tiles of one image.  Input rows live in an LDS ring indexed by
 //     (absolute row & (NR-1)); a new tile only fetches the rows the previous tiles did not (halo re-reads drop from
 //     2.5x to ~1.1x of the input for 3x3 convs on 130-wide images);
-//   * rows are fetched by a dedicated LOADER wave (wave 4) with global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip,
+//   * rows are fetched by dedicated LOADER waves (waves 4..7: one wave sustains only ~1 LDS-DMA piece per 1k cycles)
+//     with global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip,
 //     1 KB per instruction) for tile k+1 while the 4 compute waves run the MFMAs of tile k; one workgroup barrier per
 //     tile.  Compute waves never wait on HBM: their only global loads are the L2-resident packed weights;
 //   * LDS image: [chunk][ring row][column slot][16 ch] with the same stride-2 column de-interleave as the tile kernel;
@@ -40,8 +41,11 @@ __device__ __forceinline__ int fdiv(int e, int d, float inv_d) {   // e / d, 0 <
     return q;
 }
 
+constexpr int STRIP_LOADERS = 4;                        // loader waves per workgroup (waves 4..7)
+constexpr int STRIP_THREADS = 256 + 64 * STRIP_LOADERS;
+
 template <int MB, int NB>
-__global__ __launch_bounds__(320) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
+__global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
                                                          const float* __restrict__ res_mask, float* __restrict__ stats) {
@@ -65,14 +69,14 @@ __global__ __launch_bounds__(320) void conv_strip_kernel(const ConvGeo g, const 
     DAM_STAMP(1);
 
     // zero the whole ring once: border slots stay zero for the lifetime of the workgroup
-    for (int e = tid * 16; e < CHB * g.nchunks; e += 320 * 16)
+    for (int e = tid * 16; e < CHB * g.nchunks; e += STRIP_THREADS * 16)
         *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     // thin layers: the packed weights of this N tile are small; keep them in LDS so that the MFMA loop never waits on L2
     const int w_base = CHB * g.nchunks;       // always address LDS as smem + integer offset (a derived pointer variable
                                               // degrades to flat_load, which is slower and also counts on vmcnt)
     if (sg.w_lds) {
         const int n4 = sg.w_taps * g.nchunks * NB * 64;          // float4 count: [tap][chunk][nb][lane]
-        for (int e = tid; e < n4; e += 320) {
+        for (int e = tid; e < n4; e += STRIP_THREADS) {
             const int ln = e & 63, nb = (e >> 6) % NB, tc = (e >> 6) / NB;
             *reinterpret_cast<float4*>(smem + w_base + e * 16) = Wp[((size_t)tc * g.NBtot + nb0 + nb) * 64 + ln];
         }
@@ -124,13 +128,13 @@ __global__ __launch_bounds__(320) void conv_strip_kernel(const ConvGeo g, const 
     {
         int lo, hi;
         tile_rows(t_begin, lo, hi);
-        load_rows(lo, hi, wave, 5);          // first tile: every wave fetches (the compute waves have nothing else to do)
+        load_rows(lo, hi, wave, 4 + STRIP_LOADERS);          // first tile: every wave fetches (the compute waves have nothing else to do)
         loaded_hi = hi;
     }
     __syncthreads();      // (compiler drains vmcnt before the barrier: the DMA has landed)
     DAM_STAMP(3);
     // the loader shares its SIMD with compute waves that keep the issue port busy: without priority it is starved
-    if (wave == 4) __builtin_amdgcn_s_setprio(3);
+    if (wave >= 4) __builtin_amdgcn_s_setprio(3);
 
     // BatchNorm partial statistics of this workgroup's outputs (shifted sums per lane, channels 4*kq..+3 of block nb)
     float st_k[NB][4], st_s1[NB][4], st_s2[NB][4];
@@ -141,11 +145,11 @@ __global__ __launch_bounds__(320) void conv_strip_kernel(const ConvGeo g, const 
         for (int r = 0; r < 4; ++r) { st_k[nb][r] = 0.f; st_s1[nb][r] = 0.f; st_s2[nb][r] = 0.f; }
 
     for (int t = t_begin; t < t_end; ++t) {
-        if (wave == 4) {
+        if (wave >= 4) {
             if (t + 1 < t_end) {
                 int lo, hi;
                 tile_rows(t + 1, lo, hi);
-                if (hi > loaded_hi) load_rows(loaded_hi + 1 > lo ? loaded_hi + 1 : lo, hi, 0, 1);
+                if (hi > loaded_hi) load_rows(loaded_hi + 1 > lo ? loaded_hi + 1 : lo, hi, wave - 4, STRIP_LOADERS);
             }
             DAM_STAMP(4);
         } else {
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(320) void conv_strip_kernel(const ConvGeo g, const 
         // tile boundary: the loader's DMA must have landed, the compute waves' LDS reads are already consumed by their
         // MFMAs.  A raw s_barrier (not __syncthreads) so that the compute waves do NOT drain their output stores here.
         DAM_STAMP(6);
-        if (wave == 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wave >= 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         DAM_STAMP(7);
     }
@@ -350,7 +354,7 @@ static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, co
         }
     }
     dim3 grid((unsigned)sg.strips, (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
-    hipLaunchKernelGGL((conv_strip_kernel<MB, NB>), grid, dim3(320), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
+    hipLaunchKernelGGL((conv_strip_kernel<MB, NB>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
                        Y, res, res_mask, stats);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
