@@ -149,3 +149,56 @@ def test_mix_song_smooth_matches_oracle(dam):
     model.train()
     _, raw_t, _ = mix_song_smooth(d, model, tracks, chunk_length=1, sr=sr)
     assert len(raw_t['bass']) == n_chunks - 1 and not np.allclose(raw_t['bass'], raw['bass'])
+
+
+def _ddp_gpu_worker(rank, world, port, out_dir):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch
+    import deep_audio_mixer_amd  # noqa: F401
+    from deep_audio_mixer_amd import distributed as ddist
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    torch.cuda.set_device(0)
+    ddist.init_process_group('gloo')                      # one GPU on the box: both ranks share it, gloo carries the bucket
+    torch.manual_seed(10 + rank)                          # different replicas before the broadcast
+    model = ResNet18(n_stems=2, input_shape=(129, 24)).cuda().train()
+    ddist.broadcast_module(model)
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, world_size=world)
+    x, gt = model_input(4, 2, 129, 24, seed=77)
+    idx = ddist.shard_indices(4, rank, world)
+    loss = model.forward_mse(torch.from_numpy(x[idx]).cuda(), torch.from_numpy(gt[idx]).cuda())[0]
+    loss.backward()
+    opt.step()                                            # gather -> all-reduce(sum) -> Adam with 1/world folded in
+    torch.save({'flat_grad': opt.flat_grad.cpu(), 'params': opt._flat.cpu(), 'loss': loss.item()},
+               os.path.join(out_dir, 'g%d.pt' % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks_one_gpu(dam, tmp_path):
+    """an N-rank step == a single-process step over N micro-batches with the gradients averaged and local
+    BatchNorm statistics.  Two ranks share the box's one GPU (gloo transport; RCCL needs one GPU per rank)."""
+    import socket
+    import torch.multiprocessing as mp
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'g0.pt'), torch.load(tmp_path / 'g1.pt')
+    assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['flat_grad'], r1['flat_grad'])
+    # single process: same initial replica (rank 0's seed), the two micro-batches one after the other
+    torch.manual_seed(10)
+    model = ResNet18(n_stems=2, input_shape=(129, 24)).cuda().train()
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    x, gt = model_input(4, 2, 129, 24, seed=77)
+    total = None
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    for idx in ([0, 2], [1, 3]):
+        model.load_state_dict(state)                      # BN running stats: each replica starts from the same buffers
+        opt.zero_grad()
+        model.forward_mse(torch.from_numpy(x[idx]).cuda(), torch.from_numpy(gt[idx]).cuda())[0].backward()
+        g = opt.gather_grads().clone()
+        total = g if total is None else total + g
+    want = total.cpu()                                    # rank buckets hold the SUM; Adam divides by the world size
+    assert torch.allclose(r0['flat_grad'], want, rtol=1e-4, atol=1e-6 * want.abs().max())
