@@ -127,6 +127,22 @@ class ConvBnReluFn(torch.autograd.Function):
         return dx, dw, dbias, dgamma, dbeta, None, None, None
 
 
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) of ConvBlock2d as a HIP kernel; the mask is regenerated in backward from the saved call offset."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        snap = ops.dropout_tick(x.device, x.numel())
+        ctx.p, ctx.seed = p, torch.initial_seed()
+        ctx.save_for_backward(snap)
+        return ops.dropout_apply(x, p, ctx.seed, snap)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (snap,) = ctx.saved_tensors
+        return ops.dropout_apply(dy, ctx.p, ctx.seed, snap), None
+
+
 class BasicBlockFn(torch.autograd.Function):
     """models/model_resnet.py:23-28: relu(bn2(conv2(relu(bn1(conv1(x))))) + shortcut(x))."""
 
@@ -259,7 +275,7 @@ class ConvBlock2d(nn.Module):
         out = ConvBnReluFn.apply(x, self.conv.weight, self.conv.bias, self.batch_norm.weight, self.batch_norm.bias,
                                  self.spec, self.batch_norm, self.training)
         if self.training and self.dropout:
-            out = self.dropout(out)
+            out = DropoutFn.apply(out, self.dropout.p) if self.dropout.p > 0 else out
         return out
 
 

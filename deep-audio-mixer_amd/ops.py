@@ -327,3 +327,26 @@ def gain_ramp_apply(audio, gains):
     _lib.check(_lib.lib().dam_gain_ramp_apply(_lib.ptr(audio), _lib.ptr(gains), 1 if audio.dtype == torch.float64 else 0,
                                               rows, n, gains.numel(), _lib.ptr(out), _lib.stream()), 'dam_gain_ramp_apply')
     return out
+
+
+# ----------------------------------------------------------------------------- dropout
+_dropout_counters = {}
+
+
+def dropout_tick(device, n):
+    """Snapshots and advances the per-device dropout call counter; returns the snapshot tensor (int64[1])."""
+    key = (device.type, device.index)
+    if key not in _dropout_counters:
+        _dropout_counters[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    snap = torch.empty(1, dtype=torch.int64, device=device)
+    _lib.check(_lib.lib().dam_dropout_tick(_lib.ptr(_dropout_counters[key]), n, _lib.ptr(snap), _lib.stream()), 'dam_dropout_tick')
+    return snap
+
+
+def dropout_apply(x, p, seed, snapshot):
+    _lib.require_cuda(x, snapshot)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().dam_dropout_apply_f32(_lib.ptr(x), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(snapshot),
+                                                _lib.ptr(y), _lib.stream()), 'dam_dropout_apply_f32')
+    return y

@@ -169,6 +169,14 @@ int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, in
 int dam_channel_sum_f32(const float* x, int64_t n_pixels, int C, int n_real, float* out, float* workspace,
                         void* stream);
 
+/* Inverted dropout of ConvBlock2d (models/model_scalar_1s.py:177,187-188; applied only in training mode).  The mask is a
+ * counter-based function of (seed, call offset, element index): dam_dropout_tick snapshots and advances the DEVICE
+ * call counter by n (graph replays draw fresh masks), dam_dropout_apply_f32 computes y = keep ? x/(1-p) : 0 for the
+ * snapshot -- called again on the gradient with the same snapshot in backward.  n % 4 == 0. */
+int dam_dropout_tick(int64_t* counter, int64_t n, int64_t* snapshot, void* stream);
+int dam_dropout_apply_f32(const float* x, int64_t n, float p, uint64_t seed, const int64_t* snapshot, float* y,
+                          void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Gain heads, gain-weighted sum and MSE.  Replace models/model_resnet.py:75-85,108-126 (same code in
  * models/model_scalar_1s.py:222-273, models/model_scalar_2s.py:79-132) and nn.MSELoss at

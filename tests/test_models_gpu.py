@@ -156,3 +156,28 @@ def test_wrong_inputs_fail_loudly(dam):
         m(torch.zeros(1, 4, 1025, 216))
     with pytest.raises(ValueError, match='flattened_dim'):                     # wrong clip length for this head width
         m(torch.zeros(1, 4, 1025, 130, device='cuda'))
+
+
+def test_dropout_kernel_statistics(dam_lib):
+    """ConvBlock2d dropout (training mode only): keep-rate, 1/(1-p) scaling, fresh mask per call, backward uses the
+    forward's mask, eval mode is the identity."""
+    from deep_audio_mixer_amd.layers import DropoutFn
+    x = torch.ones(64, 1024, device='cuda', requires_grad=True)
+    y1 = DropoutFn.apply(x, 0.3)
+    y2 = DropoutFn.apply(x, 0.3)
+    keep = (y1 > 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    assert torch.allclose(y1[y1 > 0], torch.full_like(y1[y1 > 0], 1 / 0.7))
+    assert not torch.equal(y1 > 0, y2 > 0)
+    y1.sum().backward()
+    assert torch.equal(x.grad > 0, y1 > 0) and torch.allclose(x.grad[x.grad > 0], torch.full_like(x.grad[x.grad > 0], 1 / 0.7))
+    from deep_audio_mixer_amd.models.model_scalar_1s import MixingModelScalar1s
+    torch.manual_seed(0)
+    m = MixingModelScalar1s(n_stems=2, input_shape=(129, 80)).cuda()
+    xin = torch.randn(2, 2, 129, 80, device='cuda')
+    m.train()
+    a, b = m(xin)[0], m(xin)[0]
+    assert not torch.equal(a, b)                       # dropout active while training
+    m.eval()
+    a, b = m(xin)[0], m(xin)[0]
+    assert torch.equal(a, b)
