@@ -120,13 +120,38 @@ __global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) tw3[i] = tw[lane + 64 * i];  // W_2048^k
 
+    // float32 input: the raw samples of the wave's NEXT frame are requested before the FFT of the current one and only
+    // converted (channel mean) when that frame's turn comes, so the HBM latency of a frame hides under the previous FFT.
+    constexpr bool PREFETCH = sizeof(PCM) == 4;
+    typedef float raw_t __attribute__((ext_vector_type(2 * CH), aligned(4)));
+    raw_t rawn[PREFETCH ? 16 : 1];
+    auto frame_interior = [&](int t) {
+        const int64_t p0 = (int64_t)t * hop - NFFT / 2;
+        return t < n_frames && p0 >= 0 && p0 + NFFT <= n_samples;
+    };
+    auto issue_frame = [&](int t) {
+        if (PREFETCH && frame_interior(t)) {
+            const int64_t p0 = (int64_t)t * hop - NFFT / 2;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1)
+                rawn[n1] = *reinterpret_cast<const raw_t*>(trk + (int64_t)CH * (p0 + 2 * (lane + 64 * n1)));
+        }
+    };
+    issue_frame(t0 + wave);
+
     for (int q = 0; q < TF / STFT_WAVES; ++q) {
         const int tl = q * STFT_WAVES + wave;
         const int t = t0 + tl;
         if (t >= n_frames) break;   // wave-uniform; no workgroup barrier inside this loop
         const int64_t p0 = (int64_t)t * hop - NFFT / 2;
         float2 v[16];
-        if (p0 >= 0 && p0 + NFFT <= n_samples) {
+        if (PREFETCH && frame_interior(t)) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                if constexpr (CH == 2) v[n1] = make_float2((rawn[n1].x + rawn[n1].y) * 0.5f, (rawn[n1].z + rawn[n1].w) * 0.5f);
+                else v[n1] = make_float2(rawn[n1].x, rawn[n1].y);
+            }
+        } else if (p0 >= 0 && p0 + NFFT <= n_samples) {
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) v[n1] = load_pair_interior<PCM, CH>(trk, p0 + 2 * (lane + 64 * n1));
         } else {
@@ -137,6 +162,7 @@ __global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
                                     mono_at<PCM, CH>(trk, reflect(p + 1, n_samples)));
             }
         }
+        if (q + 1 < TF / STFT_WAVES) issue_frame(t + STFT_WAVES);     // in flight during this frame's FFT
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(v[n1].x * win[n1].x, v[n1].y * win[n1].y);
 
