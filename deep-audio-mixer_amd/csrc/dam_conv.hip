@@ -36,12 +36,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          const float* __restrict__ in_scale,
                                                          const float* __restrict__ in_shift, float* __restrict__ Y,
-                                                         const float* __restrict__ res, const float* __restrict__ res_mask) {
+                                                         const float* __restrict__ res, const float* __restrict__ res_mask,
+                                                         float* __restrict__ splitk_ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
     constexpr int MW = 16 * MB, TM = 4 * MW;
-    const int img = blockIdx.z, nb0 = blockIdx.y * NB;
+    const int ks = blockIdx.y % g.ksplit;                       // split-K slice of this workgroup
+    const int img = blockIdx.z, nb0 = (blockIdx.y / g.ksplit) * NB;
     const int HoWo = g.Ho * g.Wo;
     const int p0 = blockIdx.x * TM;
     const int oh_first = p0 / g.Wo;
@@ -70,8 +72,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
     pg.H = g.H; pg.W = g.W; pg.C = g.C; pg.s = g.s; pg.c0 = g.c0; pg.PR = g.PR; pg.PWin = g.PWin; pg.PWs = g.PWs;
     pg.PWT = g.PWT; pg.in_nchw = g.in_nchw; pg.relu_in = g.relu_in;
     const int ngroups = g.nchunks / g.CG;
-    for (int cg = 0; cg < ngroups; ++cg) {
-        if (cg) __syncthreads();
+    const int cg_lo = ks * g.gps, cg_hi = cg_lo + g.gps < ngroups ? cg_lo + g.gps : ngroups;
+    for (int cg = cg_lo; cg < cg_hi; ++cg) {
+        if (cg != cg_lo) __syncthreads();
         // ---- stage the input patch of this channel group ----
         {
             const size_t img_elems = (size_t)g.H * g.W * g.C;
@@ -141,11 +144,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
             const int ch = (nb0 + nb) * 16 + kq * 4;
             if (ch >= g.N) continue;
             v4f v = acc[mb][nb];
+            const size_t o = opix * g.N + ch;
+            if (g.ksplit > 1) {      // raw partial sums; bias / residual are applied by splitk_reduce_kernel
+                *reinterpret_cast<float4*>(splitk_ws + (size_t)ks * ((size_t)g.B * g.OHt * g.OWt * g.N) + o) =
+                    make_float4(v.x, v.y, v.z, v.w);
+                continue;
+            }
             if (bias) {
                 const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             }
-            const size_t o = opix * g.N + ch;
             if (res) {   // dgrad of a residual block: + dOut * (out > 0)
                 const float4 rv = *reinterpret_cast<const float4*>(res + o);
                 if (res_mask) {
@@ -202,9 +210,35 @@ __global__ void pack_weights_multi_kernel(const long long* __restrict__ desc) {
     }
 }
 
+// y = sum_ks slab[ks] + bias (+ res [* (mask > 0)]) for the split-K launches of the tile kernel (fixed order: deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t n4, int Q, const float* __restrict__ bias,
+                                     const float* __restrict__ res, const float* __restrict__ res_mask, float* __restrict__ y) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(ws)[e];
+        for (int k = 1; k < ksplit; ++k) {
+            const float4 b = reinterpret_cast<const float4*>(ws)[(int64_t)k * n4 + e];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (bias) {
+            const float4 b = reinterpret_cast<const float4*>(bias)[e % Q];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (res) {
+            const float4 r = reinterpret_cast<const float4*>(res)[e];
+            if (res_mask) {
+                const float4 m = reinterpret_cast<const float4*>(res_mask)[e];
+                a.x += m.x > 0.f ? r.x : 0.f; a.y += m.y > 0.f ? r.y : 0.f; a.z += m.z > 0.f ? r.z : 0.f; a.w += m.w > 0.f ? r.w : 0.f;
+            } else {
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+            }
+        }
+        reinterpret_cast<float4*>(y)[e] = a;
+    }
+}
+
 template <int MB, int NB>
 int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc,
-                const float* sh, float* Y, const float* res, const float* res_mask, hipStream_t st) {
+                const float* sh, float* Y, const float* res, const float* res_mask, float* splitk_ws, hipStream_t st) {
     constexpr int TM = 64 * MB;
     if (lds > 64 * 1024) {
         static bool raised = false;   // per instantiation
@@ -215,10 +249,16 @@ int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
             raised = true;
         }
     }
-    dim3 grid((unsigned)cdiv((int64_t)g.Ho * g.Wo, TM), (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
+    dim3 grid((unsigned)cdiv((int64_t)g.Ho * g.Wo, TM), (unsigned)(cdiv(g.N / 16, NB) * g.ksplit), (unsigned)g.B);
     hipLaunchKernelGGL((conv_igemm_kernel<MB, NB>), grid, dim3(256), lds, st, g, X, reinterpret_cast<const float4*>(Wp),
-                       bias, sc, sh, Y, res, res_mask);
+                       bias, sc, sh, Y, res, res_mask, splitk_ws);
     DAM_CHECK_LAUNCH();
+    if (g.ksplit > 1) {
+        const int64_t n4 = (int64_t)g.B * g.OHt * g.OWt * g.N / 4;
+        const int blocks = (int)(cdiv(n4, 256) < 2048 ? cdiv(n4, 256) : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, g.ksplit, n4, g.N / 4, bias, res, res_mask, Y);
+        DAM_CHECK_LAUNCH();
+    }
     return DAM_OK;
 }
 
@@ -263,7 +303,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
                                       int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                                       int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                                       const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
-                                      void* stream) {
+                                      float* workspace, int64_t workspace_floats, void* stream) {
     using namespace dam;
     if (bn_parts_host) *bn_parts_host = 0;
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || nA <= 0 || nB <= 0)
@@ -286,7 +326,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     g.PWT = g.PWs * in_stride;
 
     hipStream_t st = (hipStream_t)stream;
-    g.PR = 0; g.CG = 1; g.tiles_m = 0;
+    g.PR = 0; g.CG = 1; g.tiles_m = 0; g.ksplit = 1; g.gps = 1 << 30;
     // persistent strip variant (LDS-DMA ring, optional fused BatchNorm statistics) when the layer fits it
     if (!in_nchw && !in_scale) {
         int parts = 0;
@@ -302,13 +342,24 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
             if (rc2 != DAM_ERR_UNSUPPORTED) return rc2;
         }
     }
-    // tile choice: fill the chip (>= ~2 workgroups per CU when the layer allows), then prefer big tiles
+    // tile choice.  With a workspace: keep big tiles (weights are streamed per workgroup: FLOPs per weight byte grow with
+    // the tile) and get the workgroup count from split-K over channel groups; otherwise shrink tiles to fill the chip.
     const int64_t npix = (int64_t)Ho * Wo;
     const int nblk = n_out / 16;
     int MB = 4, NB = nblk % 4 == 0 ? 4 : (nblk % 2 == 0 ? 2 : 1);   // NB must divide the block count
     auto wgs = [&](int mb, int nb) { return cdiv(npix, 64 * mb) * cdiv(nblk, nb) * B; };
-    while (wgs(MB, NB) < 512 && (MB > 1 || NB > 1)) {
-        if (MB > 1 && (MB >= NB || NB == 1)) MB >>= 1; else NB >>= 1;
+    const bool can_split = workspace && out_stride == 1 && Ho == OHt && Wo == OWt && out_off_h == 0 && out_off_w == 0 &&
+                           k_chunks >= 4;
+    if (can_split) {
+        int64_t best_pad = -1;
+        for (int mb = 4; mb >= 1; mb >>= 1) {           // least padded pixels, larger tile on (near) ties
+            const int64_t pad = cdiv(npix, 64 * mb) * 64 * mb;
+            if (best_pad < 0 || pad * 10 < best_pad * 9) { best_pad = pad; MB = mb; }
+        }
+    } else {
+        while (wgs(MB, NB) < 512 && (MB > 1 || NB > 1)) {
+            if (MB > 1 && (MB >= NB || NB == 1)) MB >>= 1; else NB >>= 1;
+        }
     }
     // LDS: shrink the channel group, then the M tile, until the patch fits
     const size_t LDS_MAX = 64 * 1024;
@@ -331,9 +382,21 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     }
     g.CG = CG;
     g.tiles_m = (int)cdiv(npix, 64 * MB);
+    if (can_split) {
+        const int ngroups = k_chunks / CG;
+        const int64_t w = wgs(MB, NB), out_elems = (int64_t)B * OHt * OWt * n_out;
+        int ksplit = (int)cdiv(512, w);
+        if (ksplit > 8) ksplit = 8;
+        if (ksplit > ngroups) ksplit = ngroups;
+        while (ksplit > 1 && ksplit * out_elems > workspace_floats) --ksplit;
+        if (ksplit > 1) {
+            g.gps = (int)cdiv(ngroups, ksplit);
+            g.ksplit = (int)cdiv(ngroups, g.gps);
+        }
+    }
     const size_t lds = (size_t)CG * g.PR * g.PWT * 64;
 #define DAM_CONV_CASE(M_, N_) \
-    if (MB == M_ && NB == N_) return launch_conv<M_, N_>(g, lds, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, st)
+    if (MB == M_ && NB == N_) return launch_conv<M_, N_>(g, lds, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st)
     DAM_CONV_CASE(4, 4); DAM_CONV_CASE(4, 2); DAM_CONV_CASE(4, 1);
     DAM_CONV_CASE(2, 4); DAM_CONV_CASE(2, 2); DAM_CONV_CASE(2, 1);
     DAM_CONV_CASE(1, 4); DAM_CONV_CASE(1, 2); DAM_CONV_CASE(1, 1);

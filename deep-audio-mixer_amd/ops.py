@@ -45,12 +45,13 @@ def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shi
              out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
              res=None, res_mask=None, bn_partial=None):
     parts = ctypes.c_int(0)
+    ws = _workspace(y.device, min(8 * y.numel(), 64 << 20))        # split-K scratch (grow-only, shared)
     st = _lib.lib().dam_conv2d_tapgrid_f32(
         _lib.ptr(x), B, H, W, C, 1 if in_nchw else 0, _lib.ptr(wp), k_chunks, n_out, _lib.ptr(bias),
         _lib.ptr(in_scale), _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(y), OHt, OWt, Ho, Wo, out_stride,
         oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb, _lib.ptr(res),
         _lib.ptr(res_mask), _lib.ptr(bn_partial), ctypes.byref(parts) if bn_partial is not None else None,
-        _lib.stream())
+        _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(st, 'dam_conv2d_tapgrid_f32')
     return parts.value
 

@@ -102,14 +102,16 @@ int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int6
  * bn_partial (optional, >= dam_bn_workspace_floats(n_out) floats): if the launch can also produce the BatchNorm
  * partial statistics of y (records (n, mean, M2) per workgroup and channel) it does so and stores the record count
  * in *bn_parts_host (a HOST int); 0 there means "not produced" and the caller runs dam_bn_stats_f32 instead.
- * Feed the records to dam_bn_finalize_f32. */
+ * Feed the records to dam_bn_finalize_f32.
+ * workspace (optional): scratch for split-K over the input channels (used for small-spatial, wide layers; at most
+ * 8 * B*OHt*OWt*n_out floats are used, fewer if less is given); partial slabs are summed in a fixed order. */
 int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
                            int k_chunks, int n_out, const float* bias, const float* in_scale,
                            const float* in_shift, int relu_in, float* y, int OHt, int OWt, int Ho, int Wo,
                            int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                            int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                            const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
-                           void* stream);
+                           float* workspace, int64_t workspace_floats, void* stream);
 
 /* Weight gradient of the same convolutions (autograd of nn.Conv2d reached from loss.backward(),
  * model_trainer.py:36):  dw[n][k][kh][kw] = sum_{b,oh,ow} dy[b,oh,ow,n] * f(x[b, oh*stride+kh*dil-pad, ow*stride+kw*dil-pad, k])
