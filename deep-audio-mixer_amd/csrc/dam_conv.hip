@@ -350,13 +350,18 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     auto wgs = [&](int mb, int nb) { return cdiv(npix, 64 * mb) * cdiv(nblk, nb) * B; };
     const bool can_split = workspace && out_stride == 1 && Ho == OHt && Wo == OWt && out_off_h == 0 && out_off_w == 0 &&
                            k_chunks >= 4;
-    if (can_split) {
+    bool split = can_split;
+    if (split) {
+        for (int mb = 4; mb >= 2; mb >>= 1)              // enough workgroups without splitting: take the largest such tile
+            if (wgs(mb, NB) >= 400) { MB = mb; split = false; break; }
+    }
+    if (split) {
         int64_t best_pad = -1;
         for (int mb = 4; mb >= 1; mb >>= 1) {           // least padded pixels, larger tile on (near) ties
             const int64_t pad = cdiv(npix, 64 * mb) * 64 * mb;
             if (best_pad < 0 || pad * 10 < best_pad * 9) { best_pad = pad; MB = mb; }
         }
-    } else {
+    } else if (!can_split) {
         while (wgs(MB, NB) < 512 && (MB > 1 || NB > 1)) {
             if (MB > 1 && (MB >= NB || NB == 1)) MB >>= 1; else NB >>= 1;
         }
@@ -382,7 +387,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     }
     g.CG = CG;
     g.tiles_m = (int)cdiv(npix, 64 * MB);
-    if (can_split) {
+    if (split) {
         const int ngroups = k_chunks / CG;
         const int64_t w = wgs(MB, NB), out_elems = (int64_t)B * OHt * OWt * n_out;
         int ksplit = (int)cdiv(512, w);
