@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
     const int img = blockIdx.z, nb0 = (blockIdx.y / g.ksplit) * NB;
     const int HoWo = g.Ho * g.Wo;
     const int p0 = blockIdx.x * TM;
-    const int oh_first = p0 / g.Wo;
+    const float inv_wo = 1.0f / (float)g.Wo;
+    const int oh_first = fast_div(p0, g.Wo, inv_wo);
     const int chunk_bytes = g.PR * g.PWT * 64;
 
     // per-lane LDS base of each M block (pixel of column j)
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
         int p = p0 + wave * MW + mb * 16 + j;
         pix[mb] = p;
         p = p < HoWo ? p : HoWo - 1;
-        const int oh = p / g.Wo, ow = p - oh * g.Wo;
+        const int oh = fast_div(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
         base_b[mb] = (((oh - oh_first) * g.s) * g.PWT + ow) * 64 + kq * 16;
     }
 
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
     for (int mb = 0; mb < MB; ++mb) {
         const int p = pix[mb];
         if (p >= HoWo) continue;
-        const int oh = p / g.Wo, ow = p - oh * g.Wo;
+        const int oh = fast_div(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
         const size_t opix = ((size_t)img * g.OHt + (oh * g.os + g.oo_h)) * g.OWt + (ow * g.os + g.oo_w);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {

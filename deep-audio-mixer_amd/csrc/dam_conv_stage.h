@@ -38,6 +38,9 @@ __device__ __forceinline__ void stage_patch(unsigned char* smem, int chunk_bytes
         const float inv_ipr = 1.0f / (float)ipr;
         const int total = g.PR * ipr;
         const int ch0 = chunk0 * 16;
+        // (row, item-in-row) of this thread's items advance incrementally: one division per call, not one per item
+        const int step_pr = 256 / ipr, step_rem = 256 - step_pr * ipr;
+        int pr = fast_div(tid, ipr, inv_ipr), rem = tid - pr * ipr;
         for (int base = tid; base < total; base += 256 * STAGE_U) {
             float4 v[STAGE_U];
             int dst[STAGE_U];
@@ -47,16 +50,17 @@ __device__ __forceinline__ void stage_patch(unsigned char* smem, int chunk_bytes
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 dst[u] = -1;
                 if (e < total) {
-                    const int pr = fast_div(e, ipr, inv_ipr), rem = e - pr * ipr;
                     const int pw = rem >> qshift, cq = rem & (qpp - 1);
                     const int ih = ih0 + pr, iw = g.c0 + pw;
                     const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
                     dst[u] = (cq >> 2) * chunk_bytes + ((pr * g.PWT + slot) * 16 + (cq & 3) * 4) * 4;
                     if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && ch0 + cq * 4 < g.C)
-                        v[u] = *reinterpret_cast<const float4*>(ximg + ((size_t)ih * g.W + iw) * g.C + ch0 + cq * 4);
+                        v[u] = *reinterpret_cast<const float4*>(ximg + (unsigned)((ih * g.W + iw) * g.C + ch0 + cq * 4));
                     else
                         dst[u] = -2 - dst[u];            // out of the tensor: stays zero, no BN prologue
                 }
+                rem += step_rem; pr += step_pr;
+                if (rem >= ipr) { rem -= ipr; ++pr; }
             }
 #pragma unroll
             for (int u = 0; u < STAGE_U; ++u) {
