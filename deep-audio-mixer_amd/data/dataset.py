@@ -10,6 +10,8 @@ Same constructor, ``__getitem__(i) -> (train_features [S,1025,T], gt_features [1
     in-memory arrays via ``MultitrackAudioDataset.from_arrays``;
   * the per-item prints of the reference (:284,287-289) are behind ``verbose=True``;
   * ``normalize=True`` enables the per-frame max-abs normalisation that is commented out at :159-160 (SURVEY F6);
+  * ``compute_features=False`` reads the pre-computed feature cache written by ``_precompute_features()``; reader and
+    writer agree on the writer's file names (they do not at the reference HEAD, SURVEY F10);
   * ``tracklist`` may name any number of stems (last entry = the target mix).
 """
 import os
@@ -128,13 +130,46 @@ class MultitrackAudioDataset(data.Dataset):
         feats = features.stft_logmag(pcm, 2048, 1024, gain=gain, normalize=self._normalize)
         return feats[:-1], feats[-1]
 
+    # ---- pre-computed feature cache (data/dataset.py:213-268).  The reference's writer emits
+    #      {song}_FEATURES/{i}_train_{len}s[_norm].npy / {i}_gt_{len}s[_norm].npy while its reader looks for
+    #      {i}_train[_norm].npy: here both sides use the WRITER's names.
+    def _feature_paths(self, song_i, chunk_i):
+        song = self.songlist[song_i]
+        d = os.path.join(self._base_path, song, '{}_FEATURES'.format(song))
+        suffix = '_norm' if self._normalize else ''
+        return (d, os.path.join(d, '{}_train_{}s{}.npy'.format(chunk_i, self._chunk_length, suffix)),
+                os.path.join(d, '{}_gt_{}s{}.npy'.format(chunk_i, self._chunk_length, suffix)))
+
+    def _precompute_features(self):
+        """Runs the GPU front-end over every chunk of every song and stores float32 .npy files next to the audio."""
+        if self._arrays is not None:
+            raise ValueError('the feature cache lives next to the audio files: needs a base_path dataset')
+        for song_i in range(len(self.songlist)):
+            for chunk_i in range(int(self.song_durations[song_i] / self._chunk_length)):
+                d, p_train, p_gt = self._feature_paths(song_i, chunk_i)
+                os.makedirs(d, exist_ok=True)
+                aug, self._augment = self._augment, False          # the cache holds un-augmented features
+                try:
+                    train, gt = self._process_on_the_fly(song_i, chunk_i)
+                finally:
+                    self._augment = aug
+                np.save(p_train, train.cpu().numpy())
+                np.save(p_gt, gt.cpu().numpy())
+
+    def _process_precomputed(self, song_i, chunk_i) -> tuple:
+        _, p_train, p_gt = self._feature_paths(song_i, chunk_i)
+        train = torch.from_numpy(np.load(p_train)).to(self._device)
+        gt = torch.from_numpy(np.load(p_gt)).to(self._device)
+        if self._augment:
+            train = MultitrackAudioDataset._augment_features(train)
+        return train, gt
+
     def __getitem__(self, index: int) -> tuple:
         song_i, chunk_i = self._calculate_song_index(index)
         if self._verbose:
             print('Song {}, chunk {}'.format(self.songlist[song_i], chunk_i))
         if not self._compute_features:
-            raise NotImplementedError('the pre-computed feature cache (data/dataset.py:213-268) is stale at the reference '
-                                      'HEAD (SURVEY F10) and out of scope')
+            return self._process_precomputed(song_i, chunk_i)
         tic = time.time()
         train_features, gt_features = self._process_on_the_fly(song_i, chunk_i)
         if self._verbose:

@@ -203,3 +203,31 @@ def test_data_parallel_step_two_ranks_one_gpu(dam, tmp_path):
         total = g if total is None else total + g
     want = total.cpu()                                    # rank buckets hold the SUM; Adam divides by the world size
     assert torch.allclose(r0['flat_grad'], want, rtol=1e-4, atol=1e-6 * want.abs().max())
+
+
+def test_feature_cache_roundtrip(dam, tmp_path):
+    """data/dataset.py:213-268: features pre-computed to {song}_FEATURES/*.npy equal the on-the-fly ones."""
+    import wave
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    sr, n = 8000, 8000 * 3 + 123
+    rng = np.random.default_rng(2)
+    song = tmp_path / 'S' / 'S_STEMS_JOINED'
+    song.mkdir(parents=True)
+    for name in ('S_STEM_BASS.wav', 'S_STEM_DRUMS.wav', 'S_STEM_VOCALS.wav', 'S_STEM_OTHER.wav', '../S_MIX.wav'):
+        x = (rng.uniform(-0.5, 0.5, (n, 2)) * 32767).astype('<i2')
+        with wave.open(str(song / name), 'wb') as w:
+            w.setnchannels(2), w.setsampwidth(2), w.setframerate(sr)
+            w.writeframes(x.tobytes())
+    live = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr)
+    assert len(live) == 3
+    live._precompute_features()
+    assert sorted(os.listdir(tmp_path / 'S' / 'S_FEATURES'))[:2] == ['0_gt_1s.npy', '0_train_1s.npy']
+    cached = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr, compute_features=False)
+    for i in range(3):
+        a, b = live[i], cached[i]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and b[0].shape == (4, 1025, 8)
+    np.random.seed(0)
+    aug = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr, compute_features=False, augment_data=True)[1][0]
+    off = (aug - cached[1][0]).flatten(1)
+    assert torch.allclose(off, off[:, :1].expand_as(off), atol=1e-4)          # one dB offset per stem (:170-179)
+    assert off[:, 0].abs().max() <= 20 * np.log10(1.4) + 1e-3
