@@ -46,6 +46,8 @@ SIGNATURES = {
     'dam_masksum_mse_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p, c_p]),
     'dam_adam_l2_step_f32': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
     'dam_gain_ramp_apply': (c_i, [c_p, c_p, c_i, c_i64, c_i64, c_i, c_p, c_p]),
+    'dam_mixdown_workspace_elems': (c_i64, [c_i64]),
+    'dam_mixdown_peak_normalize': (c_i, [c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p]),
 }
 
 _lib = None

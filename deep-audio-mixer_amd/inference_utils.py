@@ -74,3 +74,21 @@ def mix_song_smooth(dataset, model, loaded_tracks: dict, chunk_length=1, sr=4410
         gains_dev = torch.from_numpy(np.ascontiguousarray(smoothed)).to(device=dev, dtype=pcm.dtype)
         mixed_tracks[t] = ops.gain_ramp_apply(pcm[i], gains_dev).cpu().numpy()
     return mixed_tracks, raw_gains, smooth_gains
+
+
+def mix_song_to_master(dataset, model, loaded_tracks: dict, chunk_length=1, sr=44100, normalize=True):
+    """mix_song_smooth followed by what every caller of the reference does next (inference.ipynb cells 9/11,
+    evaluation.py:59-66): ``track_sum = np.sum(list(mixed_tracks.values()), axis=0)`` and, if ``normalize``,
+    ``librosa.util.normalize(track_sum, axis=1)`` -- fused into one pass over the song on the GPU (the per-stem mixed
+    tracks are never materialised).  Returns (mix ndarray[channels, n], raw_gains, smooth_gains)."""
+    stems = [t for t in dataset.get_tracklist() if t != 'mix']
+    chunk_samples = chunk_length * sr
+    num_chunks = int(len(loaded_tracks[stems[0]][0]) / chunk_samples)
+    dev = next(model.parameters()).device
+    pcm = torch.stack([torch.from_numpy(np.ascontiguousarray(loaded_tracks[t])) for t in stems]).to(dev)
+    g = predict_chunk_gains(model, pcm, len(stems), num_chunks, chunk_samples).double().cpu().numpy()
+    raw_gains = {t: [float(scalar_dB_to_amplitude(v)) for v in g[:, i]] for i, t in enumerate(stems)}
+    smooth = np.stack([savgol_filter(raw_gains[t], _savgol_window(num_chunks), 2) for t in stems])
+    gains_dev = torch.from_numpy(np.ascontiguousarray(smooth)).to(device=dev, dtype=pcm.dtype)
+    mix = ops.mixdown_peak_normalize(pcm, gains_dev, normalize=normalize).cpu().numpy()
+    return mix, raw_gains, {t: list(smooth[i]) for i, t in enumerate(stems)}

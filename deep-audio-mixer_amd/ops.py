@@ -330,6 +330,23 @@ def gain_ramp_apply(audio, gains):
     return out
 
 
+def mixdown_peak_normalize(audio, gains, normalize=True):
+    """audio [S, rows, n], gains [S, n_gains] (same float dtype, CUDA) -> gain-ramped stem sum [rows, n], optionally
+    divided row-wise by its max-abs."""
+    _lib.require_cuda(audio, gains)
+    if audio.dtype != gains.dtype or audio.dtype not in (torch.float32, torch.float64):
+        raise TypeError('audio and gains must both be float32 or float64')
+    audio, gains = audio.contiguous(), gains.contiguous()
+    S, rows, n = audio.shape
+    mix = torch.empty((rows, n), dtype=audio.dtype, device=audio.device)
+    L = _lib.lib()
+    ws = torch.empty(L.dam_mixdown_workspace_elems(rows), dtype=audio.dtype, device=audio.device)
+    _lib.check(L.dam_mixdown_peak_normalize(_lib.ptr(audio), _lib.ptr(gains), 1 if audio.dtype == torch.float64 else 0, S, rows, n,
+                                            gains.shape[1], 1 if normalize else 0, _lib.ptr(mix), _lib.ptr(ws), _lib.stream()),
+               'dam_mixdown_peak_normalize')
+    return mix
+
+
 # ----------------------------------------------------------------------------- dropout
 _dropout_counters = {}
 

@@ -217,6 +217,15 @@ int dam_adam_l2_step_f32(float* params, const float* grads, float* exp_avg, floa
 int dam_gain_ramp_apply(const void* audio, const void* gains, int is_f64, int64_t rows, int64_t n_samples,
                         int n_gains, void* out, void* stream);
 
+/* The caller's next step (inference.ipynb cells 9/11, evaluation.py:59-66) fused with the gain ramp:
+ *   mix[r][n] = sum_s audio[s][r][n] * gains[s][min(n / (n_samples / n_gains), n_gains-1)]
+ * and, if normalize, each row divided by its max-abs (librosa.util.normalize(track_sum, axis=1)).
+ * audio [n_stems][rows][n_samples], gains [n_stems][n_gains], mix [rows][n_samples]; float64 or float32.
+ * workspace: dam_mixdown_workspace_elems(rows) elements of the same dtype. */
+int64_t dam_mixdown_workspace_elems(int64_t rows);
+int dam_mixdown_peak_normalize(const void* audio, const void* gains, int is_f64, int n_stems, int64_t rows,
+                               int64_t n_samples, int n_gains, int normalize, void* mix, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
