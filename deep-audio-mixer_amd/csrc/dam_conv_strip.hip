@@ -1,19 +1,21 @@
-// dam_conv_strip.hip -- persistent "strip" variant of the implicit-GEMM convolution (forward / dgrad) for layers whose
-// input rows, with ALL channels, fit an LDS ring: the HBM-bound full-resolution layers of ResNet18.
+// dam_conv_strip.hip -- persistent "strip" variant of the implicit-GEMM convolution (forward / dgrad) for THIN layers:
+// input rows with ALL channels fit an LDS ring and the packed weights of the output-channel tile fit beside it
+// (ResNet layer1/2 and their data gradients).  These layers sit at the MFMA/HBM ridge.
 //
-// Same GEMM mapping, packed weights and tap-grid semantics as conv_igemm_kernel (dam_conv.hip); what changes is how the
-// input reaches LDS and how much of it is re-read:
-//   * a workgroup walks `tpw` CONSECUTIVE 64*MB-pixel tiles of one image.  Input rows live in an LDS ring indexed by
-//     (absolute row & (NR-1)); a new tile only fetches the rows the previous tiles did not (halo re-reads drop from
-//     2.5x to ~1.1x of the input for 3x3 convs on 130-wide images);
-//   * rows are fetched by dedicated LOADER waves (waves 4..7: one wave sustains only ~1 LDS-DMA piece per 1k cycles)
-//     with global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip,
-//     1 KB per instruction) for tile k+1 while the 4 compute waves run the MFMAs of tile k; one workgroup barrier per
-//     tile.  Compute waves never wait on HBM: their only global loads are the L2-resident packed weights;
+// Same GEMM mapping, packed weights and tap-grid semantics as conv_igemm_kernel (dam_conv.hip).  One workgroup per CU,
+// 12 waves with fixed roles, built from what the in-kernel stamps of the first version showed (profiles/README.md):
+//   * the workgroup walks `tpw` CONSECUTIVE 64*MB-pixel tiles of one image; input rows live in an LDS ring indexed by
+//     (absolute row & (NR-1)), so a tile fetches only the rows its predecessors did not (HBM traffic 1.06x algorithmic);
+//   * compute group A (waves 0-3) and B (waves 4-7) PING-PONG: in slot s one group runs the MFMAs of tile s while the
+//     other writes out tile s-1 (epilogue + BatchNorm partial statistics).  Each SIMD hosts one wave of each group, so
+//     its matrix pipe always has exactly one MFMA stream, and the non-MFMA work of a tile hides under the next tile;
+//   * loader waves 8-11 fetch the rows tile s+2 adds with plain vector loads (up to 8 x 1 KB pieces in flight per wave)
+//     and write them to the ring; weights are LDS resident, so compute waves issue no vector-memory loads in the loop;
+//   * one raw s_barrier per slot; compute waves do not drain their output stores at it.
 //   * LDS image: [chunk][ring row][column slot][16 ch] with the same stride-2 column de-interleave as the tile kernel;
-//     border slots (zero padding) are zeroed once, the DMA only writes in-tensor pixels;
-//   * optional epilogue: per-channel BatchNorm partial statistics (n, mean, M2) of the produced tiles, one record per
-//     workgroup, merged later by bn_stats_finalize -- removes the separate statistics pass over the conv output.
+//     border slots (zero padding) are zeroed once, only in-tensor pixels are ever written;
+//   * optional epilogue: per-channel BatchNorm partial statistics (n, mean, M2), one record per workgroup, merged by
+//     bn_stats_finalize -- removes the statistics pass over the conv output.
 #include "dam_common.h"
 #include "dam_conv_geo.h"
 
@@ -26,8 +28,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifdef DAM_STAMPS
 #define DAM_STAMP(slot)                                                                                   \
     do {                                                                                                  \
-        if (lane == 0 && (wave == 0 || wave == 4) && stamp_i < 30)                                        \
-            reinterpret_cast<unsigned long long*>(stats)[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 + (wave == 4)) * 32 + \
+        if (lane == 0 && (wave == 0 || wave == 8) && stamp_i < 30)                                        \
+            reinterpret_cast<unsigned long long*>(stats)[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 + (wave == 8)) * 32 + \
                                                          (stamp_i++)] = __builtin_amdgcn_s_memtime() | ((unsigned long long)(slot) << 56); \
     } while (0)
 #else
@@ -41,10 +43,51 @@ __device__ __forceinline__ int fdiv(int e, int d, float inv_d) {   // e / d, 0 <
     return q;
 }
 
-constexpr int STRIP_LOADERS = 4;                        // loader waves per workgroup (waves 4..7)
-constexpr int STRIP_THREADS = 256 + 64 * STRIP_LOADERS;
+constexpr int STRIP_LOADERS = 4;                        // loader waves per workgroup (waves 8..11)
+constexpr int STRIP_THREADS = 512 + 64 * STRIP_LOADERS; // 2 compute groups of 4 waves + loaders
+constexpr int STRIP_PU = 8;                             // 1 KB pieces in flight per loader wave
 
-template <int MB, int NB>
+struct RowLoad {           // everything the row loader needs, by value (no closures over the kernel's arrays)
+    const float* ximg;
+    int H, W, C, s, c0, PWs, PWin, PWT, nchunks, RB, CHB, NR, ring_off, ppr, gpp;
+    float inv_ppr, inv_gpp;
+};
+
+// Requests pieces first + part + nparts*u (u < STRIP_PU) of input rows [lo, hi] into registers: unconditional loads from
+// clamped addresses, unused / out-of-tensor lanes zeroed by select (a conditional around a load costs an s_waitcnt each).
+__device__ __forceinline__ void rows_issue(const RowLoad& r, int lo, int hi, int first, int part, int nparts, int lane,
+                                           float4 (&lv)[STRIP_PU], int (&ldst)[STRIP_PU]) {
+    const int total = (hi - lo + 1) * r.ppr;
+#pragma unroll
+    for (int u = 0; u < STRIP_PU; ++u) {
+        const int q = first + part + nparts * u;
+        const bool used = q < total;
+        const int qc = used ? q : total - 1;
+        const int row = fdiv(qc, r.ppr, r.inv_ppr), rem = qc - row * r.ppr;
+        const int cc = fdiv(rem, r.gpp, r.inv_gpp), gi = rem - cc * r.gpp;
+        const int ih = lo + row;
+        const int L = gi * 64 + lane, slot = L >> 2, quad = L & 3;
+        int pw = slot;
+        if (r.s != 1) pw = slot < r.PWs ? 2 * slot : 2 * (slot - r.PWs) + 1;
+        const int iw = pw + r.c0;
+        const bool col_ok = slot < r.PWT && pw < r.PWin && iw >= 0 && iw < r.W;
+        const bool inb = used && col_ok && ih >= 0 && ih < r.H;
+        const int ihc = ih < 0 ? 0 : (ih >= r.H ? r.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= r.W ? r.W - 1 : iw);
+        const float4 x = *reinterpret_cast<const float4*>(r.ximg + (unsigned)((ihc * r.W + iwc) * r.C + cc * 16 + quad * 4));
+        lv[u] = inb ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        ldst[u] = (used && col_ok) ? cc * r.CHB + ((ih + r.ring_off) & (r.NR - 1)) * r.RB + L * 16 : -1;
+    }
+}
+__device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&lv)[STRIP_PU], int (&ldst)[STRIP_PU]) {
+#pragma unroll
+    for (int u = 0; u < STRIP_PU; ++u) {
+        if (ldst[u] >= 0) *reinterpret_cast<float4*>(smem + ldst[u]) = lv[u];
+        ldst[u] = -1;
+    }
+}
+
+// NCH: 16-channel input chunks (compile time so that every MFMA operand offset of the 3x3xNCH item grid is a scalar)
+template <int MB, int NB, int NCH>
 __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
@@ -92,51 +135,76 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         lo = fdiv(p0, g.Wo, inv_wo) * g.s + g.r0;
         hi = fdiv(p1, g.Wo, inv_wo) * g.s + g.r0 + RH - 1;
     };
-    // fetch input rows [lo, hi] into the ring.  The lane -> (column slot, channel quad) mapping of a DMA group does not
-    // depend on the row, so it is computed once per group; per row and chunk a piece then costs an M0 write, a scalar
-    // base update and the global_load_lds itself.  `part`/`nparts`: the rows are dealt round-robin to `nparts` waves.
+    // Fetch input rows [lo, hi] into the ring with plain vector loads: pieces first + part, + nparts, ... (one piece =
+    // one wave-wide 1 KB request = 16 column slots of one (row, chunk) plane), STRIP_PU pieces requested before the
+    // first is written.  Loads are unconditional from clamped addresses; unused / out-of-tensor lanes become zeros by
+    // select (a conditional around a load costs an s_waitcnt per piece).
     const int groups_per_plane = (g.PWT * 4 + 63) >> 6;
-    auto load_rows = [&](int lo, int hi, int part, int nparts) {
-        for (int gi = 0; gi < groups_per_plane; ++gi) {
-            const int L = gi * 64 + lane;                    // float4 index inside a row plane
-            const int slot = L >> 2, quad = L & 3;
-            int pw = slot;
-            if (g.s != 1) pw = slot < g.PWs ? 2 * slot : 2 * (slot - g.PWs) + 1;
-            const int iw = pw + g.c0;
-            const bool ok = slot < g.PWT && pw < g.PWin && iw >= 0 && iw < g.W;
-            const unsigned lane_off = (unsigned)((iw * g.C + quad * 4) * 4);      // bytes inside an input row
-            for (int ih = lo + part; ih <= hi; ih += nparts) {
-                const int slot_row = (ih + sg.ring_off) & (sg.NR - 1);
-                const bool row_ok = ih >= 0 && ih < g.H;
-                const char* rowp = reinterpret_cast<const char*>(ximg) + (size_t)(row_ok ? ih : 0) * g.W * g.C * 4;
-                for (int cc = 0; cc < g.nchunks; ++cc) {
-                    unsigned char* plane = smem + cc * CHB + slot_row * RB;
-                    if (row_ok) {
-                        if (ok)
-                            __builtin_amdgcn_global_load_lds(
-                                (const __attribute__((address_space(1))) void*)(rowp + cc * 64 + lane_off),
-                                (__attribute__((address_space(3))) void*)(plane + gi * 1024), 16, 0, 0);
-                    } else if (ok) {                                 // row outside the image: zeros
-                        *reinterpret_cast<float4*>(plane + L * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                }
-            }
-        }
-    };
+    const int pieces_per_row = g.nchunks * groups_per_plane;
+    const float inv_ppr = 1.0f / (float)pieces_per_row, inv_gpp = 1.0f / (float)groups_per_plane;
+    float4 lv[STRIP_PU];
+    int ldst[STRIP_PU];
+#pragma unroll
+    for (int u = 0; u < STRIP_PU; ++u) ldst[u] = -1;
+    RowLoad rl;
+    rl.ximg = ximg; rl.H = g.H; rl.W = g.W; rl.C = g.C; rl.s = g.s; rl.c0 = g.c0; rl.PWs = g.PWs; rl.PWin = g.PWin; rl.PWT = g.PWT;
+    rl.nchunks = g.nchunks; rl.RB = RB; rl.CHB = CHB; rl.NR = sg.NR; rl.ring_off = sg.ring_off;
+    rl.ppr = pieces_per_row; rl.gpp = groups_per_plane; rl.inv_ppr = inv_ppr; rl.inv_gpp = inv_gpp;
 
-    int loaded_hi;
-    {
+    const int grp = wave >> 2, cw = wave & 3;          // role: 0/1 = compute group A/B, 2 = loader; wave index inside the role
+    const int n_tiles = t_end - t_begin;
+    {   // rows of the first tile, fetched by every wave
         int lo, hi;
         tile_rows(t_begin, lo, hi);
-        load_rows(lo, hi, wave, 4 + STRIP_LOADERS);          // first tile: every wave fetches (the compute waves have nothing else to do)
-        loaded_hi = hi;
+        const int total = (hi - lo + 1) * pieces_per_row;
+        for (int base = 0; base < total; base += (STRIP_THREADS / 64) * STRIP_PU) {
+            rows_issue(rl, lo, hi, base, wave, STRIP_THREADS / 64, lane, lv, ldst);
+            rows_commit(smem, lv, ldst);
+        }
     }
-    __syncthreads();      // (compiler drains vmcnt before the barrier: the DMA has landed)
+    __syncthreads();
     DAM_STAMP(3);
-    // the loader shares its SIMD with compute waves that keep the issue port busy: without priority it is starved
-    if (wave >= 4) __builtin_amdgcn_s_setprio(3);
 
-    // BatchNorm partial statistics of this workgroup's outputs (shifted sums per lane, channels 4*kq..+3 of block nb)
+    if (grp == 2) {
+        // ================= loader waves: their own slot loop (same number of barriers as the compute waves) =============
+        // Slot s writes the rows tile s+1 adds (requested two slots earlier: HBM latency under this load is ~4 us, a full
+        // slot) and requests those of tile s+3.  Two register sets alternate; tile k uses set k & 1.
+        // a loader shares its SIMD with an MFMA stream and a write-out stream that keep the issue port busy:
+        // without priority it gets the leftover slots only (measured: ~1.2k cycles per piece of pure address arithmetic)
+        __builtin_amdgcn_s_setprio(3);
+        float4 lv1[STRIP_PU];
+        int ldst1[STRIP_PU];
+#pragma unroll
+        for (int u = 0; u < STRIP_PU; ++u) ldst1[u] = -1;
+        int loaded_hi;
+        { int lo; tile_rows(t_begin, lo, loaded_hi); }
+        auto request = [&](int k, float4 (&v)[STRIP_PU], int (&d)[STRIP_PU]) {      // rows tile k adds, if any
+            if (k < n_tiles) {
+                int lo, hi;
+                tile_rows(t_begin + k, lo, hi);
+                if (hi > loaded_hi) {
+                    rows_issue(rl, loaded_hi + 1 > lo ? loaded_hi + 1 : lo, hi, 0, cw, STRIP_LOADERS, lane, v, d);
+                    loaded_hi = hi;
+                }
+            }
+        };
+        request(1, lv1, ldst1);
+        request(2, lv, ldst);
+        for (int s = 0; s <= n_tiles; s += 2) {
+            rows_commit(smem, lv1, ldst1);          // tile s+1
+            request(s + 3, lv1, ldst1);
+            DAM_STAMP(4);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s + 1 <= n_tiles) {
+                rows_commit(smem, lv, ldst);        // tile s+2
+                request(s + 4, lv, ldst);
+                DAM_STAMP(4);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+    }
+
+    // BatchNorm partial statistics of this wave's outputs (shifted sums per lane, channels 4*kq..+3 of block nb)
     float st_k[NB][4], st_s1[NB][4], st_s2[NB][4];
     int st_n = 0;
 #pragma unroll
@@ -144,88 +212,78 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #pragma unroll
         for (int r = 0; r < 4; ++r) { st_k[nb][r] = 0.f; st_s1[nb][r] = 0.f; st_s2[nb][r] = 0.f; }
 
-    for (int t = t_begin; t < t_end; ++t) {
-        if (wave >= 4) {
-            if (t + 1 < t_end) {
-                int lo, hi;
-                tile_rows(t + 1, lo, hi);
-                if (hi > loaded_hi) load_rows(loaded_hi + 1 > lo ? loaded_hi + 1 : lo, hi, wave - 4, STRIP_LOADERS);
-            }
-            DAM_STAMP(4);
-        } else {
-            const int p0 = t * TM;
-            int colbase[MB], ohs[MB], pix[MB];
+    v4f acc[MB][NB];            // results of this group's current tile: produced in one slot, written out in the next
+    int pix[MB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                int p = p0 + wave * MW + mb * 16 + j;
-                pix[mb] = p;
-                p = p < HoWo ? p : HoWo - 1;
-                const int oh = fdiv(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
-                ohs[mb] = oh * g.s + sg.ring_off;
-                colbase[mb] = ow * 64 + kq * 16;
-            }
-            v4f acc[MB][NB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < MB; ++mb) pix[mb] = HoWo;
 
-            const int n_items = g.nA * g.nB * g.nchunks;
-            int ia = 0, ib = 0, ic = 0;
-            auto item = [&](int a, int b, int cc, int& aoff, int& coloff, size_t& w_off) {
-                aoff = g.off_h + a * g.step_h;                        // input row offset of the tap (ring index added per lane)
-                const int coff = g.off_w + b * g.step_w - g.c0;
-                const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
-                coloff = cc * CHB + slotoff * 64;
-                const int tap = g.wt_base + a * g.wt_sa + b * g.wt_sb;
-                w_off = sg.w_lds ? ((size_t)(tap * g.nchunks + cc) * NB) * 64 + lane
-                                 : ((size_t)(tap * g.nchunks + cc) * g.NBtot + nb0) * 64 + lane;
-            };
-            auto fetch = [&](int aoff, int coloff, size_t w_off, float4 (&wa)[NB], float4 (&xv)[MB]) {
-                if (sg.w_lds) {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) wa[nb] = *reinterpret_cast<const float4*>(smem + w_base + (int)(w_off + nb * 64) * 16);
-                } else {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) wa[nb] = Wp[w_off + nb * 64];
-                }
+    for (int s = 0; grp < 2 && s <= n_tiles; ++s) {
+        if (false) {
+        } else if (grp == (s & 1)) {
+            // ---------------- MFMA slot of this group: tile s ----------------
+            if (s < n_tiles) {
+                const int p0 = (t_begin + s) * TM;
+                int colbase[MB], ohs[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    const int row = (ohs[mb] + aoff) & (sg.NR - 1);
-                    xv[mb] = *reinterpret_cast<const float4*>(smem + row * RB + colbase[mb] + coloff);
-                }
-            };
-            float4 wa_n[NB], xv_n[MB];
-            {
-                int aoff, coloff; size_t wo;
-                item(0, 0, 0, aoff, coloff, wo);
-                fetch(aoff, coloff, wo, wa_n, xv_n);
-            }
-            for (int it = 0; it < n_items; ++it) {
-                float4 wa[NB], xv[MB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wa[nb] = wa_n[nb];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) xv[mb] = xv_n[mb];
-                if (++ic == g.nchunks) { ic = 0; if (++ib == g.nB) { ib = 0; ++ia; } }
-                if (it + 1 < n_items) {
-                    int aoff, coloff; size_t wo;
-                    item(ia, ib, ic, aoff, coloff, wo);
-                    fetch(aoff, coloff, wo, wa_n, xv_n);
+                    int p = p0 + cw * MW + mb * 16 + j;
+                    pix[mb] = p;
+                    p = p < HoWo ? p : HoWo - 1;
+                    const int oh = fdiv(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
+                    ohs[mb] = oh * g.s + sg.ring_off;
+                    colbase[mb] = ow * 64 + kq * 16;
                 }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].x, xv[mb].x, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].y, xv[mb].y, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].z, xv[mb].z, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].w, xv[mb].w, acc[mb][nb], 0, 0, 0);
-                    }
-            }
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+                // The whole (tap row a, tap column b, chunk) grid is unrolled (nA, nB <= 3, NCH compile time): an LDS operand
+                // address is "per-(pixel, a) base + wave-uniform offset", a weight address is a wave-uniform offset, so an item
+                // costs MB v_add + (MB + NB) ds_read_b128 next to its 16*MB*NB/4 MFMAs and the scheduler can slide the reads
+                // of the next item under the MFMAs of the current one.  sched_barrier between tap rows bounds the hoisting.
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    if (a < g.nA) {
+                        int base_a[MB];
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+                            base_a[mb] = ((ohs[mb] + g.off_h + a * g.step_h) & (sg.NR - 1)) * RB + colbase[mb];
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) {
+                            if (b < g.nB) {
+                                const int coff = g.off_w + b * g.step_w - g.c0;
+                                const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
+                                const int tap = g.wt_base + a * g.wt_sa + b * g.wt_sb;
+#pragma unroll
+                                for (int cc = 0; cc < NCH; ++cc) {
+                                    const int co = cc * CHB + slotoff * 64;
+                                    const int wo = w_base + (((tap * NCH + cc) * NB) * 64 + lane) * 16;
+                                    float4 wa[NB], xv[MB];
+#pragma unroll
+                                    for (int nb = 0; nb < NB; ++nb) wa[nb] = *reinterpret_cast<const float4*>(smem + wo + nb * 1024);
+#pragma unroll
+                                    for (int mb = 0; mb < MB; ++mb) xv[mb] = *reinterpret_cast<const float4*>(smem + base_a[mb] + co);
+#pragma unroll
+                                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                                        for (int nb = 0; nb < NB; ++nb) {
+                                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].x, xv[mb].x, acc[mb][nb], 0, 0, 0);
+                                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].y, xv[mb].y, acc[mb][nb], 0, 0, 0);
+                                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].z, xv[mb].z, acc[mb][nb], 0, 0, 0);
+                                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].w, xv[mb].w, acc[mb][nb], 0, 0, 0);
+                                        }
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
             DAM_STAMP(5);
-            // epilogue: lane holds channels 4*kq..+3 of pixel j of every (mb, nb) block
+        } else if (s >= 1) {
+            // ---------------- write-out slot of this group: tile s-1 (computed in the previous slot) ----------------
+            __builtin_amdgcn_s_setprio(2);          // ahead of the other group's MFMA stream on the issue port
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int p = pix[mb];
@@ -271,17 +329,12 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                 }
                 if (stats) ++st_n;
             }
+            __builtin_amdgcn_s_setprio(0);
+            DAM_STAMP(6);
         }
-        if (t + 1 < t_end) {
-            int lo, hi;
-            tile_rows(t + 1, lo, hi);
-            if (hi > loaded_hi) loaded_hi = hi;
-        }
-        // tile boundary: the loader's DMA must have landed, the compute waves' LDS reads are already consumed by their
-        // MFMAs.  A raw s_barrier (not __syncthreads) so that the compute waves do NOT drain their output stores here.
-        DAM_STAMP(6);
-        if (wave >= 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // slot boundary: the loaders' rows are in LDS (their ds_writes waited on the loads), the MFMA group's LDS reads
+        // are consumed.  Raw s_barrier: the write-out group does not drain its output stores here.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         DAM_STAMP(7);
     }
 
@@ -291,7 +344,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #endif
     if (stats) {
         // (n, mean, M2) per lane -> Chan merge over the 16 pixel lanes, then over the 4 compute waves through LDS
-        float* sm = reinterpret_cast<float*>(smem);        // ring no longer needed: [4 waves][NB*16 ch][3]
+        float* sm = reinterpret_cast<float*>(smem);        // ring no longer needed: [8 compute waves][NB*16 ch][3]
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -311,7 +364,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                     }
                     n = nn;
                 }
-                if (j == 0 && wave < 4) {
+                if (j == 0 && wave < 8) {
                     float* o = sm + ((wave * NB * 16) + nb * 16 + kq * 4 + r) * 3;
                     o[0] = n; o[1] = mean; o[2] = m2;
                 }
@@ -319,7 +372,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         __syncthreads();
         if (tid < NB * 16) {
             float n = 0.f, mean = 0.f, m2 = 0.f;
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < 8; ++w) {
                 const float* o = sm + ((w * NB * 16) + tid) * 3;
                 const float nb_ = o[0];
                 if (nb_ == 0.f) continue;
@@ -341,20 +394,20 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 }  // namespace
 
 // Returns DAM_OK if launched, DAM_ERR_UNSUPPORTED if the layer does not fit this variant (caller falls back).
-template <int MB, int NB>
+template <int MB, int NB, int NCH>
 static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, const float* Wp, const float* bias, float* Y,
                         const float* res, const float* res_mask, float* stats, hipStream_t st) {
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return DAM_ERR_LAUNCH;
             raised = true;
         }
     }
     dim3 grid((unsigned)sg.strips, (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
-    hipLaunchKernelGGL((conv_strip_kernel<MB, NB>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
+    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
                        Y, res, res_mask, stats);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -362,15 +415,19 @@ static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, co
 
 int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
                    const float* res, const float* res_mask, float* stats, int* stats_parts, hipStream_t st) {
-    if (g.in_nchw || g.B > 65535) return DAM_ERR_UNSUPPORTED;
+    if (g.in_nchw || g.B > 65535 || g.nA > 3 || g.nB > 3 || g.nchunks > 2) return DAM_ERR_UNSUPPORTED;
     const int nblk = g.N / 16;
     const int64_t npix = (int64_t)g.Ho * g.Wo;
     if (npix >= (1 << 22)) return DAM_ERR_UNSUPPORTED;
-    const int NB = nblk % 4 == 0 ? 4 : (nblk % 2 == 0 ? 2 : 1);
+    const int NB = nblk % 2 == 0 ? 2 : 1;
     if (stats && cdiv(nblk, NB) != 1) return DAM_ERR_UNSUPPORTED;        // statistics need all channels in one workgroup
     StripGeo sg;
     sg.RH = h_hi - h_lo + 1;
-    const size_t LDS_MAX = 72 * 1024;
+    sg.w_taps = g.wt_base + (g.nA - 1) * g.wt_sa + (g.nB - 1) * g.wt_sb + 1;
+    const size_t w_bytes = (size_t)sg.w_taps * g.nchunks * NB * 1024;      // resident packed weights of the N tile
+    if (w_bytes > 48 * 1024) return DAM_ERR_UNSUPPORTED;                    // thick layers: tile kernel (weights from L2)
+    sg.w_lds = 1;
+    const size_t LDS_MAX = 150 * 1024;                                      // one workgroup (12 waves) per CU
     int MB = 4;
     size_t lds = 0;
     for (;; MB >>= 1) {
@@ -378,35 +435,34 @@ int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* 
         int rows_out = (int)((tm + g.Wo - 2) / g.Wo + 1);
         if (rows_out > g.Ho) rows_out = g.Ho;
         const int rows_tile = (rows_out - 1) * g.s + sg.RH;       // rows one tile reads
-        const int rows_new = rows_out * g.s;                      // rows the next tile can add
+        const int rows_new = rows_out * g.s;                      // rows each following tile can add
         int nr = 1;
-        while (nr < rows_tile + rows_new) nr <<= 1;
-        lds = (size_t)nr * g.PWT * 64 * g.nchunks;
+        while (nr < rows_tile + rows_new) nr <<= 1;               // tile s in use, the rows tile s+1 adds being written
+        if ((int64_t)rows_new * g.nchunks * ((g.PWT * 4 + 63) / 64) > STRIP_LOADERS * STRIP_PU) { if (MB == 2) return DAM_ERR_UNSUPPORTED; continue; }
+        lds = (size_t)nr * g.PWT * 64 * g.nchunks + w_bytes;
         if (lds <= LDS_MAX) { sg.NR = nr; break; }
-        if (MB == 2) return DAM_ERR_UNSUPPORTED;     // 64-pixel strips measured slower than the tile kernel (MB = 1)
+        if (MB == 2) return DAM_ERR_UNSUPPORTED;     // 64-pixel strips are not worth it: tile kernel
     }
     const int tm = 64 * MB;
     sg.tiles_m = (int)cdiv(npix, tm);
     const int64_t total = (int64_t)sg.tiles_m * g.B * cdiv(nblk, NB);
-    // one resident round: <= 512 workgroups (2 per CU) when a strip of <= 32 tiles allows it, else many small ones
-    int tpw = (int)cdiv(total, 512);
-    if (tpw > 32) tpw = 32;
+    // one resident round: <= 256 workgroups (one per CU) when strips of <= 64 tiles allow it
+    int tpw = (int)cdiv(total, 256);
+    if (tpw > 64) tpw = 64;
     if (tpw > sg.tiles_m) tpw = sg.tiles_m;
+    if (tpw < 2 && sg.tiles_m >= 2) tpw = 2;                      // the two compute groups alternate tiles
     sg.tpw = tpw;
     sg.strips = (int)cdiv(sg.tiles_m, tpw);
     sg.ring_off = sg.NR * 64;           // keeps (row + ring_off) non-negative for row >= -64*NR
-    sg.w_taps = g.wt_base + (g.nA - 1) * g.wt_sa + (g.nB - 1) * g.wt_sb + 1;
-    const size_t w_bytes = (size_t)sg.w_taps * g.nchunks * NB * 1024;
-    sg.w_lds = (w_bytes <= 40 * 1024 && lds + w_bytes <= 80 * 1024) ? 1 : 0;
-    if (sg.w_lds) lds += w_bytes;
     if (stats_parts) *stats_parts = sg.strips * g.B;
     if (stats && (int64_t)sg.strips * g.B > 1024) return DAM_ERR_UNSUPPORTED;
-    if (lds < (size_t)4 * NB * 16 * 3 * sizeof(float)) lds = (size_t)4 * NB * 16 * 3 * sizeof(float);
-#define DAM_STRIP_CASE(M_, N_) \
-    if (MB == M_ && NB == N_) return launch_strip<M_, N_>(g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, st)
-    DAM_STRIP_CASE(4, 4); DAM_STRIP_CASE(4, 2); DAM_STRIP_CASE(4, 1);
-    DAM_STRIP_CASE(2, 4); DAM_STRIP_CASE(2, 2); DAM_STRIP_CASE(2, 1);
-    DAM_STRIP_CASE(1, 4); DAM_STRIP_CASE(1, 2); DAM_STRIP_CASE(1, 1);
+    if (lds < (size_t)8 * NB * 16 * 3 * sizeof(float)) lds = (size_t)8 * NB * 16 * 3 * sizeof(float);
+#define DAM_STRIP_CASE(M_, N_)                                                                                           \
+    if (MB == M_ && NB == N_)                                                                                               \
+        return g.nchunks == 1 ? launch_strip<M_, N_, 1>(g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, st)               \
+                              : launch_strip<M_, N_, 2>(g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, st)
+    DAM_STRIP_CASE(4, 2); DAM_STRIP_CASE(4, 1);
+    DAM_STRIP_CASE(2, 2); DAM_STRIP_CASE(2, 1);
 #undef DAM_STRIP_CASE
     return DAM_ERR_UNSUPPORTED;
 }

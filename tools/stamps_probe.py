@@ -18,7 +18,7 @@ buf.zero_()
 y, parts = ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1, bn_partial=buf)
 torch.cuda.synchronize()
 st = buf.view(torch.int64).cpu().numpy().astype(np.uint64).reshape(-1, 2, 32)
-nwg = 58 * 8
+nwg = int((st[:, 0, 0] != 0).sum())
 names = {1: 'start', 2: 'zeroed', 3: 'first-load', 4: 'issued', 5: 'mfma', 6: 'bar+commit', 7: 'epi+bar', 8: 'end'}
 t0all = None
 for wg in (0, 200, 463):
