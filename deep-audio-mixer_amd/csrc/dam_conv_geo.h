@@ -32,6 +32,7 @@ struct StripGeo {
     int ring_off;            // multiple of NR added to row indices before masking
     int w_lds;               // 1: the packed weights of this N tile are resident in LDS behind the ring
     int w_taps;              // taps held in LDS (max used tap index + 1)
+    unsigned wo_magic;       // floor(2^32 / Wo) + 1: p / Wo == umulhi(p, wo_magic) for p < 2^22 (scalar-ALU division)
 };
 
 // dam_conv_strip.hip

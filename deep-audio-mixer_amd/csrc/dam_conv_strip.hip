@@ -23,6 +23,7 @@ namespace dam {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 // Diagnostic build only (-DDAM_STAMPS): the `stats` buffer receives s_memtime stamps of phase boundaries instead.
 #ifdef DAM_STAMPS
@@ -87,13 +88,14 @@ __device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&
 }
 
 // NCH: 16-channel input chunks (compile time so that every MFMA operand offset of the 3x3xNCH item grid is a scalar)
-template <int MB, int NB, int NCH>
+template <int MB, int NB, int NCH, bool T33>
 __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
                                                          const float* __restrict__ res_mask, float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: role tests and loader arithmetic on the scalar ALU
     const int j = lane & 15, kq = lane >> 4;
     constexpr int MW = 16 * MB, TM = 4 * MW;
     const int img = blockIdx.z, nb0 = blockIdx.y * NB;
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         const int p0 = t * TM;
         int p1 = p0 + TM - 1;
         if (p1 > HoWo - 1) p1 = HoWo - 1;
-        lo = fdiv(p0, g.Wo, inv_wo) * g.s + g.r0;
-        hi = fdiv(p1, g.Wo, inv_wo) * g.s + g.r0 + RH - 1;
+        lo = (int)__umulhi((unsigned)p0, sg.wo_magic) * g.s + g.r0;
+        hi = (int)__umulhi((unsigned)p1, sg.wo_magic) * g.s + g.r0 + RH - 1;
     };
     // Fetch input rows [lo, hi] into the ring with plain vector loads: pieces first + part, + nparts, ... (one piece =
     // one wave-wide 1 KB request = 16 column slots of one (row, chunk) plane), STRIP_PU pieces requested before the
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 
     const int grp = wave >> 2, cw = wave & 3;          // role: 0/1 = compute group A/B, 2 = loader; wave index inside the role
     const int n_tiles = t_end - t_begin;
+    const int n_slots = (n_tiles + 2) & ~1;            // tile s is computed in slot s and written out in slot s+1; padded to even
     {   // rows of the first tile, fetched by every wave
         int lo, hi;
         tile_rows(t_begin, lo, hi);
@@ -169,39 +172,97 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         // ================= loader waves: their own slot loop (same number of barriers as the compute waves) =============
         // Slot s writes the rows tile s+1 adds (requested two slots earlier: HBM latency under this load is ~4 us, a full
         // slot) and requests those of tile s+3.  Two register sets alternate; tile k uses set k & 1.
-        // a loader shares its SIMD with an MFMA stream and a write-out stream that keep the issue port busy:
-        // without priority it gets the leftover slots only (measured: ~1.2k cycles per piece of pure address arithmetic)
-        __builtin_amdgcn_s_setprio(3);
-        float4 lv1[STRIP_PU];
-        int ldst1[STRIP_PU];
+        //
+        // A wave that streams MFMAs owns the SIMD's vector issue port (tools/mfma_valu_mix.hip: a co-resident wave's VALU
+        // instructions make no progress at all until the MFMA stream pauses, whatever s_setprio says), so every VALU
+        // instruction of a loader is paid for in MFMA time.  The loader therefore works in whole (row, chunk) planes:
+        // everything that depends on the plane is wave-uniform and lives on the scalar ALU, everything that depends on the
+        // lane (column pattern of piece gi: byte offset inside a row, which lanes are real columns) is computed once, and
+        // a piece costs no VALU instruction at all: buffer_load with scalar base + per-lane offset, ds_write with the
+        // piece's column mask in EXEC and an immediate offset.
+        constexpr int KP = NCH == 1 ? 1 : 3;            // planes per loader wave per tile
+        constexpr int GPP = NCH == 1 ? 9 : 5;           // 1 KB pieces per plane (host guarantees groups_per_plane <= GPP)
+        int loffb[GPP];
+        unsigned long long cmask[GPP];
 #pragma unroll
-        for (int u = 0; u < STRIP_PU; ++u) ldst1[u] = -1;
+        for (int gi = 0; gi < GPP; ++gi) {
+            const int L = gi * 64 + lane, slot = L >> 2, quad = L & 3;
+            int pw = slot;
+            if (g.s != 1) pw = slot < g.PWs ? 2 * slot : 2 * (slot - g.PWs) + 1;
+            const int iw = pw + g.c0;
+            const bool ok = gi < groups_per_plane && slot < g.PWT && pw < g.PWin && iw >= 0 && iw < g.W;
+            const int iwc = iw < 0 ? 0 : (iw >= g.W ? g.W - 1 : iw);
+            loffb[gi] = (iwc * g.C + quad * 4) * 4;
+            cmask[gi] = __ballot(ok);
+        }
+        // buffer addressing: scalar resource (this image) + scalar plane offset + per-lane column offset, no VALU
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, g.H * g.W * g.C * 4, 0x00020000);
+        const int lane16 = lane * 16;
+        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+        v4f lvA[KP][GPP], lvB[KP][GPP];
+        int dstA[KP], dstB[KP];                          // scalar: ring byte offset of the plane | 1 << 30 if the row is
+#pragma unroll                                           // outside the tensor (zeros are written), -1 = nothing to write
+        for (int k = 0; k < KP; ++k) { dstA[k] = -1; dstB[k] = -1; }
+        const int chs = NCH == 1 ? 0 : 1;
         int loaded_hi;
         { int lo; tile_rows(t_begin, lo, loaded_hi); }
-        auto request = [&](int k, float4 (&v)[STRIP_PU], int (&d)[STRIP_PU]) {      // rows tile k adds, if any
-            if (k < n_tiles) {
-                int lo, hi;
-                tile_rows(t_begin + k, lo, hi);
-                if (hi > loaded_hi) {
-                    rows_issue(rl, loaded_hi + 1 > lo ? loaded_hi + 1 : lo, hi, 0, cw, STRIP_LOADERS, lane, v, d);
-                    loaded_hi = hi;
-                }
-            }
-        };
-        request(1, lv1, ldst1);
-        request(2, lv, ldst);
-        for (int s = 0; s <= n_tiles; s += 2) {
-            rows_commit(smem, lv1, ldst1);          // tile s+1
-            request(s + 3, lv1, ldst1);
+#define DAM_STRIP_REQUEST(K_, LV_, DST_)                                                                                   \
+    do {                                                                                                                   \
+        int first_ = 0, planes_ = 0;                                                                                       \
+        if ((K_) < n_tiles) {                                                                                              \
+            int lo_, hi_;                                                                                                  \
+            tile_rows(t_begin + (K_), lo_, hi_);                                                                           \
+            first_ = loaded_hi + 1 > lo_ ? loaded_hi + 1 : lo_;                                                            \
+            if (hi_ >= first_) { planes_ = (hi_ - first_ + 1) << chs; loaded_hi = hi_; }                                   \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
+            const int pl_ = cw + STRIP_LOADERS * k;                                                                        \
+            const bool used_ = pl_ < planes_;                                                                              \
+            const int cc_ = pl_ & (NCH - 1), ih_ = first_ + (pl_ >> chs);                                                  \
+            const bool rowok_ = used_ && ih_ >= 0 && ih_ < g.H;                                                            \
+            const int soff_ = ((rowok_ ? ih_ : 0) * g.W * g.C + (used_ ? cc_ : 0) * 16) * 4;                               \
+            _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                             \
+                LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[gi], soff_, 0));   \
+            DST_[k] = used_ ? ((cc_ * CHB + ((ih_ + sg.ring_off) & (sg.NR - 1)) * RB) | (rowok_ ? 0 : 1 << 30)) : -1;     \
+        }                                                                                                                  \
+    } while (0)
+#define DAM_STRIP_WRITE(ADDR_, DATA_, GI_)                                                                                 \
+    asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
+                 : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024) : "memory")
+#define DAM_STRIP_COMMIT(LV_, DST_)                                                                                        \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
+            if (DST_[k] >= 0) {                                                                                            \
+                const int va_ = lane16 + (DST_[k] & 0x3fffffff);                                                           \
+                if (!(DST_[k] >> 30)) {                                                                                    \
+                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_STRIP_WRITE(va_, LV_[k][gi], gi);               \
+                } else {                                                                                                   \
+                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_STRIP_WRITE(va_, zero4, gi);                    \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
+#ifdef DAM_DIAG_NO_LOAD        // timing experiments only (results are wrong)
+#undef DAM_STRIP_REQUEST
+#define DAM_STRIP_REQUEST(K_, LV_, DST_) do { } while (0)
+#endif
+        DAM_STRIP_REQUEST(1, lvB, dstB);
+        DAM_STRIP_REQUEST(2, lvA, dstA);
+        // slots come in pairs (n_slots is even) so that no load sits inside a conditional: the compiler then knows that the
+        // set being written is the older of the two in flight and waits with vmcnt(pieces of the other set), not vmcnt(0)
+        for (int s = 0; s < n_slots; s += 2) {
+            DAM_STRIP_COMMIT(lvB, dstB);            // tile s+1
+            DAM_STRIP_REQUEST(s + 3, lvB, dstB);
             DAM_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (s + 1 <= n_tiles) {
-                rows_commit(smem, lv, ldst);        // tile s+2
-                request(s + 4, lv, ldst);
-                DAM_STAMP(4);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
+            DAM_STRIP_COMMIT(lvA, dstA);            // tile s+2
+            DAM_STRIP_REQUEST(s + 4, lvA, dstA);
+            DAM_STAMP(4);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+#undef DAM_STRIP_REQUEST
+#undef DAM_STRIP_WRITE
+#undef DAM_STRIP_COMMIT
     }
 
     // BatchNorm partial statistics of this wave's outputs (shifted sums per lane, channels 4*kq..+3 of block nb)
@@ -217,11 +278,15 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) pix[mb] = HoWo;
 
-    for (int s = 0; grp < 2 && s <= n_tiles; ++s) {
+    for (int s = 0; grp < 2 && s < n_slots; ++s) {
         if (false) {
         } else if (grp == (s & 1)) {
             // ---------------- MFMA slot of this group: tile s ----------------
+#ifdef DAM_DIAG_NO_MFMA
+            if (false) {
+#else
             if (s < n_tiles) {
+#endif
                 const int p0 = (t_begin + s) * TM;
                 int colbase[MB], ohs[MB];
 #pragma unroll
@@ -238,6 +303,61 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+                if constexpr (T33) {
+                    // Full 3x3 tap grid, everything compile time: 9*NCH items, each MB + NB ds_read_b128 feeding 4*MB*NB MFMAs.
+                    // Explicit two-deep software pipeline: the operands of item i+1 are requested before the MFMAs of item i
+                    // are issued (sched_barrier pins that order), so a wave never waits on the LDS after the first item.
+                    int base_a[3][MB];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+                            base_a[a][mb] = ((ohs[mb] + g.off_h + a * g.step_h) & (sg.NR - 1)) * RB + colbase[mb];
+                    constexpr int NI = 9 * NCH;
+                    float4 wa[2][NB], xv[2][MB];
+#define DAM_STRIP_LOAD(I_, BUF_)                                                                                          \
+    do {                                                                                                                  \
+        const int a_ = (I_) / (3 * NCH), b_ = ((I_) / NCH) % 3, cc_ = (I_) % NCH;                                         \
+        const int coff_ = g.off_w + b_ * g.step_w - g.c0;                                                                 \
+        const int slotoff_ = g.s == 1 ? coff_ : (coff_ & 1) * g.PWs + (coff_ >> 1);                                       \
+        const int tap_ = g.wt_base + a_ * g.wt_sa + b_ * g.wt_sb;                                                         \
+        const int co_ = cc_ * CHB + slotoff_ * 64;                                                                        \
+        const int wo_ = w_base + (((tap_ * NCH + cc_) * NB) * 64 + lane) * 16;                                            \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                 \
+            wa[BUF_][nb] = *reinterpret_cast<const float4*>(smem + wo_ + nb * 1024);                                      \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                 \
+            xv[BUF_][mb] = *reinterpret_cast<const float4*>(smem + base_a[a_][mb] + co_);                                 \
+    } while (0)
+                    DAM_STRIP_LOAD(0, 0);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        if (i + 1 < NI) DAM_STRIP_LOAD(i + 1, (i + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int cur = i & 1;
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cur][nb].x, xv[cur][mb].x, acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cur][nb].y, xv[cur][mb].y, acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cur][nb].z, xv[cur][mb].z, acc[mb][nb], 0, 0, 0);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cur][nb].w, xv[cur][mb].w, acc[mb][nb], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#undef DAM_STRIP_LOAD
+                } else {
                 // The whole (tap row a, tap column b, chunk) grid is unrolled (nA, nB <= 3, NCH compile time): an LDS operand
                 // address is "per-(pixel, a) base + wave-uniform offset", a weight address is a wave-uniform offset, so an item
                 // costs MB v_add + (MB + NB) ds_read_b128 next to its 16*MB*NB/4 MFMAs and the scheduler can slide the reads
@@ -280,13 +400,17 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                     }
                 }
             }
+            }
             DAM_STAMP(5);
-        } else if (s >= 1) {
+        } else if (s >= 1 && s <= n_tiles) {
             // ---------------- write-out slot of this group: tile s-1 (computed in the previous slot) ----------------
             __builtin_amdgcn_s_setprio(2);          // ahead of the other group's MFMA stream on the issue port
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int p = pix[mb];
+#ifdef DAM_DIAG_NO_WRITEOUT
+                if (p >= 0) continue;
+#endif
                 if (p >= HoWo) continue;
                 const int oh = fdiv(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
                 const size_t opix = ((size_t)img * g.OHt + (oh * g.os + g.oo_h)) * g.OWt + (ow * g.os + g.oo_w);
@@ -394,20 +518,20 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 }  // namespace
 
 // Returns DAM_OK if launched, DAM_ERR_UNSUPPORTED if the layer does not fit this variant (caller falls back).
-template <int MB, int NB, int NCH>
+template <int MB, int NB, int NCH, bool T33>
 static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, const float* Wp, const float* bias, float* Y,
                         const float* res, const float* res_mask, float* stats, hipStream_t st) {
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH, T33>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return DAM_ERR_LAUNCH;
             raised = true;
         }
     }
     dim3 grid((unsigned)sg.strips, (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
-    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
+    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
                        Y, res, res_mask, stats);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -438,7 +562,10 @@ int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* 
         const int rows_new = rows_out * g.s;                      // rows each following tile can add
         int nr = 1;
         while (nr < rows_tile + rows_new) nr <<= 1;               // tile s in use, the rows tile s+1 adds being written
-        if ((int64_t)rows_new * g.nchunks * ((g.PWT * 4 + 63) / 64) > STRIP_LOADERS * STRIP_PU) { if (MB == 2) return DAM_ERR_UNSUPPORTED; continue; }
+        // loader waves take whole (row, chunk) planes: KP planes of <= GPP pieces each per wave per tile (see the kernel)
+        const int gpp = (g.PWT * 4 + 63) / 64, kp = g.nchunks == 1 ? 1 : 3, gpp_max = g.nchunks == 1 ? 9 : 5;
+        if (gpp > gpp_max) return DAM_ERR_UNSUPPORTED;
+        if (rows_new * g.nchunks > STRIP_LOADERS * kp) { if (MB == 2) return DAM_ERR_UNSUPPORTED; continue; }
         lds = (size_t)nr * g.PWT * 64 * g.nchunks + w_bytes;
         if (lds <= LDS_MAX) { sg.NR = nr; break; }
         if (MB == 2) return DAM_ERR_UNSUPPORTED;     // 64-pixel strips are not worth it: tile kernel
@@ -453,17 +580,23 @@ int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* 
     if (tpw < 2 && sg.tiles_m >= 2) tpw = 2;                      // the two compute groups alternate tiles
     sg.tpw = tpw;
     sg.strips = (int)cdiv(sg.tiles_m, tpw);
+    if (g.Wo > 1024) return DAM_ERR_UNSUPPORTED;
+    sg.wo_magic = (unsigned)((1ull << 32) / (unsigned)g.Wo) + 1u;
     sg.ring_off = sg.NR * 64;           // keeps (row + ring_off) non-negative for row >= -64*NR
     if (stats_parts) *stats_parts = sg.strips * g.B;
     if (stats && (int64_t)sg.strips * g.B > 1024) return DAM_ERR_UNSUPPORTED;
     if (lds < (size_t)8 * NB * 16 * 3 * sizeof(float)) lds = (size_t)8 * NB * 16 * 3 * sizeof(float);
+    const bool t33 = g.nA == 3 && g.nB == 3;    // full 3x3 tap grid: compile-time item count, reads pipelined across taps
+#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, st
 #define DAM_STRIP_CASE(M_, N_)                                                                                           \
-    if (MB == M_ && NB == N_)                                                                                               \
-        return g.nchunks == 1 ? launch_strip<M_, N_, 1>(g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, st)               \
-                              : launch_strip<M_, N_, 2>(g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, st)
+    if (MB == M_ && NB == N_) {                                                                                             \
+        if (t33) return g.nchunks == 1 ? launch_strip<M_, N_, 1, true>(DAM_STRIP_ARGS) : launch_strip<M_, N_, 2, true>(DAM_STRIP_ARGS); \
+        return g.nchunks == 1 ? launch_strip<M_, N_, 1, false>(DAM_STRIP_ARGS) : launch_strip<M_, N_, 2, false>(DAM_STRIP_ARGS); \
+    }
     DAM_STRIP_CASE(4, 2); DAM_STRIP_CASE(4, 1);
     DAM_STRIP_CASE(2, 2); DAM_STRIP_CASE(2, 1);
 #undef DAM_STRIP_CASE
+#undef DAM_STRIP_ARGS
     return DAM_ERR_UNSUPPORTED;
 }
 
