@@ -24,6 +24,7 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Diagnostic build only (-DDAM_STAMPS): the `stats` buffer receives s_memtime stamps of phase boundaries instead.
 #ifdef DAM_STAMPS
@@ -106,28 +107,12 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     const int RB = g.PWT * 64;                 // bytes of one ring row of one chunk plane
     const int CHB = sg.NR * RB;                // bytes of one chunk plane
     const int RH = sg.RH;                      // input rows touched by one output row
-    const float inv_wo = 1.0f / (float)g.Wo;
     const float* ximg = X + (size_t)img * g.H * g.W * g.C;
 #ifdef DAM_STAMPS
     int stamp_i = 0;
 #endif
     DAM_STAMP(1);
 
-    // zero the whole ring once: border slots stay zero for the lifetime of the workgroup
-    for (int e = tid * 16; e < CHB * g.nchunks; e += STRIP_THREADS * 16)
-        *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-    // thin layers: the packed weights of this N tile are small; keep them in LDS so that the MFMA loop never waits on L2
-    const int w_base = CHB * g.nchunks;       // always address LDS as smem + integer offset (a derived pointer variable
-                                              // degrades to flat_load, which is slower and also counts on vmcnt)
-    if (sg.w_lds) {
-        const int n4 = sg.w_taps * g.nchunks * NB * 64;          // float4 count: [tap][chunk][nb][lane]
-        for (int e = tid; e < n4; e += STRIP_THREADS) {
-            const int ln = e & 63, nb = (e >> 6) % NB, tc = (e >> 6) / NB;
-            *reinterpret_cast<float4*>(smem + w_base + e * 16) = Wp[((size_t)tc * g.NBtot + nb0 + nb) * 64 + ln];
-        }
-    }
-    __syncthreads();
-    DAM_STAMP(2);
 
     // rows [lo, hi] of the input needed by tile t
     auto tile_rows = [&](int t, int& lo, int& hi) {
@@ -156,14 +141,36 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     const int grp = wave >> 2, cw = wave & 3;          // role: 0/1 = compute group A/B, 2 = loader; wave index inside the role
     const int n_tiles = t_end - t_begin;
     const int n_slots = (n_tiles + 2) & ~1;            // tile s is computed in slot s and written out in slot s+1; padded to even
-    {   // rows of the first tile, fetched by every wave
-        int lo, hi;
-        tile_rows(t_begin, lo, hi);
-        const int total = (hi - lo + 1) * pieces_per_row;
-        for (int base = 0; base < total; base += (STRIP_THREADS / 64) * STRIP_PU) {
-            rows_issue(rl, lo, hi, base, wave, STRIP_THREADS / 64, lane, lv, ldst);
-            rows_commit(smem, lv, ldst);
+    // Prologue: the rows of the first tile are requested first (every wave, into registers), the ring is zeroed and the
+    // weights copied while they are in flight, then the rows are written.
+    int lo0, hi0;
+    tile_rows(t_begin, lo0, hi0);
+    const int total0 = (hi0 - lo0 + 1) * pieces_per_row;
+    rows_issue(rl, lo0, hi0, 0, wave, STRIP_THREADS / 64, lane, lv, ldst);
+    // zero the whole ring once: border slots stay zero for the lifetime of the workgroup
+    for (int e = tid * 16; e < CHB * g.nchunks; e += STRIP_THREADS * 16)
+        *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // thin layers: the packed weights of this N tile are small; keep them in LDS so that the MFMA loop never waits on L2
+    const int w_base = CHB * g.nchunks;       // always address LDS as smem + integer offset (a derived pointer variable
+                                              // degrades to flat_load, which is slower and also counts on vmcnt)
+    {   // canonical order [a*3+b][chunk][nb][lane] whatever the layer's tap numbering: operand offsets become immediates
+        const int n4 = 9 * g.nchunks * NB * 64;
+        for (int e = tid; e < n4; e += STRIP_THREADS) {
+            const int ln = e & 63, nb = (e >> 6) % NB, tc = (e >> 6) / NB;
+            const int ct = tc / g.nchunks, cc = tc - ct * g.nchunks, a = ct / 3, b = ct - a * 3;
+            if (a < g.nA && b < g.nB) {
+                const int tap = g.wt_base + a * g.wt_sa + b * g.wt_sb;
+                *reinterpret_cast<float4*>(smem + w_base + e * 16) =
+                    Wp[((size_t)(tap * g.nchunks + cc) * g.NBtot + nb0 + nb) * 64 + ln];
+            }
         }
+    }
+    __syncthreads();
+    DAM_STAMP(2);
+    rows_commit(smem, lv, ldst);
+    for (int base = (STRIP_THREADS / 64) * STRIP_PU; base < total0; base += (STRIP_THREADS / 64) * STRIP_PU) {
+        rows_issue(rl, lo0, hi0, base, wave, STRIP_THREADS / 64, lane, lv, ldst);
+        rows_commit(smem, lv, ldst);
     }
     __syncthreads();
     DAM_STAMP(3);
@@ -265,18 +272,63 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #undef DAM_STRIP_COMMIT
     }
 
-    // BatchNorm partial statistics of this wave's outputs (shifted sums per lane, channels 4*kq..+3 of block nb)
-    float st_k[NB][4], st_s1[NB][4], st_s2[NB][4];
+    // BatchNorm partial statistics of this wave's outputs: shifted sums per lane (channels 4*kq..+3 of block nb), kept as
+    // float pairs so that the three updates per value are v_pk_add / v_pk_add / v_pk_fma (two values per instruction)
+    v2f st_nk[NB][2], st_s1[NB][2], st_s2[NB][2];       // -shift, sum(v - shift), sum((v - shift)^2)
     int st_n = 0;
+    bool st_have = false;                               // wave-uniform: the shift has been taken from the first outputs
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { st_k[nb][r] = 0.f; st_s1[nb][r] = 0.f; st_s2[nb][r] = 0.f; }
+        for (int h = 0; h < 2; ++h) { st_nk[nb][h] = (v2f){0.f, 0.f}; st_s1[nb][h] = (v2f){0.f, 0.f}; st_s2[nb][h] = (v2f){0.f, 0.f}; }
 
     v4f acc[MB][NB];            // results of this group's current tile: produced in one slot, written out in the next
-    int pix[MB];
+    int wflag[MB];              // 1 where this lane's pixel of block mb lies on the output row after the block's first pixel
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) pix[mb] = HoWo;
+    for (int mb = 0; mb < MB; ++mb) wflag[mb] = 0;
+
+    // Pixel geometry is decoded on the scalar ALU (an MFMA stream owns the vector issue port, see the loader comment):
+    // block mb of this wave starts at pixel pm = (oh_m, ow_m), lane j holds pixel pm + j, which wraps to the next output
+    // row at most once (Wo >= 16).  Every per-lane address is  lane constant + scalar + wflag * scalar.
+    const int lane_x = j * 64 + kq * 16;                                           // LDS: column slot, channel quad
+    const int oA = g.os * g.OWt * g.N * 4, oB = g.os * g.N * 4;                    // output bytes per output row / column
+    const int oD = oA - g.Wo * oB;
+    const int lane_o = (j * g.os * g.N + kq * 4 + nb0 * 16) * 4 + (g.oo_h * g.OWt + g.oo_w) * g.N * 4;
+    const int img_bytes_o = g.OHt * g.OWt * g.N * 4;
+    const __amdgpu_buffer_rsrc_t yrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(Y) + (size_t)img * img_bytes_o, 0, img_bytes_o, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(res)) + (res ? (size_t)img * img_bytes_o : 0), 0, res ? img_bytes_o : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(res_mask)) + (res_mask ? (size_t)img * img_bytes_o : 0), 0, res_mask ? img_bytes_o : 0, 0x00020000);
+    v4f bias4[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        bias4[nb] = bias ? *reinterpret_cast<const v4f*>(bias + (nb0 + nb) * 16 + kq * 4) : (v4f){0.f, 0.f, 0.f, 0.f};
+
+    // T33: operand row bases of this group's NEXT tile.  They are computed in the group's write-out slot, where the wave
+    // otherwise waits for the other group's MFMAs: ~200 scalar instructions that would sit in front of the MFMA stream.
+    int base_a[3][MB];
+    const int w_lane = w_base + lane * 16;
+    // A wave whose next instruction is a VALU one sits behind the other group's queued MFMAs (in-order issue), so this
+    // runs last in the slot, after the write-out: 4 scalar instructions + 13 VALU per pixel block (row index and column
+    // offset per lane, three ring rows).
+#define DAM_STRIP_GEOM(T_)                                                                                                \
+    do {                                                                                                                  \
+        const int p0g_ = (t_begin + (T_)) * TM + cw * MW;                                                                 \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                               \
+            const int pm_ = p0g_ + mb * 16;                                                                               \
+            const int oh_ = (int)__umulhi((unsigned)pm_, sg.wo_magic), ow_ = pm_ - oh_ * g.Wo;                            \
+            wflag[mb] = j >= g.Wo - ow_ ? 1 : 0;                                                                          \
+            const int col_ = lane_x + (ow_ + g.off_w - g.c0) * 64 - wflag[mb] * (g.Wo * 64);                              \
+            const int row_ = wflag[mb] * g.s + (oh_ * g.s + sg.ring_off + g.off_h);                                       \
+            _Pragma("unroll") for (int a = 0; a < 3; ++a)                                                                 \
+                base_a[a][mb] = ((row_ + a * g.step_h) & (sg.NR - 1)) * RB + col_;                                        \
+        }                                                                                                                 \
+    } while (0)
+    if constexpr (T33) {
+        if (grp == 0) DAM_STRIP_GEOM(0);
+    }
 
     for (int s = 0; grp < 2 && s < n_slots; ++s) {
         if (false) {
@@ -287,16 +339,16 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #else
             if (s < n_tiles) {
 #endif
-                const int p0 = (t_begin + s) * TM;
-                int colbase[MB], ohs[MB];
+                int ohm[MB], owm[MB];                                 // scalars (generic path: decoded in the slot)
+                if constexpr (!T33) {
+                    const int p0w = (t_begin + s) * TM + cw * MW;     // scalar: first pixel of this wave
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    int p = p0 + cw * MW + mb * 16 + j;
-                    pix[mb] = p;
-                    p = p < HoWo ? p : HoWo - 1;
-                    const int oh = fdiv(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
-                    ohs[mb] = oh * g.s + sg.ring_off;
-                    colbase[mb] = ow * 64 + kq * 16;
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int pm = p0w + mb * 16;
+                        ohm[mb] = (int)__umulhi((unsigned)pm, sg.wo_magic);
+                        owm[mb] = pm - ohm[mb] * g.Wo;
+                        wflag[mb] = j >= g.Wo - owm[mb] ? 1 : 0;
+                    }
                 }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
@@ -304,58 +356,48 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
                 if constexpr (T33) {
-                    // Full 3x3 tap grid, everything compile time: 9*NCH items, each MB + NB ds_read_b128 feeding 4*MB*NB MFMAs.
-                    // Explicit two-deep software pipeline: the operands of item i+1 are requested before the MFMAs of item i
-                    // are issued (sched_barrier pins that order), so a wave never waits on the LDS after the first item.
-                    int base_a[3][MB];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-                            base_a[a][mb] = ((ohs[mb] + g.off_h + a * g.step_h) & (sg.NR - 1)) * RB + colbase[mb];
+                    // 3x3, stride 1, unit column step: 9*NCH items, each MB + NB ds_read_b128 feeding 4*MB*NB MFMAs, every
+                    // operand address = per-(tap row, pixel block) register (computed one slot ahead, see DAM_STRIP_GEOM)
+                    // + immediate.  Two-deep software pipeline: the operands of item i+1 are requested before the MFMAs of
+                    // item i are issued (sched_barrier pins that order).
                     constexpr int NI = 9 * NCH;
                     float4 wa[2][NB], xv[2][MB];
 #define DAM_STRIP_LOAD(I_, BUF_)                                                                                          \
     do {                                                                                                                  \
-        const int a_ = (I_) / (3 * NCH), b_ = ((I_) / NCH) % 3, cc_ = (I_) % NCH;                                         \
-        const int coff_ = g.off_w + b_ * g.step_w - g.c0;                                                                 \
-        const int slotoff_ = g.s == 1 ? coff_ : (coff_ & 1) * g.PWs + (coff_ >> 1);                                       \
-        const int tap_ = g.wt_base + a_ * g.wt_sa + b_ * g.wt_sb;                                                         \
-        const int co_ = cc_ * CHB + slotoff_ * 64;                                                                        \
-        const int wo_ = w_base + (((tap_ * NCH + cc_) * NB) * 64 + lane) * 16;                                            \
+        constexpr int a_ = (I_) / (3 * NCH), b_ = ((I_) / NCH) % 3, cc_ = (I_) % NCH;                                     \
         _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                 \
-            wa[BUF_][nb] = *reinterpret_cast<const float4*>(smem + wo_ + nb * 1024);                                      \
+            wa[BUF_][nb] = *reinterpret_cast<const float4*>(smem + w_lane + ((((a_ * 3 + b_) * NCH + cc_) * NB + nb) * 1024)); \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                 \
-            xv[BUF_][mb] = *reinterpret_cast<const float4*>(smem + base_a[a_][mb] + co_);                                 \
+            xv[BUF_][mb] = *reinterpret_cast<const float4*>(smem + (cc_ ? base_a[a_][mb] + CHB : base_a[a_][mb]) + b_ * 64); \
+    } while (0)
+#define DAM_STRIP_MFMA(BUF_)                                                                                              \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                     \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                             \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                         \
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(&wa[BUF_][nb])[r],  \
+                                                                       reinterpret_cast<const float*>(&xv[BUF_][mb])[r], acc[mb][nb], 0, 0, 0); \
+    } while (0)
+#ifndef DAM_STRIP_YIELD
+#define DAM_STRIP_YIELD asm volatile("s_nop 15\n\ts_nop 15")
+#endif
+#define DAM_STRIP_ITEM(I_)                                                                                                \
+    do {                                                                                                                  \
+        if constexpr ((I_) + 1 < NI) DAM_STRIP_LOAD(((I_) + 1 < NI ? (I_) + 1 : 0), ((I_) + 1) & 1);                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        DAM_STRIP_MFMA((I_) & 1);                                                                                         \
+        DAM_STRIP_YIELD;                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
     } while (0)
                     DAM_STRIP_LOAD(0, 0);
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        if (i + 1 < NI) DAM_STRIP_LOAD(i + 1, (i + 1) & 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int cur = i & 1;
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cur][nb].x, xv[cur][mb].x, acc[mb][nb], 0, 0, 0);
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cur][nb].y, xv[cur][mb].y, acc[mb][nb], 0, 0, 0);
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cur][nb].z, xv[cur][mb].z, acc[mb][nb], 0, 0, 0);
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cur][nb].w, xv[cur][mb].w, acc[mb][nb], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                    DAM_STRIP_ITEM(0); DAM_STRIP_ITEM(1); DAM_STRIP_ITEM(2); DAM_STRIP_ITEM(3); DAM_STRIP_ITEM(4);
+                    DAM_STRIP_ITEM(5); DAM_STRIP_ITEM(6); DAM_STRIP_ITEM(7); DAM_STRIP_ITEM(8);
+                    if constexpr (NCH == 2) {
+                        DAM_STRIP_ITEM(9); DAM_STRIP_ITEM(10); DAM_STRIP_ITEM(11); DAM_STRIP_ITEM(12); DAM_STRIP_ITEM(13);
+                        DAM_STRIP_ITEM(14); DAM_STRIP_ITEM(15); DAM_STRIP_ITEM(16); DAM_STRIP_ITEM(17);
                     }
+#undef DAM_STRIP_ITEM
+#undef DAM_STRIP_MFMA
 #undef DAM_STRIP_LOAD
                 } else {
                 // The whole (tap row a, tap column b, chunk) grid is unrolled (nA, nB <= 3, NCH compile time): an LDS operand
@@ -367,14 +409,18 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                     if (a < g.nA) {
                         int base_a[MB];
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-                            base_a[mb] = ((ohs[mb] + g.off_h + a * g.step_h) & (sg.NR - 1)) * RB + colbase[mb];
+                        for (int mb = 0; mb < MB; ++mb) {
+                            const int r0 = ohm[mb] * g.s + sg.ring_off + g.off_h + a * g.step_h;      // scalar
+                            const int R0 = (r0 & (sg.NR - 1)) * RB + owm[mb] * 64;
+                            const int R1 = ((r0 + g.s) & (sg.NR - 1)) * RB + (owm[mb] - g.Wo) * 64;
+                            base_a[mb] = R0 + (lane_x + wflag[mb] * (R1 - R0));
+                        }
 #pragma unroll
                         for (int b = 0; b < 3; ++b) {
                             if (b < g.nB) {
                                 const int coff = g.off_w + b * g.step_w - g.c0;
                                 const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
-                                const int tap = g.wt_base + a * g.wt_sa + b * g.wt_sb;
+                                const int tap = a * 3 + b;             // canonical order in LDS
 #pragma unroll
                                 for (int cc = 0; cc < NCH; ++cc) {
                                     const int co = cc * CHB + slotoff * 64;
@@ -402,58 +448,54 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
             }
             }
             DAM_STAMP(5);
-        } else if (s >= 1 && s <= n_tiles) {
+        } else {
+            if (s >= 1 && s <= n_tiles) {
             // ---------------- write-out slot of this group: tile s-1 (computed in the previous slot) ----------------
-            __builtin_amdgcn_s_setprio(2);          // ahead of the other group's MFMA stream on the issue port
+            const int p0w = (t_begin + s - 1) * TM + cw * MW;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const int p = pix[mb];
+                const int pm = p0w + mb * 16;                    // scalar
 #ifdef DAM_DIAG_NO_WRITEOUT
-                if (p >= 0) continue;
+                const int nvalid = g.B == 12345 ? HoWo - pm : 0;     // runtime-false: keeps the MFMAs alive
+#else
+                const int nvalid = HoWo - pm;                    // lanes j < nvalid hold pixels of this image
 #endif
-                if (p >= HoWo) continue;
-                const int oh = fdiv(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
-                const size_t opix = ((size_t)img * g.OHt + (oh * g.os + g.oo_h)) * g.OWt + (ow * g.os + g.oo_w);
+                if (nvalid <= 0) continue;
+                const int oh_m = (int)__umulhi((unsigned)pm, sg.wo_magic), ow_m = pm - oh_m * g.Wo;
+                const int voff = __builtin_amdgcn_readfirstlane(oh_m * oA + ow_m * oB) + (lane_o + wflag[mb] * oD);
+                if (j < nvalid) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int ch = (nb0 + nb) * 16 + kq * 4;
-                    if (ch >= g.N) continue;
-                    v4f v = acc[mb][nb];
-                    if (bias) {
-                        const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    }
-                    const size_t o = opix * g.N + ch;
-                    if (res) {
-                        const float4 rv = *reinterpret_cast<const float4*>(res + o);
-                        if (res_mask) {
-                            const float4 mv = *reinterpret_cast<const float4*>(res_mask + o);
-                            v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;
-                            v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;
-                        } else {
-                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    for (int nb = 0; nb < NB; ++nb) {
+                        v4f v = acc[mb][nb] + bias4[nb];
+                        if (res) {
+                            const v4f rv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
+                            if (res_mask) {
+                                const v4f mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
+                                v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;
+                                v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;
+                            } else {
+                                v += rv;
+                            }
                         }
-                    }
-                    *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), yrsrc, voff + nb * 64, 0, 0);
 #ifndef DAM_STAMPS
-                    if (stats) {
-                        const float e[4] = {v.x, v.y, v.z, v.w};
-                        if (st_n == 0) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) st_k[nb][r] = e[r];
+                        if (stats) {
+                            if (!st_have) { st_nk[nb][0] = -v.xy; st_nk[nb][1] = -v.zw; }
+                            const v2f d0 = v.xy + st_nk[nb][0], d1 = v.zw + st_nk[nb][1];
+                            st_s1[nb][0] += d0; st_s1[nb][1] += d1;
+                            st_s2[nb][0] = __builtin_elementwise_fma(d0, d0, st_s2[nb][0]);
+                            st_s2[nb][1] = __builtin_elementwise_fma(d1, d1, st_s2[nb][1]);
                         }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float d = e[r] - st_k[nb][r];
-                            st_s1[nb][r] += d;
-                            st_s2[nb][r] = fmaf(d, d, st_s2[nb][r]);
-                        }
-                    }
 #endif
+                    }
+                    if (stats) ++st_n;
                 }
-                if (stats) ++st_n;
+                st_have = true;
             }
-            __builtin_amdgcn_s_setprio(0);
+            }
+            if constexpr (T33) {
+                if (s + 1 < n_tiles) DAM_STRIP_GEOM(s + 1);        // this group's next MFMA slot
+            }
             DAM_STAMP(6);
         }
         // slot boundary: the loaders' rows are in LDS (their ds_writes waited on the loads), the MFMA group's LDS reads
@@ -462,6 +504,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         DAM_STAMP(7);
     }
 
+#undef DAM_STRIP_GEOM
 #ifdef DAM_STAMPS
     DAM_STAMP(8);
     return;
@@ -474,9 +517,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float n = (float)st_n;
-                const float md = st_n ? st_s1[nb][r] / n : 0.f;
-                float mean = st_k[nb][r] + md;
-                float m2 = st_n ? fmaxf(st_s2[nb][r] - st_s1[nb][r] * md, 0.f) : 0.f;
+                const float s1 = st_s1[nb][r >> 1][r & 1], s2 = st_s2[nb][r >> 1][r & 1];
+                const float md = st_n ? s1 / n : 0.f;
+                float mean = md - st_nk[nb][r >> 1][r & 1];
+                float m2 = st_n ? fmaxf(s2 - s1 * md, 0.f) : 0.f;
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) {
                     const float nb_ = __shfl_xor(n, off), mb_ = __shfl_xor(mean, off), qb_ = __shfl_xor(m2, off);
@@ -537,8 +581,13 @@ static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, co
     return DAM_OK;
 }
 
-int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
+int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
                    const float* res, const float* res_mask, float* stats, int* stats_parts, hipStream_t st) {
+    ConvGeo g = g_in;                 // the caller's copy stays as it is for the tile kernel
+    if (g.nB == 3 && g.step_w < 0) {  // same taps walked left to right: column step becomes +1, weight taps are re-indexed
+        g.off_w += 2 * g.step_w; g.step_w = -g.step_w;
+        g.wt_base += 2 * g.wt_sb; g.wt_sb = -g.wt_sb;
+    }
     if (g.in_nchw || g.B > 65535 || g.nA > 3 || g.nB > 3 || g.nchunks > 2) return DAM_ERR_UNSUPPORTED;
     const int nblk = g.N / 16;
     const int64_t npix = (int64_t)g.Ho * g.Wo;
@@ -547,8 +596,8 @@ int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* 
     if (stats && cdiv(nblk, NB) != 1) return DAM_ERR_UNSUPPORTED;        // statistics need all channels in one workgroup
     StripGeo sg;
     sg.RH = h_hi - h_lo + 1;
-    sg.w_taps = g.wt_base + (g.nA - 1) * g.wt_sa + (g.nB - 1) * g.wt_sb + 1;
-    const size_t w_bytes = (size_t)sg.w_taps * g.nchunks * NB * 1024;      // resident packed weights of the N tile
+    sg.w_taps = 9;                                                         // canonical [a*3+b] order in LDS
+    const size_t w_bytes = (size_t)9 * g.nchunks * NB * 1024;      // resident packed weights of the N tile
     if (w_bytes > 48 * 1024) return DAM_ERR_UNSUPPORTED;                    // thick layers: tile kernel (weights from L2)
     sg.w_lds = 1;
     const size_t LDS_MAX = 150 * 1024;                                      // one workgroup (12 waves) per CU
@@ -580,13 +629,14 @@ int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* 
     if (tpw < 2 && sg.tiles_m >= 2) tpw = 2;                      // the two compute groups alternate tiles
     sg.tpw = tpw;
     sg.strips = (int)cdiv(sg.tiles_m, tpw);
-    if (g.Wo > 1024) return DAM_ERR_UNSUPPORTED;
+    if (g.Wo > 1024 || g.Wo < 16) return DAM_ERR_UNSUPPORTED;   // scalar pixel decode: 16 consecutive pixels span <= 2 output rows
     sg.wo_magic = (unsigned)((1ull << 32) / (unsigned)g.Wo) + 1u;
     sg.ring_off = sg.NR * 64;           // keeps (row + ring_off) non-negative for row >= -64*NR
     if (stats_parts) *stats_parts = sg.strips * g.B;
     if (stats && (int64_t)sg.strips * g.B > 1024) return DAM_ERR_UNSUPPORTED;
     if (lds < (size_t)8 * NB * 16 * 3 * sizeof(float)) lds = (size_t)8 * NB * 16 * 3 * sizeof(float);
-    const bool t33 = g.nA == 3 && g.nB == 3;    // full 3x3 tap grid: compile-time item count, reads pipelined across taps
+    // 3x3 taps, stride 1, unit column step: compile-time item grid with immediate operand offsets
+    const bool t33 = g.nA == 3 && g.nB == 3 && g.s == 1 && g.step_w == 1;
 #define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, st
 #define DAM_STRIP_CASE(M_, N_)                                                                                           \
     if (MB == M_ && NB == N_) {                                                                                             \

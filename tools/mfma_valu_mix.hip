@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float v4f __attribute__((ext_vector_type(4)));
-template <int MODE, int PRIO, int SWAP>
+template <int MODE, int PRIO, int SWAP, int YIELD>
 __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int mfma_iters, int other_iters) {
     __shared__ __attribute__((aligned(16))) float sm[4096];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -19,7 +19,14 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                    if (YIELD == 1) asm volatile("s_nop 0");
+                }
+            if (YIELD == 2) asm volatile("s_sleep 1");
+            if (YIELD == 3) asm volatile("s_nop 7");
+            if (YIELD == 4) asm volatile("s_nop 15\n\ts_nop 15");
+            if (YIELD == 5) asm volatile("s_setprio 0\n\ts_nop 3\n\ts_setprio 1");
         }
         for (int i = 0; i < 4; ++i) res += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
     } else if (MODE != 0) {
@@ -58,11 +65,11 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     if (lane == 0) cyc[blockIdx.x * 8 + (SWAP ? wave ^ 4 : wave)] = t1 - t0;
     out[blockIdx.x * 512 + threadIdx.x] = res;
 }
-template <int MODE, int PRIO, int SWAP = 0>
+template <int MODE, int PRIO, int SWAP = 0, int YIELD = 0>
 void run(const char* name, int mfma_iters, int other_iters, double other_ops_per_iter) {
     const int blocks = 256;
     float* out; unsigned long long* cyc; hipMalloc(&out, blocks * 512 * 4); hipMalloc(&cyc, blocks * 8 * 8);
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k<MODE, PRIO, SWAP>), dim3(blocks), dim3(512), 0, 0, out, cyc, mfma_iters, other_iters);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k<MODE, PRIO, SWAP, YIELD>), dim3(blocks), dim3(512), 0, 0, out, cyc, mfma_iters, other_iters);
     hipDeviceSynchronize();
     static unsigned long long h[256 * 8]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     double m = 0, o = 0;
@@ -87,5 +94,12 @@ int main() {
     run<1, 3, 1>("older VALU wave (prio 3), short", 2000, 500, 16);
     run<1, 0, 1>("older VALU wave (prio 0), long", 2000, 8000, 16);
     run<3, 0, 1>("older LDS read wave (prio 0)", 2000, 2000, 4);
+    run<1, 0, 0, 1>("yield s_nop 0 per mfma; VALU short", 2000, 500, 16);
+    run<1, 0, 0, 2>("yield s_sleep 1 per 16; VALU short", 2000, 500, 16);
+    run<1, 0, 0, 3>("yield s_nop 7 per 16; VALU short", 2000, 500, 16);
+    run<1, 0, 0, 4>("yield 2x s_nop 15 per 16; VALU short", 2000, 500, 16);
+    run<1, 3, 0, 4>("yield 2x s_nop 15 per 16; VALU prio3", 2000, 500, 16);
+    run<1, 3, 0, 5>("yield setprio dance; VALU prio3", 2000, 500, 16);
+    run<1, 0, 0, 2>("yield s_sleep 1 per 16; VALU long", 2000, 8000, 16);
     return 0;
 }

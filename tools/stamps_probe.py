@@ -2,7 +2,7 @@
 """Diagnostic: runs the layer1 conv with the -DDAM_STAMPS library and prints phase durations (s_memtime cycles)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ['DAM_LIB_PATH'] = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdam_hip_stamps.so')
+os.environ.setdefault('DAM_LIB_PATH', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdam_hip_stamps.so'))
 import numpy as np, torch
 import deep_audio_mixer_amd
 from deep_audio_mixer_amd import ops
@@ -21,8 +21,8 @@ st = buf.view(torch.int64).cpu().numpy().astype(np.uint64).reshape(-1, 2, 32)
 nwg = int((st[:, 0, 0] != 0).sum())
 names = {1: 'start', 2: 'zeroed', 3: 'first-load', 4: 'issued', 5: 'mfma', 6: 'bar+commit', 7: 'epi+bar', 8: 'end'}
 t0all = None
-for wg in (0, 200, 463):
-    for role, rn in ((0, 'wave0'), (1, 'wave3')):
+for wg in (0, min(200, nwg - 1)):
+    for role, rn in ((0, 'wave0'), (1, 'wave8 (loader)')):
         v = st[wg, role]
         v = v[v != 0]
         tags = (v >> np.uint64(56)).astype(int)
