@@ -40,6 +40,7 @@ struct WgradGeo {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 template <int TNB, int TKB, int TA, int TB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const float* __restrict__ X,
@@ -194,6 +195,258 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGeo g, int
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-streaming variant for the 3x3 / stride 1 / pad 1 layers with equal channel counts on both sides (every BasicBlock
+// convolution except the strided ones): same partial-slab output and reduce kernel as above, different data movement.
+//
+//   * A workgroup (4 compute waves + 4 loader waves, one per CU) owns one (out-channel tile, in-channel tile) and a
+//     strip of output rows of one image.  X rows and dY rows stream through two LDS rings of whole rows; row pitch P4
+//     cells of 16 channels, cell e holds pixel column e-1, the cells outside the image stay zero.  With that pitch the
+//     pixel index is linear inside a row for all three column taps: the X cell of tap b is (dY cell) + b - 1.
+//   * Slot = 4 output rows, one per compute wave.  A wave's operand addresses for a row are 3*TKB + TNB registers
+//     (row bases, scalar ring arithmetic) + immediates: the MFMA stream carries no address arithmetic at all
+//     (a streaming MFMA wave owns the SIMD's vector issue port, see dam_conv_strip.hip).
+//   * Loader waves: scalar plane arithmetic, buffer_load with per-lane column offsets computed once, ds_write with the
+//     column mask in EXEC.  One slot ahead (a slot is >= 4 us of MFMAs, longer than the HBM latency under load).
+struct RowsGeo {
+    int B, H, W, C;          // C channels per pixel in X and in dY
+    int P4;                  // ring row pitch in cells: roundup4(W + 2)
+    int rps, spi;            // output rows per strip (multiple of 4), strips per image
+    int tiles_k;             // in-channel tiles
+    int gpp;                 // 1 KB pieces per row plane
+};
+constexpr int RW_THREADS = 512, RW_NRX = 10, RW_NRD = 8, RW_GUARD = 64, RW_TAIL = 256;
+
+template <int TNB, int TKB, int STEPS, int KP, int GPP>
+__global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g, const float* __restrict__ X,
+                                                                const float* __restrict__ dY, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = TNB * TKB * 9;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int tn = blockIdx.x / g.tiles_k, tk = blockIdx.x - tn * g.tiles_k;
+    const int img = blockIdx.y / g.spi, r_begin = (blockIdx.y - img * g.spi) * g.rps;
+    const int r_end = r_begin + g.rps < g.H ? r_begin + g.rps : g.H;
+    const int n_slots = (r_end - r_begin + 3) >> 2;
+    const int ROWB = g.P4 * 64;
+    const int XPLANE = RW_NRX * ROWB, DPLANE = RW_NRD * ROWB;
+    const int XBASE = RW_GUARD, DBASE = XBASE + TKB * XPLANE;
+    const int lds_bytes = DBASE + TNB * DPLANE + RW_TAIL;
+
+    for (int e = tid * 16; e < lds_bytes; e += RW_THREADS * 16)
+        *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    v4f acc[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    if (wave >= 4) {
+        // ================================ loader waves ================================
+        const int cwl = wave - 4;
+        int loffb[GPP];
+        unsigned long long cmask[GPP];
+#pragma unroll
+        for (int gi = 0; gi < GPP; ++gi) {
+            const int L = gi * 64 + lane, e = L >> 2, quad = L & 3, col = e - 1;
+            const bool ok = gi < g.gpp && e < g.P4 && col >= 0 && col < g.W;
+            const int colc = col < 0 ? 0 : (col >= g.W ? g.W - 1 : col);
+            loffb[gi] = (colc * g.C + quad * 4) * 4;
+            cmask[gi] = __ballot(ok);
+        }
+        const int img_bytes = g.H * g.W * g.C * 4;
+        const __amdgpu_buffer_rsrc_t xrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + (size_t)img * g.H * g.W * g.C, 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t drsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY) + (size_t)img * g.H * g.W * g.C, 0, img_bytes, 0x00020000);
+        const int lane16 = lane * 16;
+        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+        v4f lv[KP][GPP];
+        int dst[KP];               // scalar: LDS byte offset of the plane | 1 << 30 (row outside the image: zeros), -1 = none
+        const int rowstride = g.W * g.C * 4;
+        // X rows xr0 .. xr0+nx-1 (in-channel chunks of this tile) then dY rows dr0 .. dr0+nd-1 (out-channel blocks), one
+        // plane = one (row, 16 channels); loader wave cwl takes planes cwl, cwl+4, ...  Loads are unconditional (clamped).
+#define DAM_RW_REQUEST(XR0_, NX_, DR0_, ND_)                                                                               \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
+            const int pl_ = cwl + 4 * k;                                                                                   \
+            const int nxp_ = (NX_) * TKB;                                                                                  \
+            const bool isx_ = pl_ < nxp_;                                                                                  \
+            const int q_ = isx_ ? pl_ : pl_ - nxp_;                                                                        \
+            const int i_ = isx_ ? q_ / TKB : q_ / TNB, c_ = isx_ ? q_ - i_ * TKB : q_ - i_ * TNB;                          \
+            const int row_ = (isx_ ? (XR0_) : (DR0_)) + i_;                                                                \
+            const bool need_ = isx_ ? row_ <= r_end : (i_ < (ND_) && row_ < r_end);                                        \
+            const bool inimg_ = need_ && row_ >= 0 && row_ < g.H;                                                          \
+            const int rel_ = row_ - r_begin + 1;                               /* >= 0 for every needed row */             \
+            const int xi_ = rel_ - ((rel_ * 52429) >> 19) * RW_NRX;            /* rel_ % 10 */                             \
+            const int di_ = (row_ - r_begin) & (RW_NRD - 1);                                                               \
+            const int ldsoff_ = isx_ ? XBASE + c_ * XPLANE + xi_ * ROWB : DBASE + c_ * DPLANE + di_ * ROWB;                \
+            const int chan_ = isx_ ? (tk * TKB + c_) * 64 : (tn * TNB + c_) * 64;                                          \
+            const int soff_ = (inimg_ ? row_ : 0) * rowstride + chan_;                                                     \
+            if (isx_) {                                                                                                    \
+                _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                         \
+                    lv[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[gi], soff_, 0)); \
+            } else {                                                                                                       \
+                _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                         \
+                    lv[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(drsrc, loffb[gi], soff_, 0)); \
+            }                                                                                                              \
+            dst[k] = need_ ? (ldsoff_ | (inimg_ ? 0 : 1 << 30)) : -1;                                                      \
+        }                                                                                                                  \
+    } while (0)
+#define DAM_RW_WRITE(ADDR_, DATA_, GI_)                                                                                    \
+    asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
+                 : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024) : "memory")
+#define DAM_RW_COMMIT()                                                                                                    \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
+            if (dst[k] >= 0) {                                                                                             \
+                const int va_ = lane16 + (dst[k] & 0x3fffffff);                                                            \
+                if (!(dst[k] >> 30)) {                                                                                     \
+                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, lv[k][gi], gi);                   \
+                } else {                                                                                                   \
+                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, zero4, gi);                       \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
+        // rows of slot 0: X rows r_begin-1 .. r_begin+4, dY rows r_begin .. r_begin+3, in two rounds
+        DAM_RW_REQUEST(r_begin - 1, 4, r_begin, 4);
+        DAM_RW_COMMIT();
+        DAM_RW_REQUEST(r_begin + 3, 2, r_begin, 0);
+        DAM_RW_COMMIT();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int s = 0; s < n_slots; ++s) {
+            // rows slot s+1 adds: X rows r_begin+4(s+1)+1 .. +4, dY rows r_begin+4(s+1) .. +3
+            DAM_RW_REQUEST(r_begin + 4 * s + 5, 4, r_begin + 4 * s + 4, 4);
+            DAM_RW_COMMIT();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+#undef DAM_RW_REQUEST
+#undef DAM_RW_WRITE
+#undef DAM_RW_COMMIT
+    } else {
+        // ================================ compute waves ================================
+        const int cw = wave;
+        const int lane_b = kq * 64 + j * 4;       // lane group kq owns cell 4t + kq of step t, lane j channel j of the cell
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS
+        for (int s = 0; s < n_slots; ++s) {
+            const int r = r_begin + 4 * s + cw;
+            if (r < r_end) {
+                int vx[TKB][3], vd[TNB];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int rel = 4 * s + cw + a;                            // row r - 1 + a relative to r_begin - 1
+                    const int xi = rel - ((rel * 52429) >> 19) * RW_NRX;
+#pragma unroll
+                    for (int kb = 0; kb < TKB; ++kb) vx[kb][a] = lane_b + (XBASE - 64 + kb * XPLANE + xi * ROWB);
+                }
+#pragma unroll
+                for (int nb = 0; nb < TNB; ++nb) vd[nb] = lane_b + (DBASE + nb * DPLANE + ((4 * s + cw) & (RW_NRD - 1)) * ROWB);
+                float av[2][TNB], bv[2][TKB][9];
+#define DAM_RW_LOAD(T_, BUF_)                                                                                              \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                                 \
+            av[BUF_][nb] = *reinterpret_cast<const float*>(smem + vd[nb] + (T_) * 256);                                    \
+        _Pragma("unroll") for (int kb = 0; kb < TKB; ++kb)                                                                 \
+            _Pragma("unroll") for (int a = 0; a < 3; ++a)                                                                  \
+                _Pragma("unroll") for (int b = 0; b < 3; ++b)                                                              \
+                    bv[BUF_][kb][a * 3 + b] = *reinterpret_cast<const float*>(smem + vx[kb][a] + ((T_) * 256 + b * 64));   \
+    } while (0)
+                DAM_RW_LOAD(0, 0);
+#pragma unroll
+                for (int t = 0; t < STEPS; ++t) {
+                    if (t + 1 < STEPS) DAM_RW_LOAD(t + 1, (t + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nb = 0; nb < TNB; ++nb)
+#pragma unroll
+                        for (int kb = 0; kb < TKB; ++kb)
+#pragma unroll
+                            for (int tap = 0; tap < 9; ++tap) {
+                                const int idx = (nb * TKB + kb) * 9 + tap;
+                                acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][nb], bv[t & 1][kb][tap], acc[idx], 0, 0, 0);
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef DAM_RW_LOAD
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+
+    // combine the 4 compute waves through LDS (sequential adds: fixed order), one slab per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) {
+                float4* d4 = reinterpret_cast<float4*>(red + (i * 64 + lane) * 4);
+                if (w == 0) {
+                    *d4 = make_float4(acc[i].x, acc[i].y, acc[i].z, acc[i].w);
+                } else {
+                    float4 o = *d4;
+                    o.x += acc[i].x; o.y += acc[i].y; o.z += acc[i].z; o.w += acc[i].w;
+                    *d4 = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NBLK * 64;
+    for (int e = tid; e < NBLK * 64; e += RW_THREADS) out[e] = reinterpret_cast<const float4*>(red)[e];
+}
+
+template <int TNB, int TKB, int STEPS, int KP, int GPP>
+int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* dY, float* partial, int64_t ws_floats,
+                      float* dw, int n_real, hipStream_t st) {
+    constexpr int NBLK = TNB * TKB * 9;
+    RowsGeo g;
+    g.B = B; g.H = H; g.W = W; g.C = C;
+    g.P4 = ((W + 2 + 3) / 4) * 4;
+    if (g.P4 != STEPS * 4) return DAM_ERR_UNSUPPORTED;
+    g.gpp = (g.P4 * 64 + 1023) / 1024;
+    if (g.gpp > GPP || (4 * TKB + 4 * TNB + 3) / 4 > KP) return DAM_ERR_UNSUPPORTED;
+    const int nblk = C / 16;
+    if (nblk % TNB || nblk % TKB || H >= 8000) return DAM_ERR_UNSUPPORTED;
+    const int tiles_n = nblk / TNB;
+    g.tiles_k = nblk / TKB;
+    const int nx = tiles_n * g.tiles_k;
+    int want = 256 / nx;                              // one workgroup per CU
+    if (want < 1) want = 1;
+    int spi = (int)cdiv(want, B);
+    if (spi > (int)cdiv(H, 4)) spi = (int)cdiv(H, 4);
+    for (;; --spi) {
+        g.rps = (int)cdiv(cdiv(H, spi), 4) * 4;
+        g.spi = (int)cdiv(H, g.rps);
+        if ((int64_t)B * g.spi * nx * NBLK * 256 <= ws_floats || spi == 1) break;
+    }
+    const int nsplit = B * g.spi;
+    if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
+    const size_t rowb = (size_t)g.P4 * 64;
+    size_t lds = RW_GUARD + (size_t)TKB * RW_NRX * rowb + (size_t)TNB * RW_NRD * rowb + RW_TAIL;
+    if (lds < (size_t)NBLK * 1024) lds = (size_t)NBLK * 1024;
+    if (lds > 160 * 1024) return DAM_ERR_UNSUPPORTED;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return DAM_ERR_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP>), dim3(nx, nsplit), dim3(RW_THREADS), lds, st, g, X, dY, partial);
+    DAM_CHECK_LAUNCH();
+    WgradGeo rg = {};                                 // what the reduce kernel reads
+    rg.tap_groups = 1; rg.tiles_k = g.tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = 3; rg.KW = 3;
+    const int64_t per_split = (int64_t)nx * NBLK * 256;
+    const int rb = (int)(cdiv(per_split, 32) < 2048 ? cdiv(per_split, 32) : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, C, partial, dw, nx);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
 template <int TNB, int TKB, int TA, int TB>
 int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, const float* sh, float* partial,
                  int64_t ws_floats, float* dw, int n_real, int k_real, hipStream_t st) {
@@ -249,6 +502,15 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     if (n_chan % 16 || n_out > n_chan || (stride != 1 && stride != 2)) return DAM_ERR_UNSUPPORTED;
     if (in_nchw ? C > 16 : C % 16) return DAM_ERR_UNSUPPORTED;
     if (in_scale && !in_shift) return DAM_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !in_nchw && !in_scale && Ho == H && Wo == W && C == n_chan) {
+        // row-streaming kernel for the shapes of the ResNet stages; anything else takes the tile kernel below
+        int rc = DAM_ERR_UNSUPPORTED;
+        if (C == 16) rc = launch_wgrad_rows<1, 1, 33, 2, 9>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
+        else if (W > 48) rc = launch_wgrad_rows<2, 1, 17, 3, 5>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
+        else rc = launch_wgrad_rows<2, 1, 9, 3, 3>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
+        if (rc != DAM_ERR_UNSUPPORTED) return rc;
+    }
     WgradGeo g;
     g.B = B; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.N = n_chan; g.s = stride; g.KH = kh; g.KW = kw;
     g.off_h = -pad; g.step_h = dil; g.off_w = -pad; g.step_w = dil;
@@ -269,7 +531,6 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     g.nblk = n_chan / 16;
     g.in_nchw = in_nchw; g.relu_in = relu_in;
     const int k_real = C;
-    hipStream_t st = (hipStream_t)stream;
     // tile choice: 2x2 channel blocks when both sides have them and LDS allows two workgroups per CU
     bool small = g.nchunks == 1 || g.nblk == 1;
     set_tile(256);

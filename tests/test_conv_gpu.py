@@ -134,6 +134,19 @@ def test_full_resolution_layer1(ops):
     close(ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), 16, 3, 3, 1, 1, 1), want_dw, 1e-4)
 
 
+@pytest.mark.parametrize('B,C,H,W', [(2, 16, 23, 130), (1, 16, 9, 127), (2, 32, 21, 65), (1, 64, 19, 33), (3, 32, 4, 66),
+                                     (1, 64, 37, 31)])
+def test_wgrad_row_streaming_shapes(ops, B, C, H, W):
+    """3x3 / stride 1 / pad 1 weight gradient at the widths of the ResNet stages (row-streaming kernel), ragged strips."""
+    g = torch.Generator().manual_seed(B * 1000 + C + H + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    dy = torch.randn(B, C, H, W, generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (C, C, 3, 3), dy.double(), 1, 1)
+    got = ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), C, 3, 3, 1, 1, 1)
+    assert got.shape == (C, C, 3, 3)
+    close(got, want, 5e-5)
+
+
 def test_fused_bn_statistics_epilogue(ops):
     """The strip kernel's BatchNorm partial records, merged by dam_bn_finalize_f32, equal the two-pass statistics of the
     conv output (mean far from zero on purpose: dB-valued activations)."""
