@@ -206,11 +206,11 @@ def main():
         k = probe['layer1_conv3x3_16x16']
         # fwd+bwd algorithmic FLOPs of the whole step (29.5 GFLOP per clip) over the step time
         # traffic: HBM bytes per launch from the committed PMC passes on this kernel at this shape
-        # (profiles/r01_conv_layer1_pmc.csv: FETCH_SIZE 38,967 KB x 2 [gfx950 halves wide coalesced reads] + WRITE_SIZE 66,625 KB)
+        # (profiles/r01_layer1_conv_wgrad_pmc.csv: FETCH_SIZE 36,648 KB x 2 [gfx950 halves wide coalesced reads] + WRITE_SIZE 66,625 KB)
         result['roofline'] = {'bound': 'mfma', 'achieved': k['fwd_tflops'], 'peak': PEAK_F32_MFMA / 1e12,
-                              'unit': 'TFLOP/s', 'frac': k['fwd_tflops'] * 1e12 / PEAK_F32_MFMA, 'traffic': 144.6e6,
-                              'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_conv_layer1_pmc.csv)',
-                              'kernel': 'conv_strip_kernel<4,1> (ResNet layer1 3x3 conv 16->16 forward, 8x1025x130 px)',
+                              'unit': 'TFLOP/s', 'frac': k['fwd_tflops'] * 1e12 / PEAK_F32_MFMA, 'traffic': 139.9e6,
+                              'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_layer1_conv_wgrad_pmc.csv)',
+                              'kernel': 'conv_strip_kernel<4,1,1,true> (ResNet layer1 3x3 conv 16->16 forward, 8x1025x130 px)',
                               'avg_launch_s': k['fwd_s'], 'flops_per_launch': k['flops_per_launch'],
                               'hbm_alg_bytes_per_launch': k['alg_bytes_per_launch'],
                               'hbm_alg_GBps': k['alg_bytes_per_launch'] / k['fwd_s'] / 1e9,
