@@ -161,24 +161,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
     for (int e = tid; e < NBLK * 64; e += 256) out[e] = reinterpret_cast<const float4*>(red)[e];
 }
 
-// dW[n][k][kh][kw] = sum over splits of the slabs.  Block = 32 elements x 8 split lanes: every thread adds a
-// strided subset of the splits, the 8 subtotals are combined in a fixed order (deterministic).
+// dW[n][k][kh][kw] = sum over splits of the slabs.  Block = 8 elements x 32 split lanes: a thread adds a strided subset
+// of the splits (4 independent chains, all loads in flight), the 32 subtotals are combined by a fixed tree (deterministic).
+template <int SL>       // split lanes: 32 for many slabs (row kernel: one per workgroup), 8 for few big ones
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGeo g, int TNB, int TKB, int TA, int TB, int n_real,
                                                            int k_real, const float* __restrict__ partial,
                                                            float* __restrict__ dw, int nx) {
-    __shared__ float sub[8][32];
+    constexpr int EL = 256 / SL;
+    __shared__ float sub[SL][EL];
     const int nblk_tile = TNB * TKB * TA * TB;
     const int64_t per_split = (int64_t)nx * nblk_tile * 256;
-    const int el = threadIdx.x & 31, ys = threadIdx.x >> 5;
-    for (int64_t e0 = (int64_t)blockIdx.x * 32; e0 < per_split; e0 += (int64_t)gridDim.x * 32) {
+    const int el = threadIdx.x % EL, ys = threadIdx.x / EL;
+    for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < per_split; e0 += (int64_t)gridDim.x * EL) {
         const int64_t e = e0 + el;
-        float s = 0.f;
-        if (e < per_split)
-            for (int y = ys; y < g.nsplit; y += 8) s += partial[y * per_split + e];
-        sub[ys][el] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int y = ys;
+        for (; y + 3 * SL < g.nsplit; y += 4 * SL) {
+            s0 += partial[y * per_split + e]; s1 += partial[(y + SL) * per_split + e];
+            s2 += partial[(y + 2 * SL) * per_split + e]; s3 += partial[(y + 3 * SL) * per_split + e];
+        }
+        for (; y < g.nsplit; y += SL) s0 += partial[y * per_split + e];
+        sub[ys][el] = (s0 + s1) + (s2 + s3);
         __syncthreads();
-        if (ys == 0 && e < per_split) {
-            s = ((sub[0][el] + sub[1][el]) + (sub[2][el] + sub[3][el])) + ((sub[4][el] + sub[5][el]) + (sub[6][el] + sub[7][el]));
+#pragma unroll
+        for (int stride = SL / 2; stride >= 1; stride >>= 1) {
+            if (ys < stride) sub[ys][el] += sub[ys + stride][el];
+            __syncthreads();
+        }
+        if (ys == 0) {
+            const float s = sub[0][el];
             const int r = e & 3, lane = (e >> 2) & 63;
             int64_t q = e >> 8;
             const int blk = q % nblk_tile;
@@ -195,12 +206,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGeo g, int
     }
 }
 
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Row-streaming variant for the 3x3 / stride 1 / pad 1 layers with equal channel counts on both sides (every BasicBlock
 // convolution except the strided ones): same partial-slab output and reduce kernel as above, different data movement.
 //
-//   * A workgroup (4 compute waves + 4 loader waves, one per CU) owns one (out-channel tile, in-channel tile) and a
+//   * A workgroup (4 compute waves + 8 loader waves, one per CU) owns one (out-channel tile, in-channel tile) and a
 //     strip of output rows of one image.  X rows and dY rows stream through two LDS rings of whole rows; row pitch P4
 //     cells of 16 channels, cell e holds pixel column e-1, the cells outside the image stay zero.  With that pitch the
 //     pixel index is linear inside a row for all three column taps: the X cell of tap b is (dY cell) + b - 1.
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGeo g, int
 //     (row bases, scalar ring arithmetic) + immediates: the MFMA stream carries no address arithmetic at all
 //     (a streaming MFMA wave owns the SIMD's vector issue port, see dam_conv_strip.hip).
 //   * Loader waves: scalar plane arithmetic, buffer_load with per-lane column offsets computed once, ds_write with the
-//     column mask in EXEC.  One slot ahead (a slot is >= 4 us of MFMAs, longer than the HBM latency under load).
+//     column mask in EXEC.  Two slots ahead in two register sets (a slot is ~4 us of MFMAs, about the HBM latency under load).
 struct RowsGeo {
     int B, H, W, C;          // C channels per pixel in X and in dY
     int P4;                  // ring row pitch in cells: roundup4(W + 2)
@@ -216,7 +226,8 @@ struct RowsGeo {
     int tiles_k;             // in-channel tiles
     int gpp;                 // 1 KB pieces per row plane
 };
-constexpr int RW_THREADS = 512, RW_NRX = 10, RW_NRD = 8, RW_GUARD = 64, RW_TAIL = 256;
+constexpr int RW_LOADERS = 8;                 // loader waves (waves 4..11)
+constexpr int RW_THREADS = 256 + 64 * RW_LOADERS, RW_NRX = 10, RW_NRD = 8, RW_GUARD = 64, RW_TAIL = 256;
 
 template <int TNB, int TKB, int STEPS, int KP, int GPP>
 __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g, const float* __restrict__ X,
@@ -230,14 +241,20 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
     const int img = blockIdx.y / g.spi, r_begin = (blockIdx.y - img * g.spi) * g.rps;
     const int r_end = r_begin + g.rps < g.H ? r_begin + g.rps : g.H;
     const int n_slots = (r_end - r_begin + 3) >> 2;
+    const int n_slots2 = (n_slots + 1) & ~1;
     const int ROWB = g.P4 * 64;
     const int XPLANE = RW_NRX * ROWB, DPLANE = RW_NRD * ROWB;
     const int XBASE = RW_GUARD, DBASE = XBASE + TKB * XPLANE;
     const int lds_bytes = DBASE + TNB * DPLANE + RW_TAIL;
 
-    for (int e = tid * 16; e < lds_bytes; e += RW_THREADS * 16)
-        *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    // every thread zeroes its share of the LDS image (padding cells stay zero for the lifetime of the workgroup); the
+    // loader waves have the rows of slot 0 in flight while that happens
+#define DAM_RW_ZERO()                                                                                                      \
+    do {                                                                                                                   \
+        for (int e = tid * 16; e < lds_bytes; e += RW_THREADS * 16)                                                        \
+            *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                    \
+    } while (0)
 
     v4f acc[NBLK];
 #pragma unroll
@@ -268,10 +285,10 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         const int rowstride = g.W * g.C * 4;
         // X rows xr0 .. xr0+nx-1 (in-channel chunks of this tile) then dY rows dr0 .. dr0+nd-1 (out-channel blocks), one
         // plane = one (row, 16 channels); loader wave cwl takes planes cwl, cwl+4, ...  Loads are unconditional (clamped).
-#define DAM_RW_REQUEST(XR0_, NX_, DR0_, ND_)                                                                               \
+#define DAM_RW_REQUEST(XR0_, NX_, DR0_, ND_, LV_, DST_, KP_)                                                                               \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
-            const int pl_ = cwl + 4 * k;                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < KP_; ++k) {                                                                  \
+            const int pl_ = cwl + RW_LOADERS * k;                                                                          \
             const int nxp_ = (NX_) * TKB;                                                                                  \
             const bool isx_ = pl_ < nxp_;                                                                                  \
             const int q_ = isx_ ? pl_ : pl_ - nxp_;                                                                        \
@@ -287,40 +304,51 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
             const int soff_ = (inimg_ ? row_ : 0) * rowstride + chan_;                                                     \
             if (isx_) {                                                                                                    \
                 _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                         \
-                    lv[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[gi], soff_, 0)); \
+                    LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[gi], soff_, 0)); \
             } else {                                                                                                       \
                 _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                         \
-                    lv[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(drsrc, loffb[gi], soff_, 0)); \
+                    LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(drsrc, loffb[gi], soff_, 0)); \
             }                                                                                                              \
-            dst[k] = need_ ? (ldsoff_ | (inimg_ ? 0 : 1 << 30)) : -1;                                                      \
+            DST_[k] = need_ ? (ldsoff_ | (inimg_ ? 0 : 1 << 30)) : -1;                                                     \
         }                                                                                                                  \
     } while (0)
 #define DAM_RW_WRITE(ADDR_, DATA_, GI_)                                                                                    \
     asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
                  : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024) : "memory")
-#define DAM_RW_COMMIT()                                                                                                    \
+#define DAM_RW_COMMIT(LV_, DST_, KP_)                                                                                      \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
-            if (dst[k] >= 0) {                                                                                             \
-                const int va_ = lane16 + (dst[k] & 0x3fffffff);                                                            \
-                if (!(dst[k] >> 30)) {                                                                                     \
-                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, lv[k][gi], gi);                   \
+        _Pragma("unroll") for (int k = 0; k < KP_; ++k) {                                                                  \
+            if (DST_[k] >= 0) {                                                                                            \
+                const int va_ = lane16 + (DST_[k] & 0x3fffffff);                                                           \
+                if (!(DST_[k] >> 30)) {                                                                                    \
+                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, LV_[k][gi], gi);                  \
                 } else {                                                                                                   \
                     _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, zero4, gi);                       \
                 }                                                                                                          \
             }                                                                                                              \
         }                                                                                                                  \
     } while (0)
-        // rows of slot 0: X rows r_begin-1 .. r_begin+4, dY rows r_begin .. r_begin+3, in two rounds
-        DAM_RW_REQUEST(r_begin - 1, 4, r_begin, 4);
-        DAM_RW_COMMIT();
-        DAM_RW_REQUEST(r_begin + 3, 2, r_begin, 0);
-        DAM_RW_COMMIT();
+        // rows of slot 0: X rows r_begin-1 .. r_begin+4, dY rows r_begin .. r_begin+3: both rounds requested up front
+        constexpr int KPB = (2 * TKB + RW_LOADERS - 1) / RW_LOADERS;
+        v4f lvb[KPB][GPP], lv2[KP][GPP];
+        int dstb[KPB], dst2[KP];
+        DAM_RW_REQUEST(r_begin - 1, 4, r_begin, 4, lv, dst, KP);
+        DAM_RW_REQUEST(r_begin + 3, 2, r_begin, 0, lvb, dstb, KPB);
+        DAM_RW_ZERO();
+        DAM_RW_COMMIT(lv, dst, KP);
+        DAM_RW_COMMIT(lvb, dstb, KPB);
+        // steady state, two slots ahead (HBM latency under this load is about one slot): slot s writes the rows slot s+1
+        // adds (X rows r_begin+4(s+1)+1 .. +4, dY rows r_begin+4(s+1) .. +3; requested during slot s-1) and requests those
+        // of slot s+3.  Two register sets alternate; slots come in pairs so that no load sits inside a conditional.
+        DAM_RW_REQUEST(r_begin + 5, 4, r_begin + 4, 4, lv, dst, KP);
+        DAM_RW_REQUEST(r_begin + 9, 4, r_begin + 8, 4, lv2, dst2, KP);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        for (int s = 0; s < n_slots; ++s) {
-            // rows slot s+1 adds: X rows r_begin+4(s+1)+1 .. +4, dY rows r_begin+4(s+1) .. +3
-            DAM_RW_REQUEST(r_begin + 4 * s + 5, 4, r_begin + 4 * s + 4, 4);
-            DAM_RW_COMMIT();
+        for (int s = 0; s < n_slots2; s += 2) {
+            DAM_RW_COMMIT(lv, dst, KP);
+            DAM_RW_REQUEST(r_begin + 4 * s + 13, 4, r_begin + 4 * s + 12, 4, lv, dst, KP);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            DAM_RW_COMMIT(lv2, dst2, KP);
+            DAM_RW_REQUEST(r_begin + 4 * s + 17, 4, r_begin + 4 * s + 16, 4, lv2, dst2, KP);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 #undef DAM_RW_REQUEST
@@ -330,8 +358,9 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         // ================================ compute waves ================================
         const int cw = wave;
         const int lane_b = kq * 64 + j * 4;       // lane group kq owns cell 4t + kq of step t, lane j channel j of the cell
+        DAM_RW_ZERO();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS
-        for (int s = 0; s < n_slots; ++s) {
+        for (int s = 0; s < n_slots2; ++s) {
             const int r = r_begin + 4 * s + cw;
             if (r < r_end) {
                 int vx[TKB][3], vd[TNB];
@@ -408,7 +437,7 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     g.P4 = ((W + 2 + 3) / 4) * 4;
     if (g.P4 != STEPS * 4) return DAM_ERR_UNSUPPORTED;
     g.gpp = (g.P4 * 64 + 1023) / 1024;
-    if (g.gpp > GPP || (4 * TKB + 4 * TNB + 3) / 4 > KP) return DAM_ERR_UNSUPPORTED;
+    if (g.gpp > GPP || (4 * TKB + 4 * TNB + RW_LOADERS - 1) / RW_LOADERS > KP) return DAM_ERR_UNSUPPORTED;
     const int nblk = C / 16;
     if (nblk % TNB || nblk % TKB || H >= 8000) return DAM_ERR_UNSUPPORTED;
     const int tiles_n = nblk / TNB;
@@ -441,8 +470,13 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     WgradGeo rg = {};                                 // what the reduce kernel reads
     rg.tap_groups = 1; rg.tiles_k = g.tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = 3; rg.KW = 3;
     const int64_t per_split = (int64_t)nx * NBLK * 256;
-    const int rb = (int)(cdiv(per_split, 32) < 2048 ? cdiv(per_split, 32) : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, C, partial, dw, nx);
+    if (nsplit >= 64) {
+        const int rb = (int)(cdiv(per_split, 8) < 4096 ? cdiv(per_split, 8) : 4096);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, C, partial, dw, nx);
+    } else {
+        const int rb = (int)(cdiv(per_split, 32) < 2048 ? cdiv(per_split, 32) : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, C, partial, dw, nx);
+    }
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
@@ -476,8 +510,13 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
     hipLaunchKernelGGL((wgrad_kernel<TNB, TKB, TA, TB>), dim3(nx, nsplit), dim3(256), lds, st, g, X, dY, sc, sh, partial);
     DAM_CHECK_LAUNCH();
     const int64_t per_split = (int64_t)nx * NBLK * 256;
-    const int rb = (int)(cdiv(per_split, 32) < 2048 ? cdiv(per_split, 32) : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, g, TNB, TKB, TA, TB, n_real, k_real, partial, dw, nx);
+    if (g.nsplit >= 64) {
+        const int rb = (int)(cdiv(per_split, 8) < 4096 ? cdiv(per_split, 8) : 4096);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, g, TNB, TKB, TA, TB, n_real, k_real, partial, dw, nx);
+    } else {
+        const int rb = (int)(cdiv(per_split, 32) < 2048 ? cdiv(per_split, 32) : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, g, TNB, TKB, TA, TB, n_real, k_real, partial, dw, nx);
+    }
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
@@ -506,9 +545,9 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !in_nchw && !in_scale && Ho == H && Wo == W && C == n_chan) {
         // row-streaming kernel for the shapes of the ResNet stages; anything else takes the tile kernel below
         int rc = DAM_ERR_UNSUPPORTED;
-        if (C == 16) rc = launch_wgrad_rows<1, 1, 33, 2, 9>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
-        else if (W > 48) rc = launch_wgrad_rows<2, 1, 17, 3, 5>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
-        else rc = launch_wgrad_rows<2, 1, 9, 3, 3>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
+        if (C == 16) rc = launch_wgrad_rows<1, 1, 33, 1, 9>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
+        else if (W > 48) rc = launch_wgrad_rows<2, 1, 17, 2, 5>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
+        else rc = launch_wgrad_rows<2, 1, 9, 2, 3>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
     WgradGeo g;
