@@ -12,6 +12,7 @@ _STATUS = {0: 'DAM_OK', -1: 'DAM_ERR_BAD_ARG', -2: 'DAM_ERR_UNSUPPORTED', -3: 'D
            -4: 'DAM_ERR_WORKSPACE'}
 
 c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+c_d = ctypes.c_double
 
 # name -> (restype, argtypes); kept in the order of include/dam_hip.h
 SIGNATURES = {
@@ -48,6 +49,9 @@ SIGNATURES = {
     'dam_gain_ramp_apply': (c_i, [c_p, c_p, c_i, c_i64, c_i64, c_i, c_p, c_p]),
     'dam_mixdown_workspace_elems': (c_i64, [c_i64]),
     'dam_mixdown_peak_normalize': (c_i, [c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    'dam_loudness_kweight_coeffs': (c_i, [c_d, c_p]),
+    'dam_loudness_workspace_bytes': (c_i64, [c_i64, c_i]),
+    'dam_loudness_block_energy': (c_i, [c_p, c_i, c_i64, c_i, c_i64, c_i64, c_p, c_p, c_p, c_i, c_d, c_p, c_p, c_p]),
 }
 
 _lib = None

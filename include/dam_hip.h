@@ -226,6 +226,26 @@ int64_t dam_mixdown_workspace_elems(int64_t rows);
 int dam_mixdown_peak_normalize(const void* audio, const void* gains, int is_f64, int n_stems, int64_t rows,
                                int64_t n_samples, int n_gains, int normalize, void* mix, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * ITU-R BS.1770 loudness.  Replaces what the reference gets from the third-party pyloudnorm
+ * package (`pyln.Meter(sr).integrated_loudness`): data/dataset.py:115-130, evaluation.py:39-46,59-66,
+ * models/baselines/mean_loudness_model.py:10-20.
+ *   dam_loudness_kweight_coeffs (host): the two normalised biquads of pyloudnorm's "K-weighting" at `rate`,
+ *     coef12 = {b0,b1,b2,1,a1,a2} for the high shelf then the high pass.
+ *   dam_loudness_block_energy (device): y = lfilter(high pass, lfilter(high shelf, x)) per channel in float64 and
+ *     z[ch][j] = sum_{n in [blk_lo[j], min(blk_hi[j], n_samples))} y[n]^2 / block_len  (the caller supplies the block
+ *     bounds exactly as the reference's int() truncations produce them; blk_lo/blk_hi/z are device pointers).
+ *     x: float32 or float64 (x_is_f64), sample n of channel ch at x[ch*channel_stride + n*sample_stride].
+ *     workspace: dam_loudness_workspace_bytes(n_samples, channels) bytes.
+ * The gating of the block energies (absolute -70 LUFS, relative -10 LU) is host logic (loudness.py).
+ * --------------------------------------------------------------------------------- */
+int dam_loudness_kweight_coeffs(double rate, double* coef12);
+int64_t dam_loudness_workspace_bytes(int64_t n_samples, int channels);
+int dam_loudness_block_energy(const void* x, int x_is_f64, int64_t n_samples, int channels, int64_t sample_stride,
+                              int64_t channel_stride, const double* coef12_host, const int64_t* blk_lo,
+                              const int64_t* blk_hi, int n_blocks, double block_len, double* z, void* workspace,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif
