@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
     PatchGeo pg;
     pg.H = g.H; pg.W = g.W; pg.C = g.C; pg.s = g.s; pg.c0 = g.c0; pg.PR = g.PR; pg.PWin = g.PWin; pg.PWs = g.PWs;
     pg.PWT = g.PWT; pg.in_nchw = g.in_nchw; pg.relu_in = g.relu_in;
+    const int lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4*>(Wp), 0, 0x7fffffff, 0x00020000);      // offsets are validated on the host (tap grid inside the packing)
     const int ngroups = g.nchunks / g.CG;
     const int cg_lo = ks * g.gps, cg_hi = cg_lo + g.gps < ngroups ? cg_lo + g.gps : ngroups;
     for (int cg = cg_lo; cg < cg_hi; ++cg) {
@@ -83,53 +86,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
         }
         __syncthreads();
 
-        // ---- MFMA over (tap a, tap b, chunk) items of the group, software-pipelined: the weights (global/L2)
-        //      and the LDS operands of item i+1 are requested before the MFMAs of item i issue ----
+        // ---- MFMA over (tap a, tap b, chunk) items of the group.  Three operand sets rotate: the weights (L2, ~1-2 us
+        //      under load, longer than the ~0.5 us of MFMAs of one item) and the LDS operands of item i+2 are requested
+        //      before the MFMAs of item i issue.  Loads are unconditional (the load pointer stops at the last item) so
+        //      that the compiler can count vmcnt; weights come through a buffer resource: scalar item offset + lane*16.
         {
             const int n_items = g.nA * g.nB * g.CG;
-            int ia = 0, ib = 0, ic = 0;
-            auto item_offsets = [&](int a, int b, int cc, int& lds_off, size_t& w_off) {
-                const int roff = g.off_h + a * g.step_h - g.r0;
-                const int coff = g.off_w + b * g.step_w - g.c0;
-                const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
-                lds_off = cc * chunk_bytes + (roff * g.PWT + slotoff) * 64;
-                const int tap = g.wt_base + a * g.wt_sa + b * g.wt_sb;
-                w_off = ((size_t)(tap * g.nchunks + cg * g.CG + cc) * g.NBtot + nb0) * 64 + lane;
-            };
-            float4 wa_n[NB], xv_n[MB];
-            {
-                int lo; size_t wo;
-                item_offsets(0, 0, 0, lo, wo);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wa_n[nb] = Wp[wo + nb * 64];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) xv_n[mb] = *reinterpret_cast<const float4*>(smem + base_b[mb] + lo);
+            float4 wa[3][NB], xv[3][MB];
+            int la = 0, lb = 0, lc = 0;                      // item the next ISSUE loads (scalar)
+#define DAM_TILE_ISSUE(S_)                                                                                                 \
+    do {                                                                                                                   \
+        const int roff_ = g.off_h + la * g.step_h - g.r0;                                                                  \
+        const int coff_ = g.off_w + lb * g.step_w - g.c0;                                                                  \
+        const int slotoff_ = g.s == 1 ? coff_ : (coff_ & 1) * g.PWs + (coff_ >> 1);                                        \
+        const int lo_ = lc * chunk_bytes + (roff_ * g.PWT + slotoff_) * 64;                                                \
+        const int tap_ = g.wt_base + la * g.wt_sa + lb * g.wt_sb;                                                          \
+        const int ws_ = ((tap_ * g.nchunks + cg * g.CG + lc) * g.NBtot + nb0) * 1024;                                      \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                  \
+            wa[S_][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + nb * 1024, ws_, 0)); \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                  \
+            xv[S_][mb] = *reinterpret_cast<const float4*>(smem + base_b[mb] + lo_);                                        \
+        if (!(la == g.nA - 1 && lb == g.nB - 1 && lc == g.CG - 1)) {                                                       \
+            if (++lc == g.CG) { lc = 0; if (++lb == g.nB) { lb = 0; ++la; } }                                              \
+        }                                                                                                                  \
+    } while (0)
+#define DAM_TILE_MFMA(S_)                                                                                                  \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                  \
+            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                            \
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[S_][nb].x, xv[S_][mb].x, acc[mb][nb], 0, 0, 0);      \
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[S_][nb].y, xv[S_][mb].y, acc[mb][nb], 0, 0, 0);      \
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[S_][nb].z, xv[S_][mb].z, acc[mb][nb], 0, 0, 0);      \
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[S_][nb].w, xv[S_][mb].w, acc[mb][nb], 0, 0, 0);      \
+            }                                                                                                              \
+    } while (0)
+            DAM_TILE_ISSUE(0);
+            DAM_TILE_ISSUE(1);
+            for (int it = 0; it < n_items; it += 3) {
+                DAM_TILE_ISSUE(2);
+                DAM_TILE_MFMA(0);
+                DAM_TILE_ISSUE(0);
+                if (it + 1 < n_items) DAM_TILE_MFMA(1);
+                DAM_TILE_ISSUE(1);
+                if (it + 2 < n_items) DAM_TILE_MFMA(2);
             }
-            for (int it = 0; it < n_items; ++it) {
-                float4 wa[NB], xv[MB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wa[nb] = wa_n[nb];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) xv[mb] = xv_n[mb];
-                if (++ic == g.CG) { ic = 0; if (++ib == g.nB) { ib = 0; ++ia; } }
-                if (it + 1 < n_items) {
-                    int lo; size_t wo;
-                    item_offsets(ia, ib, ic, lo, wo);
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) wa_n[nb] = Wp[wo + nb * 64];
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) xv_n[mb] = *reinterpret_cast<const float4*>(smem + base_b[mb] + lo);
-                }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].x, xv[mb].x, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].y, xv[mb].y, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].z, xv[mb].z, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nb].w, xv[mb].w, acc[mb][nb], 0, 0, 0);
-                    }
-            }
+#undef DAM_TILE_ISSUE
+#undef DAM_TILE_MFMA
         }
     }
 
