@@ -355,8 +355,16 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
                            k_chunks >= 4;
     bool split = can_split;
     if (split) {
-        for (int mb = 4; mb >= 2; mb >>= 1)              // enough workgroups without splitting: take the largest such tile
-            if (wgs(mb, NB) >= 400) { MB = mb; split = false; break; }
+        // enough workgroups without splitting: the tile with the smallest makespan.  Every CU works through
+        // ceil(workgroups / 256) tiles (co-resident workgroups share the matrix pipe, so it is the count that matters, not
+        // the residency), a tile costs its MFMAs (~ mb * NB) plus a fixed staging / weight-streaming part (~ 1 unit).
+        int64_t best = -1;
+        for (int mb = 4; mb >= 1; mb >>= 1) {
+            const int64_t w = wgs(mb, NB);
+            if (w < 400) continue;
+            const int64_t cost = cdiv(w, 256) * (mb * NB + 1);
+            if (best < 0 || cost < best) { best = cost; MB = mb; split = false; }
+        }
     }
     if (split) {
         int64_t best_pad = -1;
