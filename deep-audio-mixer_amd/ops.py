@@ -222,13 +222,16 @@ def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True):
     _lib.require_cuda(dy, x)
     C = x.shape[-1]
     dx = torch.empty_like(x)
-    dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    # two separate allocations: autograd takes ownership of a whole tensor it is handed as a .grad, but clones a view
+    # (30 extra device copies per ResNet18 step when these were rows of one [2, C] tensor)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = _bn_ws(x.device, C)
     _lib.check(_lib.lib().dam_bn_backward_f32(_lib.ptr(dy), _lib.ptr(y_mask), _lib.ptr(x), x.numel() // C, C, _lib.ptr(gamma),
                                               _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0, _lib.ptr(dx),
-                                              _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(ws), _lib.stream()),
+                                              _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.stream()),
                'dam_bn_backward_f32')
-    return dx, dgb[0], dgb[1]
+    return dx, dgamma, dbeta
 
 
 def channel_sum(x, n_real):

@@ -7,15 +7,16 @@ import numpy as np, torch
 import deep_audio_mixer_amd
 from deep_audio_mixer_amd import ops
 dev = torch.device('cuda', 0)
-B, H, W = 8, 1025, 130
-x = torch.randn((B, H, W, 16), device=dev)
-wp = ops.pack_weights(torch.randn((16, 16, 3, 3), device=dev) * 0.05)
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+B, H, W = {16: (8, 1025, 130), 32: (8, 513, 65), 64: (8, 257, 33)}[C]
+x = torch.randn((B, H, W, C), device=dev)
+wp = ops.pack_weights(torch.randn((C, C, 3, 3), device=dev) * 0.05)
 buf = torch.zeros(1024 * 16 * 3 * 4, dtype=torch.float32, device=dev)
 for _ in range(3):
-    y, parts = ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1, bn_partial=buf)
+    y, parts = ops.conv2d_fwd(x, wp, C, 3, 3, 1, 1, 1, bn_partial=buf)
 torch.cuda.synchronize()
 buf.zero_()
-y, parts = ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1, bn_partial=buf)
+y, parts = ops.conv2d_fwd(x, wp, C, 3, 3, 1, 1, 1, bn_partial=buf)
 torch.cuda.synchronize()
 st = buf.view(torch.int64).cpu().numpy().astype(np.uint64).reshape(-1, 2, 32)
 nwg = int((st[:, 0, 0] != 0).sum())
