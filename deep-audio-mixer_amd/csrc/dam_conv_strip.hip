@@ -330,6 +330,12 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         if (grp == 0) DAM_STRIP_GEOM(0);
     }
 
+    // residual / mask operands of the write-out (dgrad of a residual block): requested by the group right after its MFMAs,
+    // one slot before they are needed -- in the write-out slot the group's vector instructions only get to issue once the
+    // other group's MFMA stream has drained, and a load issued then would put its whole latency into the slot's tail
+    constexpr bool RES_PF = MB * NB <= 4;
+    v4f res_pf[RES_PF ? MB : 1][RES_PF ? NB : 1], msk_pf[RES_PF ? MB : 1][RES_PF ? NB : 1];
+
     for (int s = 0; grp < 2 && s < n_slots; ++s) {
         if (false) {
         } else if (grp == (s & 1)) {
@@ -447,6 +453,23 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                 }
             }
             }
+            if constexpr (RES_PF) {
+                if (res && s < n_tiles) {
+                    const int p0r = (t_begin + s) * TM + cw * MW;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int pm = p0r + mb * 16;
+                        const int oh_m = (int)__umulhi((unsigned)pm, sg.wo_magic), ow_m = pm - oh_m * g.Wo;
+                        const int voff = __builtin_amdgcn_readfirstlane(oh_m * oA + ow_m * oB) + (lane_o + wflag[mb] * oD);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {       // pixels past the image: out of the buffer's range, reads 0
+                            res_pf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
+                            if (res_mask)
+                                msk_pf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
+                        }
+                    }
+                }
+            }
             DAM_STAMP(5);
         } else {
             if (s >= 1 && s <= n_tiles) {
@@ -468,9 +491,13 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                     for (int nb = 0; nb < NB; ++nb) {
                         v4f v = acc[mb][nb] + bias4[nb];
                         if (res) {
-                            const v4f rv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
+                            v4f rv, mv;
+                            if constexpr (RES_PF) { rv = res_pf[mb][nb]; mv = msk_pf[mb][nb]; }
+                            else {
+                                rv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
+                                if (res_mask) mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
+                            }
                             if (res_mask) {
-                                const v4f mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
                                 v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;
                                 v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;
                             } else {
