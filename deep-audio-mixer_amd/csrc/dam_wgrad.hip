@@ -167,40 +167,55 @@ template <int SL>       // split lanes: 32 for many slabs (row kernel: one per w
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGeo g, int TNB, int TKB, int TA, int TB, int n_real,
                                                            int k_real, const float* __restrict__ partial,
                                                            float* __restrict__ dw, int nx) {
-    constexpr int EL = 256 / SL;
-    __shared__ float sub[SL][EL];
+    constexpr int EL = 256 / SL;         // threads along the element axis, one float4 (= the 4 out-channels r of one lane) each
+    __shared__ float4 sub[SL][EL];
     const int nblk_tile = TNB * TKB * TA * TB;
-    const int64_t per_split = (int64_t)nx * nblk_tile * 256;
+    const int64_t per_split4 = (int64_t)nx * nblk_tile * 64;       // float4 per slab
+    const float4* p4 = reinterpret_cast<const float4*>(partial);
     const int el = threadIdx.x % EL, ys = threadIdx.x / EL;
-    for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < per_split; e0 += (int64_t)gridDim.x * EL) {
+    for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < per_split4; e0 += (int64_t)gridDim.x * EL) {
         const int64_t e = e0 + el;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int y = ys;
-        for (; y + 3 * SL < g.nsplit; y += 4 * SL) {
-            s0 += partial[y * per_split + e]; s1 += partial[(y + SL) * per_split + e];
-            s2 += partial[(y + 2 * SL) * per_split + e]; s3 += partial[(y + 3 * SL) * per_split + e];
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        if (e < per_split4) {
+            int y = ys;
+            for (; y + 3 * SL < g.nsplit; y += 4 * SL) {
+                const float4 a = p4[y * per_split4 + e], b = p4[(y + SL) * per_split4 + e];
+                const float4 c = p4[(y + 2 * SL) * per_split4 + e], d = p4[(y + 3 * SL) * per_split4 + e];
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+                s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w; s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+            }
+            for (; y < g.nsplit; y += SL) { const float4 a = p4[y * per_split4 + e]; s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
         }
-        for (; y < g.nsplit; y += SL) s0 += partial[y * per_split + e];
-        sub[ys][el] = (s0 + s1) + (s2 + s3);
+        sub[ys][el] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                                  (s0.w + s1.w) + (s2.w + s3.w));
         __syncthreads();
 #pragma unroll
         for (int stride = SL / 2; stride >= 1; stride >>= 1) {
-            if (ys < stride) sub[ys][el] += sub[ys + stride][el];
+            if (ys < stride) {
+                float4 a = sub[ys][el];
+                const float4 b = sub[ys + stride][el];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                sub[ys][el] = a;
+            }
             __syncthreads();
         }
-        if (ys == 0) {
-            const float s = sub[0][el];
-            const int r = e & 3, lane = (e >> 2) & 63;
-            int64_t q = e >> 8;
+        if (ys == 0 && e < per_split4) {
+            const float4 s = sub[0][el];
+            const float sv[4] = {s.x, s.y, s.z, s.w};
+            const int lane = e & 63;
+            int64_t q = e >> 6;
             const int blk = q % nblk_tile;
             int xt = q / nblk_tile;
             const int tb = blk % TB, ta = (blk / TB) % TA, kb = (blk / (TB * TA)) % TKB, nb = blk / (TB * TA * TKB);
             const int tg = xt % g.tap_groups; xt /= g.tap_groups;
             const int tk = xt % g.tiles_k, tn = xt / g.tiles_k;
-            const int n = (tn * TNB + nb) * 16 + (lane >> 4) * 4 + r;
             const int k = (tk * TKB + kb) * 16 + (lane & 15);
             const int kh = tg * TA + ta;
-            if (n < n_real && k < k_real && kh < g.KH) dw[(((size_t)n * k_real + k) * g.KH + kh) * g.KW + tb] = s;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = (tn * TNB + nb) * 16 + (lane >> 4) * 4 + r;
+                if (n < n_real && k < k_real && kh < g.KH) dw[(((size_t)n * k_real + k) * g.KH + kh) * g.KW + tb] = sv[r];
+            }
         }
         __syncthreads();
     }
@@ -471,10 +486,10 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     rg.tap_groups = 1; rg.tiles_k = g.tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = 3; rg.KW = 3;
     const int64_t per_split = (int64_t)nx * NBLK * 256;
     if (nsplit >= 64) {
-        const int rb = (int)(cdiv(per_split, 8) < 4096 ? cdiv(per_split, 8) : 4096);
+        const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, C, partial, dw, nx);
     } else {
-        const int rb = (int)(cdiv(per_split, 32) < 2048 ? cdiv(per_split, 32) : 2048);
+        const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
         hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, C, partial, dw, nx);
     }
     DAM_CHECK_LAUNCH();
@@ -511,10 +526,10 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
     DAM_CHECK_LAUNCH();
     const int64_t per_split = (int64_t)nx * NBLK * 256;
     if (g.nsplit >= 64) {
-        const int rb = (int)(cdiv(per_split, 8) < 4096 ? cdiv(per_split, 8) : 4096);
+        const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, g, TNB, TKB, TA, TB, n_real, k_real, partial, dw, nx);
     } else {
-        const int rb = (int)(cdiv(per_split, 32) < 2048 ? cdiv(per_split, 32) : 2048);
+        const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
         hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, g, TNB, TKB, TA, TB, n_real, k_real, partial, dw, nx);
     }
     DAM_CHECK_LAUNCH();
