@@ -49,6 +49,7 @@ SIGNATURES = {
     'dam_gain_ramp_apply': (c_i, [c_p, c_p, c_i, c_i64, c_i64, c_i, c_p, c_p]),
     'dam_mixdown_workspace_elems': (c_i64, [c_i64]),
     'dam_mixdown_peak_normalize': (c_i, [c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    'dam_nchw_to_nhwc16_f32': (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p]),
     'dam_loudness_kweight_coeffs': (c_i, [c_d, c_p]),
     'dam_loudness_workspace_bytes': (c_i64, [c_i64, c_i]),
     'dam_loudness_block_energy': (c_i, [c_p, c_i, c_i64, c_i, c_i64, c_i64, c_p, c_p, c_p, c_i, c_d, c_p, c_p, c_p]),

@@ -19,6 +19,12 @@ class ConvSpec:
     def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, in_nchw=False):
         self.cin, self.cout, self.k, self.stride, self.pad, self.dil, self.in_nchw = cin, cout, k, stride, pad, dil, in_nchw
         self.wp = self.wpt = None      # packed images kept fresh by a WeightPacker (one launch per forward), if any
+        # 3x3 / stride 1 / pad 1 over <= 16 NCHW planes (the ResNet stem): the input is re-laid once as NHWC with 16
+        # zero-padded channels and the layer runs the strip / row-streaming kernels of layer1 (the packed weight image of an
+        # NCHW layer already is one 16-channel chunk with zero rows, so it is shared)
+        self.nhwc16 = None
+        if in_nchw and k == 3 and stride == 1 and pad == 1 and dil == 1 and cin <= 16:
+            self.nhwc16 = _Nhwc16Spec(self)
 
     def packed(self, w, transpose=False):
         cached = self.wpt if transpose else self.wp
@@ -55,6 +61,24 @@ class ConvSpec:
     def dgrad(self, dy, w, hw, **kw):
         return ops.conv2d_dgrad(dy, self.packed(w, transpose=True), self.cin, hw[0], hw[1], self.k, self.k,
                                 self.stride, self.pad, self.dil, **kw)
+
+
+class _Nhwc16Spec(ConvSpec):
+    """The same convolution seen over the re-laid NHWC-16 input (see ConvSpec.__init__)."""
+
+    def __init__(self, parent):
+        self.cin, self.cout, self.k, self.stride, self.pad, self.dil, self.in_nchw = 16, parent.cout, 3, 1, 1, 1, False
+        self.parent, self.nhwc16, self.wpt = parent, None, None
+
+    @property
+    def wp(self):
+        return self.parent.wp
+
+    def packed(self, w, transpose=False):
+        return self.parent.packed(w, transpose)
+
+    def wgrad(self, x, dy):
+        return ConvSpec.wgrad(self, x, dy)[:, :self.parent.cin].contiguous()
 
 
 class WeightPacker:
@@ -110,6 +134,8 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, gamma, beta, spec, bn, training):
+        if spec.nhwc16 is not None and not ctx.needs_input_grad[0]:
+            spec, x = spec.nhwc16, ops.nchw_to_nhwc16(x)
         c, mean, invstd, scale, shift = spec.fwd_bn(x, w.detach(), bn, training, None if bias is None else bias.detach())
         a = ops.bn_apply(c, scale, shift, relu=True)
         ctx.save_for_backward(x, w, c, a, gamma, mean, invstd)

@@ -162,6 +162,16 @@ def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in
     return out
 
 
+def nchw_to_nhwc16(x):
+    """[B,C,H,W] float32 (C <= 16) -> NHWC [B,H,W,16], channels C..15 zero."""
+    _lib.require_cuda(x)
+    _f32c(x, 'x')
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, 16), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().dam_nchw_to_nhwc16_f32(_lib.ptr(x), B, C, H * W, _lib.ptr(y), _lib.stream()), 'dam_nchw_to_nhwc16_f32')
+    return y
+
+
 # ----------------------------------------------------------------------------- batch norm
 def _bn_ws(device, C):
     return _workspace(device, _lib.lib().dam_bn_workspace_floats(C))

@@ -246,6 +246,12 @@ int dam_loudness_block_energy(const void* x, int x_is_f64, int64_t n_samples, in
                               const int64_t* blk_hi, int n_blocks, double block_len, double* z, void* workspace,
                               void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Stem input layout: x [B][C][HW] (C <= 16 planes, the reference's [B,S,F,T] feature stack) -> y [B][HW][16] with
+ * channels C..15 zero, so that the first convolution (models/model_resnet.py:64,97) runs the NHWC kernels.
+ * --------------------------------------------------------------------------------- */
+int dam_nchw_to_nhwc16_f32(const float* x, int B, int C, int64_t HW, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,6 +147,25 @@ def test_wgrad_row_streaming_shapes(ops, B, C, H, W):
     close(got, want, 5e-5)
 
 
+def test_stem_relayout_and_nhwc16_path(ops):
+    """NCHW stem input re-laid as NHWC-16 (zero channels), and the stem convolution / weight gradient through it."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 8, 37, 130, generator=g)
+    y = ops.nchw_to_nhwc16(x.cuda()).cpu()
+    assert y.shape == (2, 37, 130, 16)
+    assert torch.equal(y[..., :8], x.permute(0, 2, 3, 1)) and torch.count_nonzero(y[..., 8:]) == 0
+    from deep_audio_mixer_amd.layers import ConvSpec
+    spec = ConvSpec(8, 16, 3, 1, 1, in_nchw=True)
+    assert spec.nhwc16 is not None
+    w = torch.randn(16, 8, 3, 3, generator=g) / 9
+    c = spec.nhwc16.fwd(ops.nchw_to_nhwc16(x.cuda()), w.cuda())
+    close(nchw(c), F.conv2d(x.double(), w.double(), None, 1, 1))
+    dy = torch.randn(2, 16, 37, 130, generator=g)
+    dw = spec.nhwc16.wgrad(ops.nchw_to_nhwc16(x.cuda()), nhwc(dy).cuda())
+    assert dw.shape == (16, 8, 3, 3)
+    close(dw, torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, 1), 5e-5)
+
+
 def test_fused_bn_statistics_epilogue(ops):
     """The strip kernel's BatchNorm partial records, merged by dam_bn_finalize_f32, equal the two-pass statistics of the
     conv output (mean far from zero on purpose: dB-valued activations)."""
