@@ -496,6 +496,99 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     return DAM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions (the strided shortcut of a down-sampling block, models/model_resnet.py:18-21): dW[n][k] = sum over
+// output pixels of dY[p][n] * X[s*p][k] -- a skinny GEMM with no operand reuse across taps, so nothing goes through LDS:
+// a wave walks whole output rows, both MFMA operands are buffer loads straight from HBM (lane = (pixel 4t + kq, channel
+// j); addresses are linear in t, lanes past the row end get an out-of-range offset and read 0).  Memory-bound: 8 steps
+// (32 pixels) of loads are in flight per wave.  Output: the same slabs + reduce kernel as the other variants.
+template <int TNB, int TKB>
+__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict__ X, const float* __restrict__ dY, int rows,
+                                                        int Ho, int Wo, int H, int W, int C, int N, int s, int tiles_k,
+                                                        float* __restrict__ partial) {
+    __shared__ float4 red[TNB * TKB * 64];
+    constexpr int NBLK = TNB * TKB, U = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY), 0, 0x7fffffff, 0x00020000);
+    v4f acc[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const int steps = (Wo + 3) >> 2;
+    const int lane_x = (kq * s * C + tk * TKB * 16 + j) * 4, lane_d = (kq * N + tn * TNB * 16 + j) * 4;   // bytes
+    const int step_x = 4 * s * C * 4, step_d = 4 * N * 4;
+    for (int row = blockIdx.y * 4 + wave; row < rows; row += gridDim.y * 4) {        // row = (image, output row)
+        const int img = row / Ho, oh = row - img * Ho;
+        const int xs = (int)(((int64_t)(img * H + oh * s) * W) * C * 4);             // scalar byte offsets (< 2^31: host check)
+        const int ds = (int)(((int64_t)row * Wo) * N * 4);
+        for (int t0 = 0; t0 < steps; t0 += U) {
+            float a[U][TNB], b[U][TKB];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u;
+                const bool ok = t < steps && 4 * t + kq < Wo;
+                const int vx = ok ? lane_x + t * step_x : 0x7fffffff, vd = ok ? lane_d + t * step_d : 0x7fffffff;
+#pragma unroll
+                for (int nb = 0; nb < TNB; ++nb) a[u][nb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, vd + nb * 64, ds, 0));
+#pragma unroll
+                for (int kb = 0; kb < TKB; ++kb) b[u][kb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vx + kb * 64, xs, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int nb = 0; nb < TNB; ++nb)
+#pragma unroll
+                    for (int kb = 0; kb < TKB; ++kb)
+                        acc[nb * TKB + kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][nb], b[u][kb], acc[nb * TKB + kb], 0, 0, 0);
+        }
+    }
+    for (int w = 0; w < 4; ++w) {            // combine the 4 waves in fixed order
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) {
+                float4 o = w == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : red[i * 64 + lane];
+                o.x += acc[i].x; o.y += acc[i].y; o.z += acc[i].z; o.w += acc[i].w;
+                red[i * 64 + lane] = o;
+            }
+        }
+        __syncthreads();
+    }
+    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NBLK * 64;
+    for (int e = tid; e < NBLK * 64; e += 256) out[e] = red[e];
+}
+
+template <int TNB, int TKB>
+int launch_wgrad_1x1(int B, int H, int W, int C, int Ho, int Wo, int N, int s, const float* X, const float* dY, float* partial,
+                     int64_t ws_floats, float* dw, int n_real, hipStream_t st) {
+    constexpr int NBLK = TNB * TKB;
+    const int nblk = N / 16, nch = C / 16;
+    if (nblk % TNB || nch % TKB) return DAM_ERR_UNSUPPORTED;
+    if ((int64_t)B * H * W * C * 4 >= (1ll << 31) || (int64_t)B * Ho * Wo * N * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;
+    const int tiles_n = nblk / TNB, tiles_k = nch / TKB, nx = tiles_n * tiles_k;
+    const int rows = B * Ho;
+    int nsplit = (int)cdiv(1024, nx);                     // ~4 workgroups per CU: the kernel lives on loads in flight
+    if (nsplit > (int)cdiv(rows, 4)) nsplit = (int)cdiv(rows, 4);
+    while (nsplit > 1 && (int64_t)nsplit * nx * NBLK * 256 > ws_floats) --nsplit;
+    if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
+    hipLaunchKernelGGL((wgrad_1x1_kernel<TNB, TKB>), dim3(nx, nsplit), dim3(256), 0, st, X, dY, rows, Ho, Wo, H, W, C, N, s,
+                       tiles_k, partial);
+    DAM_CHECK_LAUNCH();
+    WgradGeo rg = {};
+    rg.tap_groups = 1; rg.tiles_k = tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = 1; rg.KW = 1;
+    const int64_t per_split = (int64_t)nx * NBLK * 256;
+    if (nsplit >= 64) {
+        const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 1, 1, n_real, C, partial, dw, nx);
+    } else {
+        const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 1, 1, n_real, C, partial, dw, nx);
+    }
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
 template <int TNB, int TKB, int TA, int TB>
 int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, const float* sh, float* partial,
                  int64_t ws_floats, float* dw, int n_real, int k_real, hipStream_t st) {
@@ -563,6 +656,14 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
         if (C == 16) rc = launch_wgrad_rows<1, 1, 33, 1, 9>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
         else if (W > 48) rc = launch_wgrad_rows<2, 1, 17, 2, 5>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
         else rc = launch_wgrad_rows<2, 1, 9, 2, 3>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
+        if (rc != DAM_ERR_UNSUPPORTED) return rc;
+    }
+    if (kh == 1 && kw == 1 && pad == 0 && !in_nchw && !in_scale) {
+        int rc = launch_wgrad_1x1<2, 2>(B, H, W, C, Ho, Wo, n_chan, stride, x, dy, workspace, workspace_floats, dw, n_out, st);
+        if (rc == DAM_ERR_UNSUPPORTED)
+            rc = launch_wgrad_1x1<2, 1>(B, H, W, C, Ho, Wo, n_chan, stride, x, dy, workspace, workspace_floats, dw, n_out, st);
+        if (rc == DAM_ERR_UNSUPPORTED)
+            rc = launch_wgrad_1x1<1, 1>(B, H, W, C, Ho, Wo, n_chan, stride, x, dy, workspace, workspace_floats, dw, n_out, st);
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
     WgradGeo g;
