@@ -497,17 +497,20 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 1x1 convolutions (the strided shortcut of a down-sampling block, models/model_resnet.py:18-21): dW[n][k] = sum over
-// output pixels of dY[p][n] * X[s*p][k] -- a skinny GEMM with no operand reuse across taps, so nothing goes through LDS:
-// a wave walks whole output rows, both MFMA operands are buffer loads straight from HBM (lane = (pixel 4t + kq, channel
-// j); addresses are linear in t, lanes past the row end get an out-of-range offset and read 0).  Memory-bound: 8 steps
-// (32 pixels) of loads are in flight per wave.  Output: the same slabs + reduce kernel as the other variants.
-template <int TNB, int TKB>
-__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict__ X, const float* __restrict__ dY, int rows,
-                                                        int Ho, int Wo, int H, int W, int C, int N, int s, int tiles_k,
-                                                        float* __restrict__ partial) {
-    __shared__ float4 red[TNB * TKB * 64];
-    constexpr int NBLK = TNB * TKB, U = 8;
+// Direct variant: nothing goes through LDS.  dW[n][k][a][b] = sum over output pixels of dY[p][n] * X[s*p + tap][k]; a
+// wave walks whole output rows, lane = (pixel 4t + kq, channel j), both MFMA operands are buffer loads (dword per lane,
+// 64-byte segments) straight from HBM / L2 -- every X element is wanted by at most KH*KW/s^2 taps and those re-reads are
+// L2 hits.  Addresses are linear in t; lanes past the row end or on a padding column get an out-of-range offset and read
+// 0; a tap row outside the image is skipped (scalar branch).  U steps of loads are in flight per wave.
+//   1x1: the strided shortcut of a down-sampling block (models/model_resnet.py:18-21) -- a skinny memory-bound GEMM;
+//   3x3: the strided first convolution of those blocks (a staged patch would hold both column parities of every row).
+// Output: the same partial slabs + reduce kernel as the other variants.
+template <int TNB, int TKB, int KH, int KW>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restrict__ X, const float* __restrict__ dY, int rows,
+                                                           int Ho, int Wo, int H, int W, int C, int N, int s, int pad, int dil,
+                                                           int tiles_k, float* __restrict__ partial) {
+    constexpr int NBLK = TNB * TKB * KH * KW, U = KH * KW == 1 ? 8 : 4;
+    __shared__ float4 red[NBLK * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
@@ -521,27 +524,48 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
     const int step_x = 4 * s * C * 4, step_d = 4 * N * 4;
     for (int row = blockIdx.y * 4 + wave; row < rows; row += gridDim.y * 4) {        // row = (image, output row)
         const int img = row / Ho, oh = row - img * Ho;
-        const int xs = (int)(((int64_t)(img * H + oh * s) * W) * C * 4);             // scalar byte offsets (< 2^31: host check)
-        const int ds = (int)(((int64_t)row * Wo) * N * 4);
+        const int ds = (int)(((int64_t)row * Wo) * N * 4);                           // scalar byte offsets (< 2^31: host check)
         for (int t0 = 0; t0 < steps; t0 += U) {
-            float a[U][TNB], b[U][TKB];
+            float av[U][TNB];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + u;
-                const bool ok = t < steps && 4 * t + kq < Wo;
-                const int vx = ok ? lane_x + t * step_x : 0x7fffffff, vd = ok ? lane_d + t * step_d : 0x7fffffff;
-#pragma unroll
-                for (int nb = 0; nb < TNB; ++nb) a[u][nb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, vd + nb * 64, ds, 0));
-#pragma unroll
-                for (int kb = 0; kb < TKB; ++kb) b[u][kb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vx + kb * 64, xs, 0));
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+                const int vd = (t < steps && 4 * t + kq < Wo) ? lane_d + t * step_d : 0x7fffffff;
 #pragma unroll
                 for (int nb = 0; nb < TNB; ++nb)
+                    av[u][nb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, vd + nb * 64, ds, 0));
+            }
 #pragma unroll
-                    for (int kb = 0; kb < TKB; ++kb)
-                        acc[nb * TKB + kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][nb], b[u][kb], acc[nb * TKB + kb], 0, 0, 0);
+            for (int a = 0; a < KH; ++a) {
+                const int ih = oh * s + a * dil - pad;
+                if (ih < 0 || ih >= H) continue;                                     // wave-uniform
+                const int xs = (int)(((int64_t)(img * H + ih) * W) * C * 4);
+                float bv[U][KW][TKB];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u;
+#pragma unroll
+                    for (int b = 0; b < KW; ++b) {
+                        const int iw = (4 * t + kq) * s + b * dil - pad;
+                        const int vx = (t < steps && 4 * t + kq < Wo && iw >= 0 && iw < W) ? lane_x + t * step_x + (b * dil - pad) * C * 4
+                                                                                         : 0x7fffffff;
+#pragma unroll
+                        for (int kb = 0; kb < TKB; ++kb)
+                            bv[u][b][kb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vx + kb * 64, xs, 0));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int nb = 0; nb < TNB; ++nb)
+#pragma unroll
+                        for (int kb = 0; kb < TKB; ++kb)
+#pragma unroll
+                            for (int b = 0; b < KW; ++b) {
+                                const int idx = ((nb * TKB + kb) * KH + a) * KW + b;
+                                acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][nb], bv[u][b][kb], acc[idx], 0, 0, 0);
+                            }
+            }
         }
     }
     for (int w = 0; w < 4; ++w) {            // combine the 4 waves in fixed order
@@ -559,31 +583,31 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
     for (int e = tid; e < NBLK * 64; e += 256) out[e] = red[e];
 }
 
-template <int TNB, int TKB>
-int launch_wgrad_1x1(int B, int H, int W, int C, int Ho, int Wo, int N, int s, const float* X, const float* dY, float* partial,
-                     int64_t ws_floats, float* dw, int n_real, hipStream_t st) {
-    constexpr int NBLK = TNB * TKB;
+template <int TNB, int TKB, int KH, int KW>
+int launch_wgrad_direct(int B, int H, int W, int C, int Ho, int Wo, int N, int s, int pad, int dil, const float* X,
+                        const float* dY, float* partial, int64_t ws_floats, float* dw, int n_real, hipStream_t st) {
+    constexpr int NBLK = TNB * TKB * KH * KW;
     const int nblk = N / 16, nch = C / 16;
     if (nblk % TNB || nch % TKB) return DAM_ERR_UNSUPPORTED;
     if ((int64_t)B * H * W * C * 4 >= (1ll << 31) || (int64_t)B * Ho * Wo * N * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;
     const int tiles_n = nblk / TNB, tiles_k = nch / TKB, nx = tiles_n * tiles_k;
     const int rows = B * Ho;
-    int nsplit = (int)cdiv(1024, nx);                     // ~4 workgroups per CU: the kernel lives on loads in flight
+    int nsplit = (int)cdiv(KH * KW == 1 ? 1024 : 768, nx);      // 3-4 workgroups per CU: the kernel lives on loads in flight
     if (nsplit > (int)cdiv(rows, 4)) nsplit = (int)cdiv(rows, 4);
     while (nsplit > 1 && (int64_t)nsplit * nx * NBLK * 256 > ws_floats) --nsplit;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
-    hipLaunchKernelGGL((wgrad_1x1_kernel<TNB, TKB>), dim3(nx, nsplit), dim3(256), 0, st, X, dY, rows, Ho, Wo, H, W, C, N, s,
-                       tiles_k, partial);
+    hipLaunchKernelGGL((wgrad_direct_kernel<TNB, TKB, KH, KW>), dim3(nx, nsplit), dim3(256), 0, st, X, dY, rows, Ho, Wo, H, W, C,
+                       N, s, pad, dil, tiles_k, partial);
     DAM_CHECK_LAUNCH();
     WgradGeo rg = {};
-    rg.tap_groups = 1; rg.tiles_k = tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = 1; rg.KW = 1;
+    rg.tap_groups = 1; rg.tiles_k = tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = KH; rg.KW = KW;
     const int64_t per_split = (int64_t)nx * NBLK * 256;
     if (nsplit >= 64) {
         const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 1, 1, n_real, C, partial, dw, nx);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, KH, KW, n_real, C, partial, dw, nx);
     } else {
         const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 1, 1, n_real, C, partial, dw, nx);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, KH, KW, n_real, C, partial, dw, nx);
     }
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -658,14 +682,22 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
         else rc = launch_wgrad_rows<2, 1, 9, 2, 3>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
+#define DAM_WGD(TN_, TK_, KH_, KW_) \
+    launch_wgrad_direct<TN_, TK_, KH_, KW_>(B, H, W, C, Ho, Wo, n_chan, stride, pad, dil, x, dy, workspace, workspace_floats, dw, n_out, st)
     if (kh == 1 && kw == 1 && pad == 0 && !in_nchw && !in_scale) {
-        int rc = launch_wgrad_1x1<2, 2>(B, H, W, C, Ho, Wo, n_chan, stride, x, dy, workspace, workspace_floats, dw, n_out, st);
-        if (rc == DAM_ERR_UNSUPPORTED)
-            rc = launch_wgrad_1x1<2, 1>(B, H, W, C, Ho, Wo, n_chan, stride, x, dy, workspace, workspace_floats, dw, n_out, st);
-        if (rc == DAM_ERR_UNSUPPORTED)
-            rc = launch_wgrad_1x1<1, 1>(B, H, W, C, Ho, Wo, n_chan, stride, x, dy, workspace, workspace_floats, dw, n_out, st);
+        int rc = DAM_WGD(2, 2, 1, 1);
+        if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGD(2, 1, 1, 1);
+        if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGD(1, 1, 1, 1);
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
+    // strided 3x3 (the first convolution of a down-sampling block): measured 61/62/58 us against 80/78/67 us for the tile
+    // kernel; for stride-1 narrow rows (17 pixels, 96 channels) it is slower (117 vs 60 us: nine L2 reads per element)
+    if (kh == 3 && kw == 3 && !in_nchw && !in_scale && Wo >= 16 && stride == 2) {
+        int rc = DAM_WGD(2, 1, 3, 3);
+        if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGD(1, 1, 3, 3);
+        if (rc != DAM_ERR_UNSUPPORTED) return rc;
+    }
+#undef DAM_WGD
     WgradGeo g;
     g.B = B; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.N = n_chan; g.s = stride; g.KH = kh; g.KW = kw;
     g.off_h = -pad; g.step_h = dil; g.off_w = -pad; g.step_w = dil;

@@ -147,6 +147,21 @@ def test_wgrad_row_streaming_shapes(ops, B, C, H, W):
     close(got, want, 5e-5)
 
 
+@pytest.mark.parametrize('B,Ci,Co,H,W,k,s,p', [(2, 16, 32, 41, 65, 3, 2, 1), (1, 32, 64, 33, 34, 3, 2, 1), (2, 96, 96, 9, 17, 3, 1, 1),
+                                              (2, 16, 32, 41, 65, 1, 2, 0), (1, 64, 96, 21, 33, 1, 2, 0), (1, 48, 48, 20, 30, 3, 1, 1)])
+def test_wgrad_direct_kernel_shapes(ops, B, Ci, Co, H, W, k, s, p):
+    """Weight gradient without LDS staging: strided 3x3, narrow-row 3x3 and 1x1 shortcut shapes (ragged row ends, padding
+    columns and rows, odd channel-block counts)."""
+    g = torch.Generator().manual_seed(Ci + Co + H + W + k)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(B, Co, Ho, Wo, generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, k, k), dy.double(), s, p)
+    got = ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), Co, k, k, s, p, 1)
+    assert got.shape == (Co, Ci, k, k)
+    close(got, want, 5e-5)
+
+
 def test_stem_relayout_and_nhwc16_path(ops):
     """NCHW stem input re-laid as NHWC-16 (zero channels), and the stem convolution / weight gradient through it."""
     g = torch.Generator().manual_seed(11)
