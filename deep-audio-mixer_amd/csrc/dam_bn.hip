@@ -191,14 +191,20 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t nquads, int
 }
 
 // partial[blk][c] = (sum dz, sum dz*xhat)
+// MASK: 0 none, 1 from y_mask (saved output), 2 recomputed as fma(x, mscale, mshift) > 0 -- the forward's own expression, so
+// the bits agree and the saved activation is not read at all
+template <int MASK>
 __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y_mask,
                                       const float* __restrict__ x, int64_t P, int C, int Q, int R, int64_t ppb,
                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      const float* __restrict__ mscale, const float* __restrict__ mshift,
                                       float* __restrict__ partial /* [parts][C][2] */) {
     extern __shared__ float sm[];    // [R][C][2]
     const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
     const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
     const float4 mu = reinterpret_cast<const float4*>(mean)[cq], is = reinterpret_cast<const float4*>(invstd)[cq];
+    float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
+    if (MASK == 2) { msc = reinterpret_cast<const float4*>(mscale)[cq]; msh = reinterpret_cast<const float4*>(mshift)[cq]; }
     float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     constexpr int U = 4;      // 3 streams x 4 loads in flight per thread
     for (int64_t p = lo + pr; p < hi; p += (int64_t)R * U) {
@@ -210,12 +216,14 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float*
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             gv[u] = ok ? *reinterpret_cast<const float4*>(dy + q * C + cq * 4) : z;
             xv[u] = ok ? *reinterpret_cast<const float4*>(x + q * C + cq * 4) : z;
-            mv[u] = (ok && y_mask) ? *reinterpret_cast<const float4*>(y_mask + q * C + cq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+            mv[u] = (ok && MASK == 1) ? *reinterpret_cast<const float4*>(y_mask + q * C + cq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float4 g = gv[u];
-            const float4 m = mv[u], v = xv[u];
+            const float4 v = xv[u];
+            float4 m = mv[u];
+            if (MASK == 2) m = make_float4(fmaf(v.x, msc.x, msh.x), fmaf(v.y, msc.y, msh.y), fmaf(v.z, msc.z, msh.z), fmaf(v.w, msc.w, msh.w));
             g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
             a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
             b[0] = fmaf(g.x, (v.x - mu.x) * is.x, b[0]); b[1] = fmaf(g.y, (v.y - mu.y) * is.y, b[1]);
@@ -279,17 +287,25 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
     coef[c] = (float)g; coef[C + c] = (float)c2; coef[2 * C + c] = (float)c3;
 }
 
+template <int MASK>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y_mask,
                                     const float* __restrict__ x, int64_t nquads, int Q, int C,
-                                    const float* __restrict__ coef, float* __restrict__ dx) {
+                                    const float* __restrict__ coef, const float* __restrict__ mscale,
+                                    const float* __restrict__ mshift, float* __restrict__ dx) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nquads; e += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(e % Q);
         float4 g = reinterpret_cast<const float4*>(dy)[e];
-        if (y_mask) {
-            const float4 m = reinterpret_cast<const float4*>(y_mask)[e];
+        const float4 v = reinterpret_cast<const float4*>(x)[e];
+        if (MASK != 0) {
+            float4 m;
+            if (MASK == 1) {
+                m = reinterpret_cast<const float4*>(y_mask)[e];
+            } else {
+                const float4 sc = reinterpret_cast<const float4*>(mscale)[cq], sh = reinterpret_cast<const float4*>(mshift)[cq];
+                m = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+            }
             g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
         }
-        const float4 v = reinterpret_cast<const float4*>(x)[e];
         const float4 c1 = reinterpret_cast<const float4*>(coef)[cq], c2 = reinterpret_cast<const float4*>(coef + C)[cq],
                      c3 = reinterpret_cast<const float4*>(coef + 2 * C)[cq];
         float4 o;
@@ -413,21 +429,31 @@ extern "C" int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const f
 
 extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
                                    const float* gamma, const float* save_mean, const float* save_invstd, int training,
-                                   float* dx, float* dgamma, float* dbeta, float* workspace, void* stream) {
+                                   const float* mask_scale, const float* mask_shift, float* dx, float* dgamma, float* dbeta,
+                                   float* workspace, void* stream) {
     if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || n_pixels <= 0)
         return DAM_ERR_BAD_ARG;
+    if ((mask_scale != nullptr) != (mask_shift != nullptr) || (y_mask && mask_scale)) return DAM_ERR_BAD_ARG;
     if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
     const BnLaunch l = bn_plan(n_pixels, C);
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + (size_t)BN_MAX_PARTS * C * 2;    // workspace holds [parts][C][2] then [3][C]
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 2 * sizeof(float), st, dy,
-                       y_mask, x, n_pixels, C, l.q, l.r, l.ppb, save_mean, save_invstd, workspace);
+    const int mask = y_mask ? 1 : (mask_scale ? 2 : 0);
+#define DAM_BN_PARTIAL(M_)                                                                                                   \
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<M_>, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 2 * sizeof(float), st, dy, \
+                       y_mask, x, n_pixels, C, l.q, l.r, l.ppb, save_mean, save_invstd, mask_scale, mask_shift, workspace)
+    if (mask == 1) DAM_BN_PARTIAL(1); else if (mask == 2) DAM_BN_PARTIAL(2); else DAM_BN_PARTIAL(0);
+#undef DAM_BN_PARTIAL
     DAM_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
                        (double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef);
     DAM_CHECK_LAUNCH();
     const int64_t nq = n_pixels * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elt_blocks(nq)), dim3(256), 0, st, dy, y_mask, x, nq, C / 4, C, coef, dx);
+#define DAM_BN_APPLY(M_)                                                                                                     \
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<M_>, dim3(elt_blocks(nq)), dim3(256), 0, st, dy, y_mask, x, nq, C / 4, C, coef,   \
+                       mask_scale, mask_shift, dx)
+    if (mask == 1) DAM_BN_APPLY(1); else if (mask == 2) DAM_BN_APPLY(2); else DAM_BN_APPLY(0);
+#undef DAM_BN_APPLY
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }

@@ -138,15 +138,17 @@ class ConvBnReluFn(torch.autograd.Function):
             spec, x = spec.nhwc16, ops.nchw_to_nhwc16(x)
         c, mean, invstd, scale, shift = spec.fwd_bn(x, w.detach(), bn, training, None if bias is None else bias.detach())
         a = ops.bn_apply(c, scale, shift, relu=True)
-        ctx.save_for_backward(x, w, c, a, gamma, mean, invstd)
+        ctx.save_for_backward(x, w, c, gamma, mean, invstd, scale, shift)
         ctx.spec, ctx.training, ctx.has_bias = spec, training, bias is not None
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x, w, c, a, gamma, mean, invstd = ctx.saved_tensors
+        x, w, c, gamma, mean, invstd, scale, shift = ctx.saved_tensors
         spec = ctx.spec
-        dc, dgamma, dbeta = ops.bn_backward(da.contiguous(), a, c, gamma, mean, invstd, ctx.training)
+        # relu mask recomputed from c and the forward's affine: the saved activation is not read (nor kept by this node)
+        dc, dgamma, dbeta = ops.bn_backward(da.contiguous(), None, c, gamma, mean, invstd, ctx.training,
+                                            mask_affine=(scale, shift))
         dw = spec.wgrad(x, dc)
         dbias = ops.channel_sum(dc, spec.cout) if ctx.has_bias else None
         dx = spec.dgrad(dc, w, _hw(x, spec.in_nchw)) if ctx.needs_input_grad[0] else None
@@ -180,10 +182,10 @@ class BasicBlockFn(torch.autograd.Function):
         if wsc is not None:
             cs, ms, is_, scs, shs = blk.spec_sc.fwd_bn(x, wsc.detach(), blk.shortcut[1], training)
             out = ops.bn_apply(c2, sc2, sh2, relu=True, res=cs, res_scale=scs, res_shift=shs)
-            ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, wsc, gsc, cs, ms, is_)
+            ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_)
         else:
             out = ops.bn_apply(c2, sc2, sh2, relu=True, res=x)
-            ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2)
+            ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, sc1, sh1)
         ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None
         return out
 
@@ -191,15 +193,15 @@ class BasicBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         blk, tr = ctx.blk, ctx.training
         if ctx.has_sc:
-            x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, wsc, gsc, cs, ms, is_ = ctx.saved_tensors
+            x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_ = ctx.saved_tensors
         else:
-            x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2 = ctx.saved_tensors
+            x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, sc1, sh1 = ctx.saved_tensors
         dout = dout.contiguous()
         hw = (x.shape[1], x.shape[2])
         dc2, dg2, db2 = ops.bn_backward(dout, out, c2, g2, m2, i2, tr)
         dw2 = blk.spec2.wgrad(a1, dc2)
         da1 = blk.spec2.dgrad(dc2, w2, (a1.shape[1], a1.shape[2]))
-        dc1, dg1, db1 = ops.bn_backward(da1, a1, c1, g1, m1, i1, tr)
+        dc1, dg1, db1 = ops.bn_backward(da1, None, c1, g1, m1, i1, tr, mask_affine=(sc1, sh1))   # mask = (bn1(c1) > 0)
         dw1 = blk.spec1.wgrad(x, dc1)
         if ctx.has_sc:
             dcs, dgs, dbs = ops.bn_backward(dout, out, cs, gsc, ms, is_, tr)

@@ -227,8 +227,10 @@ def bn_apply(x, scale, shift, relu=True, res=None, res_scale=None, res_shift=Non
     return y
 
 
-def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True):
-    """Returns (dx, dgamma, dbeta) for y = [relu](bn(x) + ...); y_mask (the post-ReLU output) may be None."""
+def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mask_affine=None):
+    """Returns (dx, dgamma, dbeta) for y = [relu](bn(x) + ...).  The ReLU mask comes from y_mask (the saved output), or --
+    for a plain relu(bn(x)) -- from mask_affine=(scale, shift), the forward's fused affine (the saved output is not read),
+    or there is none (both None)."""
     _lib.require_cuda(dy, x)
     C = x.shape[-1]
     dx = torch.empty_like(x)
@@ -238,7 +240,9 @@ def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True):
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = _bn_ws(x.device, C)
     _lib.check(_lib.lib().dam_bn_backward_f32(_lib.ptr(dy), _lib.ptr(y_mask), _lib.ptr(x), x.numel() // C, C, _lib.ptr(gamma),
-                                              _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0, _lib.ptr(dx),
+                                              _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
+                                              _lib.ptr(mask_affine[0]) if mask_affine else None,
+                                              _lib.ptr(mask_affine[1]) if mask_affine else None, _lib.ptr(dx),
                                               _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.stream()),
                'dam_bn_backward_f32')
     return dx, dgamma, dbeta

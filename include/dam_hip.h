@@ -160,12 +160,15 @@ int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const float* scale
                      const float* res, const float* res_scale, const float* res_shift, int relu, float* y,
                      void* stream);
 
-/* Backward of y = [relu](bn(x) [+ ...]): dz = dy * (y_mask > 0) (y_mask NULL: dz = dy);
+/* Backward of y = [relu](bn(x) [+ ...]): dz = dy * mask, where mask is (y_mask > 0) if y_mask (the saved output) is given,
+ * (x*mask_scale + mask_shift > 0) if the forward's fused affine is given instead (plain relu(bn(x)): the saved output is
+ * then not read at all), 1 if both are NULL;
  * dgamma = sum dz*xhat, dbeta = sum dz, dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
  * (training) or gamma*invstd*dz (training == 0, running statistics). */
 int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
                         const float* gamma, const float* save_mean, const float* save_invstd, int training,
-                        float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
+                        const float* mask_scale, const float* mask_shift, float* dx, float* dgamma, float* dbeta,
+                        float* workspace, void* stream);
 
 /* out[c] = sum_p x[p][c] for c < n_real (gradient of a convolution bias, models/model_scalar_1s.py:167). */
 int dam_channel_sum_f32(const float* x, int64_t n_pixels, int C, int n_real, float* out, float* workspace,

@@ -1,0 +1,54 @@
+"""GPU: BatchNorm forward statistics / apply and the three mask modes of the backward (saved output, recomputed from the fused
+affine, none) through the C ABI against torch autograd in float64.  Tolerance: fp32 accumulation over up to 1e5 pixels."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops(dam_lib):
+    from deep_audio_mixer_amd import ops
+    return ops
+
+
+def close(got, want, tol):
+    got, want = got.double().cpu(), want.double()
+    scale = want.abs().max().item() + 1e-30
+    assert (got - want).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize('B,H,W,C', [(2, 37, 23, 16), (1, 129, 65, 32), (3, 9, 5, 256), (8, 128, 130, 16)])
+def test_bn_relu_forward_backward_mask_modes(ops, B, H, W, C):
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, H, W, C, generator=g) * 3 + 5).requires_grad_(False)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dy = torch.randn(B, H, W, C, generator=g)
+    # reference: float64 autograd, training-mode statistics, relu(bn(x))
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean = xr.mean(dim=(0, 1, 2)); var = xr.var(dim=(0, 1, 2), unbiased=False)
+    yr = torch.relu((xr - mean) / torch.sqrt(var + 1e-5) * gr + br)
+    yr.backward(dy.double())
+    xd = x.cuda()
+    rm, rv, nbt = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    sm, si, sc, sh = ops.bn_stats(xd, gamma.cuda(), beta.cuda(), rm, rv, nbt, 0.1, 1e-5)
+    a = ops.bn_apply(xd, sc, sh, relu=True)
+    close(a, yr.detach(), 2e-5)
+    for mode in ('saved', 'affine'):
+        if mode == 'saved':
+            dx, dgm, dbt = ops.bn_backward(dy.cuda(), a, xd, gamma.cuda(), sm, si, True)
+        else:
+            dx, dgm, dbt = ops.bn_backward(dy.cuda(), None, xd, gamma.cuda(), sm, si, True, mask_affine=(sc, sh))
+        close(dx, xr.grad, 1e-4); close(dgm, gr.grad, 1e-4); close(dbt, br.grad, 1e-4)
+    # the two mask modes must agree bit for bit (same fma as the forward)
+    d1 = ops.bn_backward(dy.cuda(), a, xd, gamma.cuda(), sm, si, True)
+    d2 = ops.bn_backward(dy.cuda(), None, xd, gamma.cuda(), sm, si, True, mask_affine=(sc, sh))
+    assert all(torch.equal(p, q) for p, q in zip(d1, d2))
+    # no mask: plain bn
+    xr2 = x.double().requires_grad_(True)
+    y2 = (xr2 - xr2.mean(dim=(0, 1, 2))) / torch.sqrt(xr2.var(dim=(0, 1, 2), unbiased=False) + 1e-5) * gamma.double() + beta.double()
+    y2.backward(dy.double())
+    dx0, _, _ = ops.bn_backward(dy.cuda(), None, xd, gamma.cuda(), sm, si, True)
+    close(dx0, xr2.grad, 1e-4)
