@@ -331,16 +331,16 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     hipStream_t st = (hipStream_t)stream;
     g.PR = 0; g.CG = 1; g.tiles_m = 0; g.ksplit = 1; g.gps = 1 << 30;
     // persistent strip variant (LDS-DMA ring, optional fused BatchNorm statistics) when the layer fits it
-    if (!in_nchw && !in_scale) {
+    if (!in_nchw) {
         int parts = 0;
-        const int rc = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, bn_partial, &parts, st);
+        const int rc = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, bn_partial, &parts, in_scale, in_shift, st);
         if (rc == DAM_OK) {
             if (bn_partial && bn_parts_host) *bn_parts_host = parts;
             return DAM_OK;
         }
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
         if (bn_partial) {       // maybe only the statistics did not fit: retry without them
-            const int rc2 = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, nullptr, nullptr, st);
+            const int rc2 = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, nullptr, nullptr, in_scale, in_shift, st);
             if (rc2 == DAM_OK) return DAM_OK;
             if (rc2 != DAM_ERR_UNSUPPORTED) return rc2;
         }

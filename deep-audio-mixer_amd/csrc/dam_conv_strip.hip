@@ -58,7 +58,7 @@ struct RowLoad {           // everything the row loader needs, by value (no clos
 // Requests pieces first + part + nparts*u (u < STRIP_PU) of input rows [lo, hi] into registers: unconditional loads from
 // clamped addresses, unused / out-of-tensor lanes zeroed by select (a conditional around a load costs an s_waitcnt each).
 __device__ __forceinline__ void rows_issue(const RowLoad& r, int lo, int hi, int first, int part, int nparts, int lane,
-                                           float4 (&lv)[STRIP_PU], int (&ldst)[STRIP_PU]) {
+                                           float4 (&lv)[STRIP_PU], int (&ldst)[STRIP_PU], int (&laff)[STRIP_PU]) {
     const int total = (hi - lo + 1) * r.ppr;
 #pragma unroll
     for (int u = 0; u < STRIP_PU; ++u) {
@@ -78,12 +78,28 @@ __device__ __forceinline__ void rows_issue(const RowLoad& r, int lo, int hi, int
         const float4 x = *reinterpret_cast<const float4*>(r.ximg + (unsigned)((ihc * r.W + iwc) * r.C + cc * 16 + quad * 4));
         lv[u] = inb ? x : make_float4(0.f, 0.f, 0.f, 0.f);
         ldst[u] = (used && col_ok) ? cc * r.CHB + ((ih + r.ring_off) & (r.NR - 1)) * r.RB + L * 16 : -1;
+        laff[u] = inb ? cc : -1;               // real data of chunk cc (gets the fused input affine), else padding zeros
     }
 }
-__device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&lv)[STRIP_PU], int (&ldst)[STRIP_PU]) {
+// y = [relu](x * scale + shift) on the real-data lanes of a piece (the producer's BatchNorm + ReLU fused into the load)
+template <int NCH>
+__device__ __forceinline__ float4 in_affine(float4 v, int cc, const v4f (&scq)[NCH], const v4f (&shq)[NCH], bool relu) {
+    const v4f sc = (NCH > 1 && cc > 0) ? scq[NCH - 1] : scq[0], sh = (NCH > 1 && cc > 0) ? shq[NCH - 1] : shq[0];
+    float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    return o;
+}
+template <int NCH>
+__device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&lv)[STRIP_PU], int (&ldst)[STRIP_PU],
+                                            const int (&laff)[STRIP_PU], bool has_aff, const v4f (&scq)[NCH],
+                                            const v4f (&shq)[NCH], bool relu) {
 #pragma unroll
     for (int u = 0; u < STRIP_PU; ++u) {
-        if (ldst[u] >= 0) *reinterpret_cast<float4*>(smem + ldst[u]) = lv[u];
+        if (ldst[u] >= 0) {
+            float4 v = lv[u];
+            if (has_aff && laff[u] >= 0) v = in_affine<NCH>(v, laff[u], scq, shq, relu);
+            *reinterpret_cast<float4*>(smem + ldst[u]) = v;
+        }
         ldst[u] = -1;
     }
 }
@@ -93,7 +109,8 @@ template <int MB, int NB, int NCH, bool T33>
 __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
-                                                         const float* __restrict__ res_mask, float* __restrict__ stats) {
+                                                         const float* __restrict__ res_mask, float* __restrict__ stats,
+                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: role tests and loader arithmetic on the scalar ALU
@@ -108,6 +125,15 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     const int CHB = sg.NR * RB;                // bytes of one chunk plane
     const int RH = sg.RH;                      // input rows touched by one output row
     const float* ximg = X + (size_t)img * g.H * g.W * g.C;
+    // fused input affine (the producer's BatchNorm + ReLU applied while the rows are written to LDS): a lane always holds
+    // channel quad (lane & 3) of a cell, so its scale / shift values are two registers per chunk for the whole kernel
+    const bool has_aff = in_scale != nullptr, relu_in = g.relu_in != 0;
+    v4f scq[NCH], shq[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        scq[c] = has_aff ? *reinterpret_cast<const v4f*>(in_scale + c * 16 + (lane & 3) * 4) : (v4f){1.f, 1.f, 1.f, 1.f};
+        shq[c] = has_aff ? *reinterpret_cast<const v4f*>(in_shift + c * 16 + (lane & 3) * 4) : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
 #ifdef DAM_STAMPS
     int stamp_i = 0;
 #endif
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     const int pieces_per_row = g.nchunks * groups_per_plane;
     const float inv_ppr = 1.0f / (float)pieces_per_row, inv_gpp = 1.0f / (float)groups_per_plane;
     float4 lv[STRIP_PU];
-    int ldst[STRIP_PU];
+    int ldst[STRIP_PU], laff[STRIP_PU];
 #pragma unroll
     for (int u = 0; u < STRIP_PU; ++u) ldst[u] = -1;
     RowLoad rl;
@@ -146,7 +172,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     int lo0, hi0;
     tile_rows(t_begin, lo0, hi0);
     const int total0 = (hi0 - lo0 + 1) * pieces_per_row;
-    rows_issue(rl, lo0, hi0, 0, wave, STRIP_THREADS / 64, lane, lv, ldst);
+    rows_issue(rl, lo0, hi0, 0, wave, STRIP_THREADS / 64, lane, lv, ldst, laff);
     // zero the whole ring once: border slots stay zero for the lifetime of the workgroup
     for (int e = tid * 16; e < CHB * g.nchunks; e += STRIP_THREADS * 16)
         *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,10 +193,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     }
     __syncthreads();
     DAM_STAMP(2);
-    rows_commit(smem, lv, ldst);
+    rows_commit<NCH>(smem, lv, ldst, laff, has_aff, scq, shq, relu_in);
     for (int base = (STRIP_THREADS / 64) * STRIP_PU; base < total0; base += (STRIP_THREADS / 64) * STRIP_PU) {
-        rows_issue(rl, lo0, hi0, base, wave, STRIP_THREADS / 64, lane, lv, ldst);
-        rows_commit(smem, lv, ldst);
+        rows_issue(rl, lo0, hi0, base, wave, STRIP_THREADS / 64, lane, lv, ldst, laff);
+        rows_commit<NCH>(smem, lv, ldst, laff, has_aff, scq, shq, relu_in);
     }
     __syncthreads();
     DAM_STAMP(3);
@@ -208,12 +234,13 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
         v4f lvA[KP][GPP], lvB[KP][GPP];
         int dstA[KP], dstB[KP];                          // scalar: ring byte offset of the plane | 1 << 30 if the row is
-#pragma unroll                                           // outside the tensor (zeros are written), -1 = nothing to write
-        for (int k = 0; k < KP; ++k) { dstA[k] = -1; dstB[k] = -1; }
+        int ccA[KP], ccB[KP];                            // outside the tensor (zeros are written), -1 = nothing to write; chunk
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { dstA[k] = -1; dstB[k] = -1; ccA[k] = 0; ccB[k] = 0; }
         const int chs = NCH == 1 ? 0 : 1;
         int loaded_hi;
         { int lo; tile_rows(t_begin, lo, loaded_hi); }
-#define DAM_STRIP_REQUEST(K_, LV_, DST_)                                                                                   \
+#define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_)                                                                                \
     do {                                                                                                                   \
         int first_ = 0, planes_ = 0;                                                                                       \
         if ((K_) < n_tiles) {                                                                                              \
@@ -231,18 +258,29 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
             _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                             \
                 LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[gi], soff_, 0));   \
             DST_[k] = used_ ? ((cc_ * CHB + ((ih_ + sg.ring_off) & (sg.NR - 1)) * RB) | (rowok_ ? 0 : 1 << 30)) : -1;     \
+            CC_[k] = cc_;                                                                                                  \
         }                                                                                                                  \
     } while (0)
 #define DAM_STRIP_WRITE(ADDR_, DATA_, GI_)                                                                                 \
     asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
                  : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024) : "memory")
-#define DAM_STRIP_COMMIT(LV_, DST_)                                                                                        \
+#define DAM_STRIP_COMMIT(LV_, DST_, CC_)                                                                                   \
     do {                                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
             if (DST_[k] >= 0) {                                                                                            \
                 const int va_ = lane16 + (DST_[k] & 0x3fffffff);                                                           \
                 if (!(DST_[k] >> 30)) {                                                                                    \
-                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_STRIP_WRITE(va_, LV_[k][gi], gi);               \
+                    if (has_aff) {             /* 8 VALU per piece (4 fma + 4 max), ~40 per loader wave and slot */        \
+                        const v4f sc_ = (NCH > 1 && CC_[k] > 0) ? scq[NCH - 1] : scq[0];                                   \
+                        const v4f sh_ = (NCH > 1 && CC_[k] > 0) ? shq[NCH - 1] : shq[0];                                   \
+                        _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) {                                               \
+                            v4f v_ = __builtin_elementwise_fma(LV_[k][gi], sc_, sh_);                                      \
+                            if (relu_in) v_ = __builtin_elementwise_max(v_, zero4);                                        \
+                            DAM_STRIP_WRITE(va_, v_, gi);                                                                  \
+                        }                                                                                                  \
+                    } else {                                                                                               \
+                        _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_STRIP_WRITE(va_, LV_[k][gi], gi);           \
+                    }                                                                                                      \
                 } else {                                                                                                   \
                     _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_STRIP_WRITE(va_, zero4, gi);                    \
                 }                                                                                                          \
@@ -251,19 +289,19 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     } while (0)
 #ifdef DAM_DIAG_NO_LOAD        // timing experiments only (results are wrong)
 #undef DAM_STRIP_REQUEST
-#define DAM_STRIP_REQUEST(K_, LV_, DST_) do { } while (0)
+#define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_) do { } while (0)
 #endif
-        DAM_STRIP_REQUEST(1, lvB, dstB);
-        DAM_STRIP_REQUEST(2, lvA, dstA);
+        DAM_STRIP_REQUEST(1, lvB, dstB, ccB);
+        DAM_STRIP_REQUEST(2, lvA, dstA, ccA);
         // slots come in pairs (n_slots is even) so that no load sits inside a conditional: the compiler then knows that the
         // set being written is the older of the two in flight and waits with vmcnt(pieces of the other set), not vmcnt(0)
         for (int s = 0; s < n_slots; s += 2) {
-            DAM_STRIP_COMMIT(lvB, dstB);            // tile s+1
-            DAM_STRIP_REQUEST(s + 3, lvB, dstB);
+            DAM_STRIP_COMMIT(lvB, dstB, ccB);       // tile s+1
+            DAM_STRIP_REQUEST(s + 3, lvB, dstB, ccB);
             DAM_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            DAM_STRIP_COMMIT(lvA, dstA);            // tile s+2
-            DAM_STRIP_REQUEST(s + 4, lvA, dstA);
+            DAM_STRIP_COMMIT(lvA, dstA, ccA);       // tile s+2
+            DAM_STRIP_REQUEST(s + 4, lvA, dstA, ccA);
             DAM_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -591,7 +629,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 // Returns DAM_OK if launched, DAM_ERR_UNSUPPORTED if the layer does not fit this variant (caller falls back).
 template <int MB, int NB, int NCH, bool T33>
 static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, const float* Wp, const float* bias, float* Y,
-                        const float* res, const float* res_mask, float* stats, hipStream_t st) {
+                        const float* res, const float* res_mask, float* stats, const float* in_scale, const float* in_shift,
+                        hipStream_t st) {
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
@@ -603,13 +642,14 @@ static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, co
     }
     dim3 grid((unsigned)sg.strips, (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
     hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
-                       Y, res, res_mask, stats);
+                       Y, res, res_mask, stats, in_scale, in_shift);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
 
 int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
-                   const float* res, const float* res_mask, float* stats, int* stats_parts, hipStream_t st) {
+                   const float* res, const float* res_mask, float* stats, int* stats_parts, const float* in_scale,
+                   const float* in_shift, hipStream_t st) {
     ConvGeo g = g_in;                 // the caller's copy stays as it is for the tile kernel
     if (g.nB == 3 && g.step_w < 0) {  // same taps walked left to right: column step becomes +1, weight taps are re-indexed
         g.off_w += 2 * g.step_w; g.step_w = -g.step_w;
@@ -664,7 +704,7 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     if (lds < (size_t)8 * NB * 16 * 3 * sizeof(float)) lds = (size_t)8 * NB * 16 * 3 * sizeof(float);
     // 3x3 taps, stride 1, unit column step: compile-time item grid with immediate operand offsets
     const bool t33 = g.nA == 3 && g.nB == 3 && g.s == 1 && g.step_w == 1;
-#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, st
+#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, in_scale, in_shift, st
 #define DAM_STRIP_CASE(M_, N_)                                                                                           \
     if (MB == M_ && NB == N_) {                                                                                             \
         if (t33) return g.nchunks == 1 ? launch_strip<M_, N_, 1, true>(DAM_STRIP_ARGS) : launch_strip<M_, N_, 2, true>(DAM_STRIP_ARGS); \

@@ -246,7 +246,9 @@ constexpr int RW_THREADS = 256 + 64 * RW_LOADERS, RW_NRX = 10, RW_NRD = 8, RW_GU
 
 template <int TNB, int TKB, int STEPS, int KP, int GPP>
 __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g, const float* __restrict__ X,
-                                                                const float* __restrict__ dY, float* __restrict__ partial) {
+                                                                const float* __restrict__ dY, const float* __restrict__ in_scale,
+                                                                const float* __restrict__ in_shift, int relu_in,
+                                                                float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NBLK = TNB * TKB * 9;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -295,12 +297,22 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY) + (size_t)img * g.H * g.W * g.C, 0, img_bytes, 0x00020000);
         const int lane16 = lane * 16;
         const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+        // fused input affine on the X planes (the producer's BatchNorm + ReLU): a lane holds channel quad (lane & 3) of a cell
+        const bool has_aff = in_scale != nullptr;
+        v4f scq[TKB], shq[TKB];
+#pragma unroll
+        for (int kb = 0; kb < TKB; ++kb) {
+            const int ch = (tk * TKB + kb) * 16 + (lane & 3) * 4;
+            scq[kb] = has_aff ? *reinterpret_cast<const v4f*>(in_scale + ch) : (v4f){1.f, 1.f, 1.f, 1.f};
+            shq[kb] = has_aff ? *reinterpret_cast<const v4f*>(in_shift + ch) : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
         v4f lv[KP][GPP];
         int dst[KP];               // scalar: LDS byte offset of the plane | 1 << 30 (row outside the image: zeros), -1 = none
+        int aff[KP], aff2[KP];     // scalar: chunk index kb of an X plane that gets the input affine, -1 otherwise
         const int rowstride = g.W * g.C * 4;
         // X rows xr0 .. xr0+nx-1 (in-channel chunks of this tile) then dY rows dr0 .. dr0+nd-1 (out-channel blocks), one
         // plane = one (row, 16 channels); loader wave cwl takes planes cwl, cwl+4, ...  Loads are unconditional (clamped).
-#define DAM_RW_REQUEST(XR0_, NX_, DR0_, ND_, LV_, DST_, KP_)                                                                               \
+#define DAM_RW_REQUEST(XR0_, NX_, DR0_, ND_, LV_, DST_, KP_, AFF_)                                                                               \
     do {                                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < KP_; ++k) {                                                                  \
             const int pl_ = cwl + RW_LOADERS * k;                                                                          \
@@ -325,20 +337,29 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
                     LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(drsrc, loffb[gi], soff_, 0)); \
             }                                                                                                              \
             DST_[k] = need_ ? (ldsoff_ | (inimg_ ? 0 : 1 << 30)) : -1;                                                     \
+            AFF_[k] = (isx_ && has_aff) ? c_ : -1;                                                                         \
         }                                                                                                                  \
     } while (0)
 #define DAM_RW_WRITE(ADDR_, DATA_, GI_)                                                                                    \
     asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
                  : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024) : "memory")
-#define DAM_RW_COMMIT(LV_, DST_, KP_)                                                                                      \
+#define DAM_RW_COMMIT(LV_, DST_, KP_, AFF_)                                                                                \
     do {                                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < KP_; ++k) {                                                                  \
             if (DST_[k] >= 0) {                                                                                            \
                 const int va_ = lane16 + (DST_[k] & 0x3fffffff);                                                           \
-                if (!(DST_[k] >> 30)) {                                                                                    \
-                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, LV_[k][gi], gi);                  \
-                } else {                                                                                                   \
+                if (DST_[k] >> 30) {                                                                                       \
                     _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, zero4, gi);                       \
+                } else if (AFF_[k] >= 0) {                                                                                 \
+                    const v4f sc_ = (TKB > 1 && AFF_[k] > 0) ? scq[TKB - 1] : scq[0];                                      \
+                    const v4f sh_ = (TKB > 1 && AFF_[k] > 0) ? shq[TKB - 1] : shq[0];                                      \
+                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) {                                                   \
+                        v4f v_ = __builtin_elementwise_fma(LV_[k][gi], sc_, sh_);                                          \
+                        if (relu_in) v_ = __builtin_elementwise_max(v_, zero4);                                            \
+                        DAM_RW_WRITE(va_, v_, gi);                                                                         \
+                    }                                                                                                      \
+                } else {                                                                                                   \
+                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, LV_[k][gi], gi);                  \
                 }                                                                                                          \
             }                                                                                                              \
         }                                                                                                                  \
@@ -346,24 +367,24 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         // rows of slot 0: X rows r_begin-1 .. r_begin+4, dY rows r_begin .. r_begin+3: both rounds requested up front
         constexpr int KPB = (2 * TKB + RW_LOADERS - 1) / RW_LOADERS;
         v4f lvb[KPB][GPP], lv2[KP][GPP];
-        int dstb[KPB], dst2[KP];
-        DAM_RW_REQUEST(r_begin - 1, 4, r_begin, 4, lv, dst, KP);
-        DAM_RW_REQUEST(r_begin + 3, 2, r_begin, 0, lvb, dstb, KPB);
+        int dstb[KPB], dst2[KP], affb[KPB];
+        DAM_RW_REQUEST(r_begin - 1, 4, r_begin, 4, lv, dst, KP, aff);
+        DAM_RW_REQUEST(r_begin + 3, 2, r_begin, 0, lvb, dstb, KPB, affb);
         DAM_RW_ZERO();
-        DAM_RW_COMMIT(lv, dst, KP);
-        DAM_RW_COMMIT(lvb, dstb, KPB);
+        DAM_RW_COMMIT(lv, dst, KP, aff);
+        DAM_RW_COMMIT(lvb, dstb, KPB, affb);
         // steady state, two slots ahead (HBM latency under this load is about one slot): slot s writes the rows slot s+1
         // adds (X rows r_begin+4(s+1)+1 .. +4, dY rows r_begin+4(s+1) .. +3; requested during slot s-1) and requests those
         // of slot s+3.  Two register sets alternate; slots come in pairs so that no load sits inside a conditional.
-        DAM_RW_REQUEST(r_begin + 5, 4, r_begin + 4, 4, lv, dst, KP);
-        DAM_RW_REQUEST(r_begin + 9, 4, r_begin + 8, 4, lv2, dst2, KP);
+        DAM_RW_REQUEST(r_begin + 5, 4, r_begin + 4, 4, lv, dst, KP, aff);
+        DAM_RW_REQUEST(r_begin + 9, 4, r_begin + 8, 4, lv2, dst2, KP, aff2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int s = 0; s < n_slots2; s += 2) {
-            DAM_RW_COMMIT(lv, dst, KP);
-            DAM_RW_REQUEST(r_begin + 4 * s + 13, 4, r_begin + 4 * s + 12, 4, lv, dst, KP);
+            DAM_RW_COMMIT(lv, dst, KP, aff);
+            DAM_RW_REQUEST(r_begin + 4 * s + 13, 4, r_begin + 4 * s + 12, 4, lv, dst, KP, aff);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            DAM_RW_COMMIT(lv2, dst2, KP);
-            DAM_RW_REQUEST(r_begin + 4 * s + 17, 4, r_begin + 4 * s + 16, 4, lv2, dst2, KP);
+            DAM_RW_COMMIT(lv2, dst2, KP, aff2);
+            DAM_RW_REQUEST(r_begin + 4 * s + 17, 4, r_begin + 4 * s + 16, 4, lv2, dst2, KP, aff2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 #undef DAM_RW_REQUEST
@@ -444,8 +465,8 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
 }
 
 template <int TNB, int TKB, int STEPS, int KP, int GPP>
-int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* dY, float* partial, int64_t ws_floats,
-                      float* dw, int n_real, hipStream_t st) {
+int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* dY, const float* in_scale, const float* in_shift,
+                      int relu_in, float* partial, int64_t ws_floats, float* dw, int n_real, hipStream_t st) {
     constexpr int NBLK = TNB * TKB * 9;
     RowsGeo g;
     g.B = B; g.H = H; g.W = W; g.C = C;
@@ -480,7 +501,8 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
             return DAM_ERR_LAUNCH;
         raised = true;
     }
-    hipLaunchKernelGGL((wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP>), dim3(nx, nsplit), dim3(RW_THREADS), lds, st, g, X, dY, partial);
+    hipLaunchKernelGGL((wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP>), dim3(nx, nsplit), dim3(RW_THREADS), lds, st, g, X, dY, in_scale,
+                       in_shift, relu_in, partial);
     DAM_CHECK_LAUNCH();
     WgradGeo rg = {};                                 // what the reduce kernel reads
     rg.tap_groups = 1; rg.tiles_k = g.tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = 3; rg.KW = 3;
@@ -674,12 +696,12 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     if (in_nchw ? C > 16 : C % 16) return DAM_ERR_UNSUPPORTED;
     if (in_scale && !in_shift) return DAM_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !in_nchw && !in_scale && Ho == H && Wo == W && C == n_chan) {
+    if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !in_nchw && Ho == H && Wo == W && C == n_chan) {
         // row-streaming kernel for the shapes of the ResNet stages; anything else takes the tile kernel below
         int rc = DAM_ERR_UNSUPPORTED;
-        if (C == 16) rc = launch_wgrad_rows<1, 1, 33, 1, 9>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
-        else if (W > 48) rc = launch_wgrad_rows<2, 1, 17, 2, 5>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
-        else rc = launch_wgrad_rows<2, 1, 9, 2, 3>(B, H, W, C, x, dy, workspace, workspace_floats, dw, n_out, st);
+        if (C == 16) rc = launch_wgrad_rows<1, 1, 33, 1, 9>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, st);
+        else if (W > 48) rc = launch_wgrad_rows<2, 1, 17, 2, 5>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, st);
+        else rc = launch_wgrad_rows<2, 1, 9, 2, 3>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, st);
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
 #define DAM_WGD(TN_, TK_, KH_, KW_) \

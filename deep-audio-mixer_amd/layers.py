@@ -34,16 +34,18 @@ class ConvSpec:
         return ops.conv2d_fwd(x, self.packed(w), self.cout, self.k, self.k, self.stride, self.pad, self.dil,
                               bias=bias, in_nchw=self.in_nchw)
 
-    def fwd_bn(self, x, w, bn, training, bias=None):
+    def fwd_bn(self, x, w, bn, training, bias=None, in_affine=None):
         """Convolution followed by the statistics of its BatchNorm: (c, save_mean, save_invstd, scale, shift).  In
         training mode the conv launch emits the per-workgroup partial statistics itself when it can (strip kernel);
-        otherwise a separate statistics pass runs over c."""
+        otherwise a separate statistics pass runs over c.  in_affine=(scale, shift): the input is relu(x*scale + shift),
+        applied while the kernel loads x (the producer's BatchNorm + ReLU never materialised)."""
         wp = self.packed(w)
+        aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
         if training and not self.in_nchw:
             n16 = (self.cout + 15) // 16 * 16
             buf = ops.bn_partial_buffer(x.device, n16)
             c, parts = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
-                                      bn_partial=buf)
+                                      bn_partial=buf, **aff)
             if parts > 0:
                 mom = bn.momentum if bn.momentum is not None else 0.1
                 track = bn.track_running_stats
@@ -52,11 +54,12 @@ class ConvSpec:
                                                     bn.num_batches_tracked if track else None, mom, bn.eps))
         else:
             c = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
-                               in_nchw=self.in_nchw)
+                               in_nchw=self.in_nchw, **aff)
         return (c,) + tuple(_bn_fwd_stats(c, bn, training))
 
-    def wgrad(self, x, dy):
-        return ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil, in_nchw=self.in_nchw)
+    def wgrad(self, x, dy, in_affine=None):
+        aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
+        return ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil, in_nchw=self.in_nchw, **aff)
 
     def dgrad(self, dy, w, hw, **kw):
         return ops.conv2d_dgrad(dy, self.packed(w, transpose=True), self.cin, hw[0], hw[1], self.k, self.k,
@@ -177,15 +180,16 @@ class BasicBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wsc, gsc, bsc, blk, training):
         c1, m1, i1, sc1, sh1 = blk.spec1.fwd_bn(x, w1.detach(), blk.bn1, training)
-        a1 = ops.bn_apply(c1, sc1, sh1, relu=True)
-        c2, m2, i2, sc2, sh2 = blk.spec2.fwd_bn(a1, w2.detach(), blk.bn2, training)
+        # a1 = relu(bn1(c1)) is never written: conv2 (and later its weight gradient and bn1's backward) read c1 and apply the
+        # fused affine themselves
+        c2, m2, i2, sc2, sh2 = blk.spec2.fwd_bn(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1))
         if wsc is not None:
             cs, ms, is_, scs, shs = blk.spec_sc.fwd_bn(x, wsc.detach(), blk.shortcut[1], training)
             out = ops.bn_apply(c2, sc2, sh2, relu=True, res=cs, res_scale=scs, res_shift=shs)
-            ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_)
+            ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_)
         else:
             out = ops.bn_apply(c2, sc2, sh2, relu=True, res=x)
-            ctx.save_for_backward(x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, sc1, sh1)
+            ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1)
         ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None
         return out
 
@@ -193,14 +197,14 @@ class BasicBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         blk, tr = ctx.blk, ctx.training
         if ctx.has_sc:
-            x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_ = ctx.saved_tensors
+            x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_ = ctx.saved_tensors
         else:
-            x, w1, g1, w2, g2, c1, a1, c2, out, m1, i1, m2, i2, sc1, sh1 = ctx.saved_tensors
+            x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1 = ctx.saved_tensors
         dout = dout.contiguous()
         hw = (x.shape[1], x.shape[2])
         dc2, dg2, db2 = ops.bn_backward(dout, out, c2, g2, m2, i2, tr)
-        dw2 = blk.spec2.wgrad(a1, dc2)
-        da1 = blk.spec2.dgrad(dc2, w2, (a1.shape[1], a1.shape[2]))
+        dw2 = blk.spec2.wgrad(c1, dc2, in_affine=(sc1, sh1))
+        da1 = blk.spec2.dgrad(dc2, w2, (c1.shape[1], c1.shape[2]))
         dc1, dg1, db1 = ops.bn_backward(da1, None, c1, g1, m1, i1, tr, mask_affine=(sc1, sh1))   # mask = (bn1(c1) > 0)
         dw1 = blk.spec1.wgrad(x, dc1)
         if ctx.has_sc:
