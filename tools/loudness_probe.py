@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: time of the BS.1770 meter on a 4-minute stereo stem (device) next to the CPU oracle (scipy lfilter)."""
+"""Diagnostic: time of the BS.1770 meter on a 4-minute stereo stem (device).  The CPU figure quoted in DESIGN.md (scipy
+lfilter restatement, 296 ms) comes from tests/test_loudness_gpu.py::test_full_song_length_property's oracle call."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,7 +20,3 @@ dev = (time.perf_counter() - t0) / 5
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); z = m.block_energies(xd); e1.record(); torch.cuda.synchronize()
 print('device: %.2f ms per 4-min stereo stem end to end (%.2f ms kernels+copy), %.3f LUFS' % (dev * 1e3, e0.elapsed_time(e1), v))
-if '--cpu' in sys.argv:
-    from oracle import loudness_ref as ref
-    t0 = time.perf_counter(); w = ref.integrated_loudness(x.astype(np.float64), rate); cpu = time.perf_counter() - t0
-    print('oracle (scipy lfilter + numpy, 1 thread): %.1f ms, %.3f LUFS' % (cpu * 1e3, w))
