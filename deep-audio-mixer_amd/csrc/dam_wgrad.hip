@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
         const int p0 = (tile - img * g.tiles_m) * TMW;
         const int oh_first = p0 / g.Wo;
         __syncthreads();
-        stage_patch(smem, chunk_bytes, X + (size_t)img * img_elems, pg, oh_first * g.s + g.r0, tk * TKB, TKB,
+        // only the input rows the TA kernel rows of this tap group touch (a 1 x KW group needs no vertical halo at all)
+        stage_patch(smem, chunk_bytes, X + (size_t)img * img_elems, pg, oh_first * g.s + g.off_h + a0 * g.step_h, tk * TKB, TKB,
                     in_scale, in_shift, tid);
         {   // dY pixels p0 .. p0+TMW-1, channels of this n tile; zero beyond the image / channel count
             constexpr int QPP = TNB * 4;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
             const int base = (((oh - oh_first) * g.s) * g.PWT + ow) * 64 + j * 4;
 #pragma unroll
             for (int ta = 0; ta < TA; ++ta) {
-                const int roff = g.off_h + (a0 + ta) * g.step_h - g.r0;
+                const int roff = ta * g.step_h;                 // relative to the first staged row (tap row a0)
 #pragma unroll
                 for (int tb = 0; tb < TB; ++tb) {
                     const int coff = g.off_w + tb * g.step_w - g.c0;
@@ -727,11 +728,12 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     g.PWin = (Wo - 1) * stride + (kw - 1) * dil + 1;
     g.PWs = (int)cdiv(g.PWin, stride);
     g.PWT = g.PWs * stride;
+    const int ta_rows = (kh == 3 && kw == 3) ? 3 : 1;               // TA of the instantiations below
     auto set_tile = [&](int tmw) {
         int rows_out = (tmw + Wo - 2) / Wo + 1;
         if (rows_out > Ho) rows_out = Ho;
         g.TMW = tmw;
-        g.PR = (rows_out - 1) * stride + (kh - 1) * dil + 1;
+        g.PR = (rows_out - 1) * stride + (ta_rows - 1) * dil + 1;        // rows one tap group (TA kernel rows) touches
         g.tiles_m = (int)cdiv((int64_t)Ho * Wo, tmw);
         g.total_tiles = g.tiles_m * B;
     };
