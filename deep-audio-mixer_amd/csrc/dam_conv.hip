@@ -299,6 +299,91 @@ extern "C" int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_te
     return DAM_OK;
 }
 
+namespace dam {
+namespace {
+
+// Single-tap convolutions (the 1x1 strided shortcut of a down-sampling block, forward and its data gradient): no operand is
+// reused across taps, so nothing is staged -- a wave owns 16 consecutive output pixels of one output row and NB output
+// blocks, the input pixels (16 x 64-byte segments per 16-channel chunk) and the packed weights come straight from HBM / L2
+// through buffer loads, all chunks in flight at once.  Memory- and latency-bound: 51 MB for the largest instance.
+template <int NB, int NCHMAX>
+__global__ __launch_bounds__(256) void conv1x1_direct_kernel(const ConvGeo g, const float* __restrict__ X,
+                                                             const float4* __restrict__ Wp, const float* __restrict__ bias,
+                                                             float* __restrict__ Y, const float* __restrict__ res,
+                                                             const float* __restrict__ res_mask, int segs, int total_units) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int unit = blockIdx.x * 4 + wave;                  // (image, output row, 16-pixel segment)
+    if (unit >= total_units) return;
+    const int nb0 = blockIdx.y * NB;
+    const int seg = unit % segs, row = unit / segs, img = row / g.Ho, oh = row - img * g.Ho;
+    const int ow = seg * 16 + j;
+    const bool valid = ow < g.Wo;
+    const int ih = oh * g.s + g.off_h, iw = ow * g.s + g.off_w;          // single tap: always inside the tensor for pad 0;
+    const bool inb = valid && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W; // checked anyway
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp), 0, 0x7fffffff, 0x00020000);
+    const int xoff = inb ? (((img * g.H + ih) * g.W + iw) * g.C + kq * 4) * 4 : 0x7fffffff;
+    const int tap = g.wt_base;
+    float4 xv[NCHMAX], wa[NCHMAX][NB];
+#pragma unroll
+    for (int c = 0; c < NCHMAX; ++c) {
+        const bool cok = c < g.nchunks;
+        xv[c] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, cok ? xoff : 0x7fffffff, c * 64, 0));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            wa[c][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                wr, cok ? lane * 16 : 0x7fffffff, (((tap * g.nchunks + c) * g.NBtot + nb0 + nb) * 64) * 16, 0));
+    }
+    v4f acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCHMAX; ++c)            // chunks past nchunks loaded zeros (out-of-range offsets)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][nb].x, xv[c].x, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][nb].y, xv[c].y, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][nb].z, xv[c].z, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][nb].w, xv[c].w, acc[nb], 0, 0, 0);
+        }
+    if (!valid) return;
+    const size_t opix = ((size_t)img * g.OHt + (oh * g.os + g.oo_h)) * g.OWt + (ow * g.os + g.oo_w);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int ch = (nb0 + nb) * 16 + kq * 4;
+        v4f v = acc[nb];
+        if (bias) v += *reinterpret_cast<const v4f*>(bias + ch);
+        const size_t o = opix * g.N + ch;
+        if (res) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + o);
+            if (res_mask) {
+                const float4 mv = *reinterpret_cast<const float4*>(res_mask + o);
+                v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;
+                v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;
+            } else {
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+        }
+        *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
+    }
+}
+
+template <int NB, int NCHMAX>
+int launch_conv1x1(const ConvGeo& g, const float* X, const float* Wp, const float* bias, float* Y, const float* res,
+                   const float* res_mask, hipStream_t st) {
+    const int segs = (int)cdiv(g.Wo, 16);
+    const int64_t units = (int64_t)g.B * g.Ho * segs;
+    if (units >= (1ll << 30)) return DAM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, NCHMAX>), dim3((unsigned)cdiv(units, 4), (unsigned)(g.N / 16 / NB)), dim3(256), 0, st,
+                       g, X, reinterpret_cast<const float4*>(Wp), bias, Y, res, res_mask, segs, (int)units);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+}  // namespace
+}  // namespace dam
+
 // Generic tap-grid convolution (see dam_hip.h).  The host wrapper derives the patch geometry and picks the tile.
 extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
                                       int k_chunks, int n_out, const float* bias, const float* in_scale,
@@ -330,6 +415,17 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
 
     hipStream_t st = (hipStream_t)stream;
     g.PR = 0; g.CG = 1; g.tiles_m = 0; g.ksplit = 1; g.gps = 1 << 30;
+    // single tap (1x1 shortcut convolutions, forward and data gradient): direct kernel, nothing staged
+    if (nA == 1 && nB == 1 && !in_nchw && !in_scale && k_chunks <= 8 &&
+        (int64_t)B * H * W * C * 4 < (1ll << 31) && (int64_t)B * OHt * OWt * n_out * 4 < (1ll << 62)) {
+        const int nblk = n_out / 16;
+        if (k_chunks <= 2) return nblk % 2 == 0 ? launch_conv1x1<2, 2>(g, x, w_packed, bias, y, res, res_mask, st)
+                                                : launch_conv1x1<1, 2>(g, x, w_packed, bias, y, res, res_mask, st);
+        if (k_chunks <= 4) return nblk % 2 == 0 ? launch_conv1x1<2, 4>(g, x, w_packed, bias, y, res, res_mask, st)
+                                                : launch_conv1x1<1, 4>(g, x, w_packed, bias, y, res, res_mask, st);
+        return nblk % 2 == 0 ? launch_conv1x1<2, 8>(g, x, w_packed, bias, y, res, res_mask, st)
+                             : launch_conv1x1<1, 8>(g, x, w_packed, bias, y, res, res_mask, st);
+    }
     // persistent strip variant (LDS-DMA ring, optional fused BatchNorm statistics) when the layer fits it
     if (!in_nchw) {
         int parts = 0;
