@@ -426,7 +426,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
         return nblk % 2 == 0 ? launch_conv1x1<2, 8>(g, x, w_packed, bias, y, res, res_mask, st)
                              : launch_conv1x1<1, 8>(g, x, w_packed, bias, y, res, res_mask, st);
     }
-    // persistent strip variant (LDS-DMA ring, optional fused BatchNorm statistics) when the layer fits it
+    // persistent strip variant (LDS row ring fed by loader waves, optional fused BatchNorm statistics) when the layer fits it
     if (!in_nchw) {
         int parts = 0;
         const int rc = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, bn_partial, &parts, in_scale, in_shift, st);

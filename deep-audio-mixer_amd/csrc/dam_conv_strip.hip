@@ -3,15 +3,20 @@
 // (ResNet layer1/2 and their data gradients).  These layers sit at the MFMA/HBM ridge.
 //
 // Same GEMM mapping, packed weights and tap-grid semantics as conv_igemm_kernel (dam_conv.hip).  One workgroup per CU,
-// 12 waves with fixed roles, built from what the in-kernel stamps of the first version showed (profiles/README.md):
+// 12 waves with fixed roles, built from what in-kernel stamps and the issue-port probes showed (profiles/README.md,
+// tools/mfma_valu_mix.hip, tools/mfma_stream_cost.hip):
 //   * the workgroup walks `tpw` CONSECUTIVE 64*MB-pixel tiles of one image; input rows live in an LDS ring indexed by
-//     (absolute row & (NR-1)), so a tile fetches only the rows its predecessors did not (HBM traffic 1.06x algorithmic);
+//     (absolute row & (NR-1)), so a tile fetches only the rows its predecessors did not (HBM traffic 1.03x algorithmic);
 //   * compute group A (waves 0-3) and B (waves 4-7) PING-PONG: in slot s one group runs the MFMAs of tile s while the
-//     other writes out tile s-1 (epilogue + BatchNorm partial statistics).  Each SIMD hosts one wave of each group, so
-//     its matrix pipe always has exactly one MFMA stream, and the non-MFMA work of a tile hides under the next tile;
-//   * loader waves 8-11 fetch the rows tile s+2 adds with plain vector loads (up to 8 x 1 KB pieces in flight per wave)
-//     and write them to the ring; weights are LDS resident, so compute waves issue no vector-memory loads in the loop;
-//   * one raw s_barrier per slot; compute waves do not drain their output stores at it.
+//     other writes out tile s-1 (bias, residual / mask, BatchNorm partial statistics) and prepares its next tile.  Each
+//     SIMD hosts one wave of each group, so its matrix pipe always has exactly one MFMA stream;
+//   * a streaming MFMA wave owns its SIMD's vector issue port, so everything wave-uniform runs on the scalar ALU: loader
+//     waves 8-11 work in whole (row, chunk) planes (scalar plane arithmetic, per-lane column pattern computed once,
+//     buffer_load + EXEC-masked ds_write: no VALU per piece; optional fused input affine = 8 VALU per piece), two slots
+//     ahead in two register sets; pixel geometry by s_mul_hi; outputs through buffer_store;
+//   * 3x3 / stride 1: compile-time item grid, operands = register + immediate, two-deep software pipeline; weights are LDS
+//     resident in canonical [3a+b][chunk][nb][lane] order, so compute waves issue no vector-memory loads in the loop;
+//   * one raw s_barrier per slot; compute waves do not drain their output stores at it;
 //   * LDS image: [chunk][ring row][column slot][16 ch] with the same stride-2 column de-interleave as the tile kernel;
 //     border slots (zero padding) are zeroed once, only in-tensor pixels are ever written;
 //   * optional epilogue: per-channel BatchNorm partial statistics (n, mean, M2), one record per workgroup, merged by
