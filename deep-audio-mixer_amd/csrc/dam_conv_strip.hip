@@ -110,7 +110,9 @@ __device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&
 }
 
 // NCH: 16-channel input chunks (compile time so that every MFMA operand offset of the 3x3xNCH item grid is a scalar)
-template <int MB, int NB, int NCH, bool T33>
+// LW: loader shape -- false: rows of up to 144 (16 ch) / 80 (32 ch) cells, true: up to 224 / 112 cells (the reference's native
+// 216-frame spectrograms and their half-resolution stage)
+template <int MB, int NB, int NCH, bool T33, bool LW>
 __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
@@ -218,8 +220,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         // lane (column pattern of piece gi: byte offset inside a row, which lanes are real columns) is computed once, and
         // a piece costs no VALU instruction at all: buffer_load with scalar base + per-lane offset, ds_write with the
         // piece's column mask in EXEC and an immediate offset.
-        constexpr int KP = NCH == 1 ? 1 : 3;            // planes per loader wave per tile
-        constexpr int GPP = NCH == 1 ? 9 : 5;           // 1 KB pieces per plane (host guarantees groups_per_plane <= GPP)
+        constexpr int KP = NCH == 1 ? 1 : (LW ? 2 : 3);           // planes per loader wave per tile
+        constexpr int GPP = NCH == 1 ? (LW ? 14 : 9) : (LW ? 7 : 5);   // 1 KB pieces per plane (host: groups_per_plane <= GPP)
         int loffb[GPP];
         unsigned long long cmask[GPP];
 #pragma unroll
@@ -632,21 +634,21 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 }  // namespace
 
 // Returns DAM_OK if launched, DAM_ERR_UNSUPPORTED if the layer does not fit this variant (caller falls back).
-template <int MB, int NB, int NCH, bool T33>
+template <int MB, int NB, int NCH, bool T33, bool LW = false>
 static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, const float* Wp, const float* bias, float* Y,
                         const float* res, const float* res_mask, float* stats, const float* in_scale, const float* in_shift,
                         hipStream_t st) {
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH, T33>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH, T33, LW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return DAM_ERR_LAUNCH;
             raised = true;
         }
     }
     dim3 grid((unsigned)sg.strips, (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
-    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
+    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33, LW>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
                        Y, res, res_mask, stats, in_scale, in_shift);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -675,6 +677,7 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     const size_t LDS_MAX = 150 * 1024;                                      // one workgroup (12 waves) per CU
     int MB = 4;
     size_t lds = 0;
+    bool wide = false;
     for (;; MB >>= 1) {
         const int tm = 64 * MB;
         int rows_out = (int)((tm + g.Wo - 2) / g.Wo + 1);
@@ -684,8 +687,11 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
         int nr = 1;
         while (nr < rows_tile + rows_new) nr <<= 1;               // tile s in use, the rows tile s+1 adds being written
         // loader waves take whole (row, chunk) planes: KP planes of <= GPP pieces each per wave per tile (see the kernel)
-        const int gpp = (g.PWT * 4 + 63) / 64, kp = g.nchunks == 1 ? 1 : 3, gpp_max = g.nchunks == 1 ? 9 : 5;
+        const int gpp = (g.PWT * 4 + 63) / 64;
+        wide = gpp > (g.nchunks == 1 ? 9 : 5);                    // wide-row loader shape (LW): instantiated for two tiles only
+        const int kp = g.nchunks == 1 ? 1 : (wide ? 2 : 3), gpp_max = g.nchunks == 1 ? (wide ? 14 : 9) : (wide ? 7 : 5);
         if (gpp > gpp_max) return DAM_ERR_UNSUPPORTED;
+        if (wide && MB != (g.nchunks == 1 ? 4 : 2)) { if (MB == 2) return DAM_ERR_UNSUPPORTED; continue; }
         if (rows_new * g.nchunks > STRIP_LOADERS * kp) { if (MB == 2) return DAM_ERR_UNSUPPORTED; continue; }
         lds = (size_t)nr * g.PWT * 64 * g.nchunks + w_bytes;
         if (lds <= LDS_MAX) { sg.NR = nr; break; }
@@ -714,6 +720,13 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     if (MB == M_ && NB == N_) {                                                                                             \
         if (t33) return g.nchunks == 1 ? launch_strip<M_, N_, 1, true>(DAM_STRIP_ARGS) : launch_strip<M_, N_, 2, true>(DAM_STRIP_ARGS); \
         return g.nchunks == 1 ? launch_strip<M_, N_, 1, false>(DAM_STRIP_ARGS) : launch_strip<M_, N_, 2, false>(DAM_STRIP_ARGS); \
+    }
+    if (wide) {         // 16 ch: <4, 1>, 32 ch: <2, 2> only
+        if (g.nchunks == 1 && MB == 4 && NB == 1)
+            return t33 ? launch_strip<4, 1, 1, true, true>(DAM_STRIP_ARGS) : launch_strip<4, 1, 1, false, true>(DAM_STRIP_ARGS);
+        if (g.nchunks == 2 && MB == 2 && NB == 2)
+            return t33 ? launch_strip<2, 2, 2, true, true>(DAM_STRIP_ARGS) : launch_strip<2, 2, 2, false, true>(DAM_STRIP_ARGS);
+        return DAM_ERR_UNSUPPORTED;
     }
     DAM_STRIP_CASE(4, 2); DAM_STRIP_CASE(4, 1);
     DAM_STRIP_CASE(2, 2); DAM_STRIP_CASE(2, 1);

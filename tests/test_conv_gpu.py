@@ -41,6 +41,8 @@ CASES = [  # B, Cin, Cout, H, W, k, stride, pad, dil, bias
     (1, 48, 64, 40, 33, 7, 1, 0, 1, True),
     (1, 64, 128, 30, 25, 9, 1, 0, 1, True),
     (2, 16, 32, 45, 31, 5, 1, 0, 1, True),
+    (1, 16, 16, 40, 216, 3, 1, 1, 1, False),     # the reference's native 216-frame rows: wide-row strip loader
+    (1, 32, 32, 30, 108, 3, 1, 1, 1, False),
 ]
 
 
