@@ -243,22 +243,27 @@ struct RowsGeo {
     int gpp;                 // 1 KB pieces per row plane
 };
 constexpr int RW_LOADERS = 8;                 // loader waves (waves 4..11)
-constexpr int RW_THREADS = 256 + 64 * RW_LOADERS, RW_NRX = 10, RW_NRD = 8, RW_GUARD = 64, RW_TAIL = 256;
+constexpr int RW_THREADS = 256 + 64 * RW_LOADERS, RW_GUARD = 64, RW_TAIL = 256;
+// v % d for the two ring sizes (scalar multiply-shift, v < 30000)
+template <int D> __device__ __forceinline__ int rw_mod(int v) { return D == 10 ? v - ((v * 52429) >> 19) * 10 : v - ((v * 43691) >> 18) * 6; }
 
-template <int TNB, int TKB, int STEPS, int KP, int GPP>
+// HV: 1 = a compute wave takes a whole output row per slot (4 rows per slot), 2 = half a row (2 rows per slot, for rows too
+// wide for ten-row rings: the reference's native 216-frame spectrograms); STEPS = MFMA steps per wave and row (part)
+template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV>
 __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g, const float* __restrict__ X,
                                                                 const float* __restrict__ dY, const float* __restrict__ in_scale,
                                                                 const float* __restrict__ in_shift, int relu_in,
                                                                 float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NBLK = TNB * TKB * 9;
+    constexpr int RPS = 4 / HV, RW_NRX = 2 * RPS + 2, RW_NRD = 2 * RPS;     // rows per slot; ring rows (in use + being written)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kq = lane >> 4;
     const int tn = blockIdx.x / g.tiles_k, tk = blockIdx.x - tn * g.tiles_k;
     const int img = blockIdx.y / g.spi, r_begin = (blockIdx.y - img * g.spi) * g.rps;
     const int r_end = r_begin + g.rps < g.H ? r_begin + g.rps : g.H;
-    const int n_slots = (r_end - r_begin + 3) >> 2;
+    const int n_slots = (r_end - r_begin + RPS - 1) / RPS;
     const int n_slots2 = (n_slots + 1) & ~1;
     const int ROWB = g.P4 * 64;
     const int XPLANE = RW_NRX * ROWB, DPLANE = RW_NRD * ROWB;
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
             const bool need_ = isx_ ? row_ <= r_end : (i_ < (ND_) && row_ < r_end);                                        \
             const bool inimg_ = need_ && row_ >= 0 && row_ < g.H;                                                          \
             const int rel_ = row_ - r_begin + 1;                               /* >= 0 for every needed row */             \
-            const int xi_ = rel_ - ((rel_ * 52429) >> 19) * RW_NRX;            /* rel_ % 10 */                             \
+            const int xi_ = rw_mod<RW_NRX>(rel_);                                                                          \
             const int di_ = (row_ - r_begin) & (RW_NRD - 1);                                                               \
             const int ldsoff_ = isx_ ? XBASE + c_ * XPLANE + xi_ * ROWB : DBASE + c_ * DPLANE + di_ * ROWB;                \
             const int chan_ = isx_ ? (tk * TKB + c_) * 64 : (tn * TNB + c_) * 64;                                          \
@@ -365,29 +370,32 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
             }                                                                                                              \
         }                                                                                                                  \
     } while (0)
-        // rows of slot 0: X rows r_begin-1 .. r_begin+4, dY rows r_begin .. r_begin+3: both rounds requested up front
+        // rows of slot 0: X rows r_begin-1 .. r_begin+RPS, dY rows r_begin .. r_begin+RPS-1: both rounds requested up front
         constexpr int KPB = (2 * TKB + RW_LOADERS - 1) / RW_LOADERS;
         v4f lvb[KPB][GPP], lv2[KP][GPP];
         int dstb[KPB], dst2[KP], affb[KPB];
-        DAM_RW_REQUEST(r_begin - 1, 4, r_begin, 4, lv, dst, KP, aff);
-        DAM_RW_REQUEST(r_begin + 3, 2, r_begin, 0, lvb, dstb, KPB, affb);
+        DAM_RW_REQUEST(r_begin - 1, RPS, r_begin, RPS, lv, dst, KP, aff);
+        DAM_RW_REQUEST(r_begin + RPS - 1, 2, r_begin, 0, lvb, dstb, KPB, affb);
         DAM_RW_ZERO();
         DAM_RW_COMMIT(lv, dst, KP, aff);
         DAM_RW_COMMIT(lvb, dstb, KPB, affb);
         // steady state, two slots ahead (HBM latency under this load is about one slot): slot s writes the rows slot s+1
-        // adds (X rows r_begin+4(s+1)+1 .. +4, dY rows r_begin+4(s+1) .. +3; requested during slot s-1) and requests those
-        // of slot s+3.  Two register sets alternate; slots come in pairs so that no load sits inside a conditional.
-        DAM_RW_REQUEST(r_begin + 5, 4, r_begin + 4, 4, lv, dst, KP, aff);
-        DAM_RW_REQUEST(r_begin + 9, 4, r_begin + 8, 4, lv2, dst2, KP, aff2);
+        // adds (X rows r_begin+RPS(s+1)+1 .. +RPS, dY rows r_begin+RPS(s+1) .. +RPS-1; requested during slot s-1) and
+        // requests those of slot s+3.  Two register sets alternate; slots come in pairs so that no load sits inside a
+        // conditional.
+#define DAM_RW_SLOT(T_, LV_, DST_, AFF_) DAM_RW_REQUEST(r_begin + RPS * (T_) + 1, RPS, r_begin + RPS * (T_), RPS, LV_, DST_, KP, AFF_)
+        DAM_RW_SLOT(1, lv, dst, aff);
+        DAM_RW_SLOT(2, lv2, dst2, aff2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int s = 0; s < n_slots2; s += 2) {
             DAM_RW_COMMIT(lv, dst, KP, aff);
-            DAM_RW_REQUEST(r_begin + 4 * s + 13, 4, r_begin + 4 * s + 12, 4, lv, dst, KP, aff);
+            DAM_RW_SLOT(s + 3, lv, dst, aff);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             DAM_RW_COMMIT(lv2, dst2, KP, aff2);
-            DAM_RW_REQUEST(r_begin + 4 * s + 17, 4, r_begin + 4 * s + 16, 4, lv2, dst2, KP, aff2);
+            DAM_RW_SLOT(s + 4, lv2, dst2, aff2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+#undef DAM_RW_SLOT
 #undef DAM_RW_REQUEST
 #undef DAM_RW_WRITE
 #undef DAM_RW_COMMIT
@@ -398,18 +406,20 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         DAM_RW_ZERO();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS
         for (int s = 0; s < n_slots2; ++s) {
-            const int r = r_begin + 4 * s + cw;
+            const int rw = cw / HV, half = cw - rw * HV;                      // row of the slot, part of the row
+            const int r = r_begin + RPS * s + rw;
             if (r < r_end) {
                 int vx[TKB][3], vd[TNB];
+                const int part = half * STEPS * 256;                          // byte offset of this wave's first cell
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const int rel = 4 * s + cw + a;                            // row r - 1 + a relative to r_begin - 1
-                    const int xi = rel - ((rel * 52429) >> 19) * RW_NRX;
+                    const int xi = rw_mod<RW_NRX>(RPS * s + rw + a);          // row r - 1 + a relative to r_begin - 1
 #pragma unroll
-                    for (int kb = 0; kb < TKB; ++kb) vx[kb][a] = lane_b + (XBASE - 64 + kb * XPLANE + xi * ROWB);
+                    for (int kb = 0; kb < TKB; ++kb) vx[kb][a] = lane_b + (XBASE - 64 + kb * XPLANE + xi * ROWB + part);
                 }
 #pragma unroll
-                for (int nb = 0; nb < TNB; ++nb) vd[nb] = lane_b + (DBASE + nb * DPLANE + ((4 * s + cw) & (RW_NRD - 1)) * ROWB);
+                for (int nb = 0; nb < TNB; ++nb)
+                    vd[nb] = lane_b + (DBASE + nb * DPLANE + ((RPS * s + rw) & (RW_NRD - 1)) * ROWB + part);
                 float av[2][TNB], bv[2][TKB][9];
 #define DAM_RW_LOAD(T_, BUF_)                                                                                              \
     do {                                                                                                                   \
@@ -465,16 +475,17 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
     for (int e = tid; e < NBLK * 64; e += RW_THREADS) out[e] = reinterpret_cast<const float4*>(red)[e];
 }
 
-template <int TNB, int TKB, int STEPS, int KP, int GPP>
+template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV = 1>
 int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* dY, const float* in_scale, const float* in_shift,
                       int relu_in, float* partial, int64_t ws_floats, float* dw, int n_real, hipStream_t st) {
     constexpr int NBLK = TNB * TKB * 9;
     RowsGeo g;
     g.B = B; g.H = H; g.W = W; g.C = C;
-    g.P4 = ((W + 2 + 3) / 4) * 4;
-    if (g.P4 != STEPS * 4) return DAM_ERR_UNSUPPORTED;
+    constexpr int RPS = 4 / HV, NRX = 2 * RPS + 2, NRD = 2 * RPS;
+    g.P4 = ((W + 2 + 4 * HV - 1) / (4 * HV)) * (4 * HV);
+    if (g.P4 != STEPS * 4 * HV) return DAM_ERR_UNSUPPORTED;
     g.gpp = (g.P4 * 64 + 1023) / 1024;
-    if (g.gpp > GPP || (4 * TKB + 4 * TNB + RW_LOADERS - 1) / RW_LOADERS > KP) return DAM_ERR_UNSUPPORTED;
+    if (g.gpp > GPP || (RPS * (TKB + TNB) + RW_LOADERS - 1) / RW_LOADERS > KP) return DAM_ERR_UNSUPPORTED;
     const int nblk = C / 16;
     if (nblk % TNB || nblk % TKB || H >= 8000) return DAM_ERR_UNSUPPORTED;
     const int tiles_n = nblk / TNB;
@@ -483,26 +494,26 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     int want = 256 / nx;                              // one workgroup per CU
     if (want < 1) want = 1;
     int spi = (int)cdiv(want, B);
-    if (spi > (int)cdiv(H, 4)) spi = (int)cdiv(H, 4);
+    if (spi > (int)cdiv(H, RPS)) spi = (int)cdiv(H, RPS);
     for (;; --spi) {
-        g.rps = (int)cdiv(cdiv(H, spi), 4) * 4;
+        g.rps = (int)cdiv(cdiv(H, spi), RPS) * RPS;
         g.spi = (int)cdiv(H, g.rps);
         if ((int64_t)B * g.spi * nx * NBLK * 256 <= ws_floats || spi == 1) break;
     }
     const int nsplit = B * g.spi;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
     const size_t rowb = (size_t)g.P4 * 64;
-    size_t lds = RW_GUARD + (size_t)TKB * RW_NRX * rowb + (size_t)TNB * RW_NRD * rowb + RW_TAIL;
+    size_t lds = RW_GUARD + (size_t)TKB * NRX * rowb + (size_t)TNB * NRD * rowb + RW_TAIL;
     if (lds < (size_t)NBLK * 1024) lds = (size_t)NBLK * 1024;
     if (lds > 160 * 1024) return DAM_ERR_UNSUPPORTED;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return DAM_ERR_LAUNCH;
         raised = true;
     }
-    hipLaunchKernelGGL((wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP>), dim3(nx, nsplit), dim3(RW_THREADS), lds, st, g, X, dY, in_scale,
+    hipLaunchKernelGGL((wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV>), dim3(nx, nsplit), dim3(RW_THREADS), lds, st, g, X, dY, in_scale,
                        in_shift, relu_in, partial);
     DAM_CHECK_LAUNCH();
     WgradGeo rg = {};                                 // what the reduce kernel reads
@@ -700,9 +711,14 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !in_nchw && Ho == H && Wo == W && C == n_chan) {
         // row-streaming kernel for the shapes of the ResNet stages; anything else takes the tile kernel below
         int rc = DAM_ERR_UNSUPPORTED;
-        if (C == 16) rc = launch_wgrad_rows<1, 1, 33, 1, 9>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, st);
-        else if (W > 48) rc = launch_wgrad_rows<2, 1, 17, 2, 5>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, st);
-        else rc = launch_wgrad_rows<2, 1, 9, 2, 3>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, st);
+#define DAM_WGR(...) launch_wgrad_rows<__VA_ARGS__>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, st)
+        // <TN, TK, steps, planes per loader wave, pieces per plane, row parts>: the shapes of the ResNet stages at 130 frames
+        // (3 s clips) and at the reference's native 216 frames
+        if (C == 16) { rc = DAM_WGR(1, 1, 33, 1, 9); if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGR(1, 1, 28, 1, 14, 2); }
+        else if (W > 80) rc = DAM_WGR(2, 1, 14, 1, 7, 2);
+        else if (W > 48) { rc = DAM_WGR(2, 1, 17, 2, 5); if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGR(2, 1, 14, 2, 4); }
+        else rc = DAM_WGR(2, 1, 9, 2, 3);
+#undef DAM_WGR
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
 #define DAM_WGD(TN_, TK_, KH_, KW_) \
