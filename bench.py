@@ -2,46 +2,96 @@
 """bench.py -- BASELINE.json headline metric on MI355X.
 
   metric : stem-spectrogram-frames/sec (train), model_resnet, 8-stem 3 s @ 44.1 kHz (BASELINE config C3/C4)
-  step   : STFT/log-mag front-end (9 tracks per clip) + ResNet18 forward + MSE + backward + gradient bucket
-           (+ RCCL all-reduce when N > 1) + Adam(+L2), batch 8 clips per GPU, float32 end to end;
-           PCM already resident in HBM when the timed region starts (synthetic clips)
+  step   : STFT/log-mag front-end (9 tracks per clip, one launch) + ResNet18 forward + MSE + backward + gradient
+           buckets (+ RCCL all-reduce overlapped with backward when N > 1) + Adam(+L2), batch 8 clips per GPU, float32
+           end to end; PCM already resident in HBM when the timed region starts (synthetic clips)
   unit   : one 1025-bin STFT column of one input stem (8 stems x 130 frames = 1040 per clip)
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C5]
 
-Prints ONE JSON line on rank 0, with the `roofline` object of the dominant kernel (measured live with HIP
-events on the launch stream) and the `cpu_baseline` object (the CPU oracle timed on the host cores, N = 1 only).
+With --gpus N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py`) BEFORE touching the GPU and relays their output; it
+never falls back to one rank.  Launched by torch.distributed.run it is one rank (RANK / LOCAL_RANK / WORLD_SIZE).
+
+Prints ONE JSON line on rank 0, with the `roofline` object of the config's dominant kernel (measured live with HIP
+events on the launch stream), the `cpu_baseline` object (the CPU oracle timed on the host cores, N = 1 only) and
+`pcie_inclusive` (the same steps fed from page-locked host memory through an overlapped copy stream).
+Other configs (--config) print the same shape of line for BASELINE.json's other configurations.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_STEMS, SR, SECONDS, CHANNELS = 8, 44100, 3, 2
-N_SAMPLES = SR * SECONDS
-HOP, N_FFT = 1024, 2048
-BATCH = 8
+N_FFT = 2048
 PEAK_F32_MFMA = 157.3e12        # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM = 8.0e12               # MI355X_MICROARCH.md: HBM3E spec
 
+# BASELINE.json configs resolved to shapes (SURVEY section 8, table "Configs")
+CONFIGS = {
+    'C1': dict(model='scalar_1s', n_stems=2, sr=16000, seconds=1, hop=256, batch=8, gflop_fwd=9.65,
+               workload='C1: model_scalar_1s train step incl. STFT front-end, 2-stem 1 s @ 16 kHz stereo clips, n_fft 2048 '
+                        'hop 256 -> 2x1025x63 per clip'),
+    'C2': dict(model='scalar_2s', n_stems=4, sr=44100, seconds=3, hop=1024, batch=4, gflop_fwd=36.89,
+               workload='C2: model_scalar_2s train step incl. STFT front-end (HIP conv stack as well), 4-stem 3 s @ 44.1 kHz '
+                        'stereo clips, n_fft 2048 hop 1024 -> 4x1025x130 per clip'),
+    'C3': dict(model='resnet', n_stems=8, sr=44100, seconds=3, hop=1024, batch=8, gflop_fwd=9.89,
+               workload='C3: model_resnet (ResNet18, 8 stems) train step incl. STFT front-end, 8-stem 3 s @ 44.1 kHz '
+                        'stereo clips, n_fft 2048 hop 1024 -> 8x1025x130 per clip'),
+    'C5': dict(model='resnet', n_stems=8, sr=44100, seconds=3, hop=1024, batch=59, gflop_fwd=9.89, song_seconds=180,
+               workload='C5: inference_utils full-song inference, 8-stem 3-min @ 44.1 kHz stereo, 59 chunks of 3 s as one '
+                        'eval-mode ResNet18 batch, one hipGraph from PCM in HBM to the peak-normalised master'),
+}
+CHANNELS = 2
+N_HOST_CLIPS = 512              # SURVEY 8(d): dataset of 512 clips held in pinned host memory
 
-def synth_clips(n_clips, device, seed):
-    """stems 0.1*N(0,1), mix = sum_s linspace(0.5, 1.5, S)[s] * stem_s (stereo float32)."""
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """Parent of an N-rank run: no GPU call has been made in this process (torch.cuda.device_count() does not
+    initialise the device on this image)."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    rehearsal = os.environ.get('DAM_DIST_BACKEND', 'nccl') != 'nccl'       # gloo rehearsal: ranks may share a GPU
+    if n_dev < args.gpus and not rehearsal:
+        sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) visible; refusing to run fewer ranks\n' % (args.gpus, n_dev))
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
+
+
+def synth_clips(n_clips, n_stems, n_samples, device, seed):
+    """stems 0.1*N(0,1), mix = sum_s linspace(0.5, 1.5, S)[s] * stem_s (stereo float32).
+    Returns [n_clips, S+1, n, ch]: every clip's stems followed by its mix."""
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    stems = 0.1 * torch.randn((n_clips, N_STEMS, N_SAMPLES, CHANNELS), generator=g, device=device, dtype=torch.float32)
-    w = torch.linspace(0.5, 1.5, N_STEMS, device=device).view(1, N_STEMS, 1, 1)
-    return stems, (stems * w).sum(1)
+    clips = torch.empty((n_clips, n_stems + 1, n_samples, CHANNELS), device=device, dtype=torch.float32)
+    clips[:, :n_stems] = 0.1 * torch.randn((n_clips, n_stems, n_samples, CHANNELS), generator=g, device=device)
+    w = torch.linspace(0.5, 1.5, n_stems, device=device).view(1, n_stems, 1, 1)
+    clips[:, n_stems] = (clips[:, :n_stems] * w).sum(1)
+    return clips
 
 
 def time_kernel(fn, iters=30, warm=5):
     """Average device time of one launch sequence, HIP events on the current (launch) stream."""
+    import torch
     for _ in range(warm):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,114 +103,224 @@ def time_kernel(fn, iters=30, warm=5):
     return a.elapsed_time(b) * 1e-3 / iters
 
 
-def roofline_probe(device):
-    """Times the dominant kernels in isolation at the benchmark's shapes.
+def build_model(cfg, device, train=True):
+    import torch
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.models.model_scalar_1s import MixingModelScalar1s
+    from deep_audio_mixer_amd.models.model_scalar_2s import MixingModelScalar2s
+    ctor = {'resnet': ResNet18, 'scalar_1s': MixingModelScalar1s, 'scalar_2s': MixingModelScalar2s}[cfg['model']]
+    t = 1 + cfg['sr'] * cfg['seconds'] // cfg['hop']
+    torch.manual_seed(0)
+    m = ctor(n_stems=cfg['n_stems'], input_shape=(N_FFT // 2 + 1, t)).to(device)
+    return m.train() if train else m.eval()
 
-    Dominant kernel: the implicit-GEMM convolution (forward/dgrad; conv_strip_kernel for the thin full-resolution layers,
-    conv_igemm_kernel otherwise).  Its heaviest instance is a ResNet layer1 convolution: 16 -> 16 channels, 3x3, on
-    8 x 1025 x 130 pixels.  Algorithmic FLOPs per launch =
-    2 * B*H*W * Cout * 9*Cin; the bound is the fp32 matrix pipe (157.3 TFLOP/s).
-    """
+
+# ------------------------------------------------------------------------------------------------ roofline probes
+def roofline_resnet_layer1(device, batch, t_frames):
+    """Dominant kernel of C3 / C5: the implicit-GEMM convolution of the thin full-resolution layers (conv_strip_kernel;
+    ResNet layer1: 16 -> 16 channels, 3x3, on batch x 1025 x T pixels).  Algorithmic FLOPs per launch =
+    2 * B*H*W * Cout * 9*Cin; algorithmic HBM bytes = 4 * B*H*W * (Cin + Cout); the bound is the
+    fp32 matrix pipe (157.3 TFLOP/s), with the HBM figure beside it because the intensity (36 FLOP/B) sits at the ridge."""
+    import torch
     from deep_audio_mixer_amd import ops
-    out = {}
-    B, H, W = BATCH, N_FFT // 2 + 1, 1 + N_SAMPLES // HOP
-    for name, cin, cout, h, w_ in (('layer1_conv3x3_16x16', 16, 16, H, W), ('layer3_conv3x3_64x64', 64, 64, 257, 33)):
-        x = torch.randn((B, h, w_, cin), device=device)
-        wt = torch.randn((cout, cin, 3, 3), device=device) * 0.05
-        wp = ops.pack_weights(wt)
-        dy = torch.randn((B, h, w_, cout), device=device)
-        flops = 2.0 * B * h * w_ * cout * 9 * cin
-        t_f = time_kernel(lambda: ops.conv2d_fwd(x, wp, cout, 3, 3, 1, 1, 1))
-        t_w = time_kernel(lambda: ops.conv2d_wgrad(x, dy, cout, 3, 3, 1, 1, 1))
-        out[name] = {'fwd_s': t_f, 'fwd_tflops': flops / t_f / 1e12, 'wgrad_s': t_w, 'wgrad_tflops': flops / t_w / 1e12,
-                     'flops_per_launch': flops,
-                     'alg_bytes_per_launch': 4.0 * B * h * w_ * (cin + cout)}
-        if cin == 16:
-            # the nine launches of this kernel in one training step, as the step issues them (stem + two BasicBlocks of
-            # layer1): 3 forward with BatchNorm statistics, 2 forward with statistics and the fused input affine, 2 plain
-            # data gradients, 2 data gradients with the residual / mask epilogue -- what a kernel trace of the step averages
-            wpt = ops.pack_weights(wt, transpose=True)
-            sc, sh = torch.rand(cin, device=device) + 0.5, torch.randn(cin, device=device)
-            buf = ops.bn_partial_buffer(device, cout)
-            msk = torch.randn((B, h, w_, cin), device=device)
+    B, H, W, c = batch, N_FFT // 2 + 1, t_frames, 16
+    x = torch.randn((B, H, W, c), device=device)
+    wt = torch.randn((c, c, 3, 3), device=device) * 0.05
+    wp, wpt = ops.pack_weights(wt), ops.pack_weights(wt, transpose=True)
+    dy = torch.randn((B, H, W, c), device=device)
+    flops = 2.0 * B * H * W * c * 9 * c
+    out = {'flops_per_launch': flops, 'alg_bytes_per_launch': 4.0 * B * H * W * 2 * c}
+    out['fwd_s'] = time_kernel(lambda: ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1))
+    out['wgrad_s'] = time_kernel(lambda: ops.conv2d_wgrad(x, dy, c, 3, 3, 1, 1, 1))
+    # the launches of this kernel in one training step, as the step issues them (stem + two BasicBlocks of layer1):
+    # 3 forward with BatchNorm statistics, 2 forward with statistics and the fused input affine, 2 plain data gradients,
+    # 2 data gradients with the residual / mask epilogue -- what a kernel trace of the step averages
+    sc, sh = torch.rand(c, device=device) + 0.5, torch.randn(c, device=device)
+    buf = ops.bn_partial_buffer(device, c)
+    msk = torch.randn((B, H, W, c), device=device)
 
-            def step_mix():
-                for _ in range(3):
-                    ops.conv2d_fwd(x, wp, cout, 3, 3, 1, 1, 1, bn_partial=buf)
-                for _ in range(2):
-                    ops.conv2d_fwd(x, wp, cout, 3, 3, 1, 1, 1, bn_partial=buf, in_scale=sc, in_shift=sh, relu_in=True)
-                for _ in range(2):
-                    ops.conv2d_dgrad(dy, wpt, cin, h, w_, 3, 3, 1, 1, 1)
-                for _ in range(2):
-                    ops.conv2d_dgrad(dy, wpt, cin, h, w_, 3, 3, 1, 1, 1, res=x, res_mask=msk)
-            t_mix = time_kernel(step_mix) / 9.0
-            out[name]['step_mix_s'] = t_mix
-            out[name]['step_mix_tflops'] = flops / t_mix / 1e12
+    def step_mix():
+        for _ in range(3):
+            ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1, bn_partial=buf)
+        for _ in range(2):
+            ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1, bn_partial=buf, in_scale=sc, in_shift=sh, relu_in=True)
+        for _ in range(2):
+            ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1)
+        for _ in range(2):
+            ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1, res=x, res_mask=msk)
+    out['step_mix_s'] = time_kernel(step_mix) / 9.0
     return out
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The CPU oracle (oracle/: numpy front-end + PyTorch-CPU ResNet18 S=8, Adam) on the host cores: the same
-    step on a bounded sample (1 warm-up + up to 3 timed steps of batch 8)."""
-    import numpy as np
-    from oracle import features_ref, models_ref
+def roofline_conv(device, batch, h, w, cin, cout, k):
+    """A valid k x k convolution (scalar models' conv_b5: the tile kernel, conv_igemm_kernel)."""
+    import torch
+    from deep_audio_mixer_amd import ops
+    x = torch.randn((batch, h, w, cin), device=device)
+    wt = torch.randn((cout, cin, k, k), device=device) * 0.02
+    wp = ops.pack_weights(wt)
+    ho, wo = h - k + 1, w - k + 1
+    dy = torch.randn((batch, ho, wo, cout), device=device)
+    flops = 2.0 * batch * ho * wo * cout * k * k * cin
+    return {'flops_per_launch': flops, 'alg_bytes_per_launch': 4.0 * batch * (h * w * cin + ho * wo * cout),
+            'fwd_s': time_kernel(lambda: ops.conv2d_fwd(x, wp, cout, k, k, 1, 0, 1), iters=10, warm=3),
+            'wgrad_s': time_kernel(lambda: ops.conv2d_wgrad(x, dy, cout, k, k, 1, 0, 1), iters=10, warm=3)}
+
+
+def roofline_object(name, cfg, device, t_frames):
+    if cfg['model'] == 'resnet':
+        k = roofline_resnet_layer1(device, cfg['batch'], t_frames)
+        train = name != 'C5'
+        t = k['step_mix_s'] if train else k['fwd_s']
+        tf = k['flops_per_launch'] / t / 1e12
+        kern = ('conv_strip_kernel<4,1,1,true> (ResNet layer1 3x3 conv 16->16, %dx1025x%d px: ' % (cfg['batch'], t_frames) +
+                ('5 forward + 4 dgrad launches per step)' if train else 'forward launches of the eval-mode chunk batch)'))
+        # traffic: measured in a SEPARATE rocprofv3 --pmc run (bench.py cannot read PMC counters of its own launches);
+        # the figure below was taken at batch 8 on the forward launch of this kernel at the commit named in traffic_source
+        obj = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_MFMA / 1e12, 'unit': 'TFLOP/s', 'frac': tf * 1e12 / PEAK_F32_MFMA,
+               'traffic': 139.9e6 if cfg['batch'] == 8 else None,
+               'traffic_source': 'profiles/r01_layer1_conv_wgrad_pmc.csv @ commit 4f2ad47 (FETCH_SIZE 36,648 KB x 2 for the '
+                                 'gfx950 halving of wide coalesced reads + WRITE_SIZE 66,625 KB, forward launch, batch 8); '
+                                 'constant, not re-measured by this run',
+               'kernel': kern, 'avg_launch_s': t, 'flops_per_launch': k['flops_per_launch'],
+               'forward_only': {'avg_launch_s': k['fwd_s'], 'achieved': k['flops_per_launch'] / k['fwd_s'] / 1e12,
+                                'frac': k['flops_per_launch'] / k['fwd_s'] / PEAK_F32_MFMA},
+               'wgrad': {'avg_launch_s': k['wgrad_s'], 'achieved': k['flops_per_launch'] / k['wgrad_s'] / 1e12},
+               'hbm_alg_bytes_per_launch': k['alg_bytes_per_launch'],
+               'hbm_alg_GBps': k['alg_bytes_per_launch'] / t / 1e9,
+               'hbm_frac_of_8TBps': k['alg_bytes_per_launch'] / t / PEAK_HBM}
+        return obj
+    # scalar models: conv_b5 (9x9, 64 -> 128) is 60 % of the forward FLOPs
+    f, t = N_FFT // 2 + 1, t_frames
+    dil = 2 if cfg['model'] == 'scalar_2s' else 1
+    f, t = (f - dil * 2 - 1) // 2 + 1, (t - dil * 2 - 1) // 2 + 1          # conv_b1 (k3 s2, dilated in the 2 s model)
+    for kk in (5, 5, 7):
+        f, t = f - kk + 1, t - kk + 1
+    k = roofline_conv(device, cfg['batch'], f, t, 64, 128, 9)
+    tf = k['flops_per_launch'] / k['fwd_s'] / 1e12
+    return {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_MFMA / 1e12, 'unit': 'TFLOP/s', 'frac': tf * 1e12 / PEAK_F32_MFMA,
+            'traffic': None, 'kernel': 'conv_igemm_kernel (conv_b5: 9x9 valid conv 64->128 on %dx%dx%d px, forward launch)'
+                                       % (cfg['batch'], f, t),
+            'avg_launch_s': k['fwd_s'], 'flops_per_launch': k['flops_per_launch'],
+            'wgrad': {'avg_launch_s': k['wgrad_s'], 'achieved': k['flops_per_launch'] / k['wgrad_s'] / 1e12},
+            'hbm_alg_bytes_per_launch': k['alg_bytes_per_launch']}
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def host_cores():
+    """(threads to use, os.cpu_count()): the cgroup CPU quota when there is one (a 1-GPU box grants a share of the
+    host), else the affinity mask."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = min(avail, 16)          # a 1-GPU box grants a 16-core share; more threads only oversubscribe
+    quota = None
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            quota = max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    return (min(avail, quota) if quota else avail), (os.cpu_count() or avail)
+
+
+class _CpuClipFeatures:
+    """Dataset of the 6-worker leg: item = the oracle's features of one clip (data/dataset.py:185-210 on the CPU)."""
+
+    def __init__(self, clips, hop):
+        self.clips, self.hop = clips, hop
+
+    def __len__(self):
+        return len(self.clips)
+
+    def __getitem__(self, i):
+        import torch
+        from oracle import features_ref
+        import numpy as np
+        x, gt = features_ref.clip_features(self.clips[i], N_FFT, self.hop, np.float32)
+        return torch.from_numpy(x), torch.from_numpy(gt)
+
+
+def cpu_baseline(cfg):
+    """the CPU oracle (oracle/: numpy front-end + PyTorch-CPU model, Adam) on the host cores,
+    same synthetic clips, float32; 2 warm-up + 5 timed steps, medians; legs: (a) front-end only, single process and with
+    the reference's DataLoader(num_workers=6) arrangement, (b) model train step only, (c) end to end."""
+    import numpy as np
+    import torch
+    from oracle import features_ref, models_ref
+    cores, visible = host_cores()
     torch.set_num_threads(cores)
+    S, B, hop = cfg['n_stems'], cfg['batch'], cfg['hop']
+    n = cfg['sr'] * cfg['seconds']
+    t = 1 + n // hop
     rng = np.random.default_rng(1234)
-    stems = (0.1 * rng.standard_normal((BATCH, N_STEMS, N_SAMPLES, CHANNELS))).astype(np.float32)
-    mix = (stems * np.linspace(0.5, 1.5, N_STEMS, dtype=np.float32)[None, :, None, None]).sum(1)
+    clips = np.empty((B, S + 1, n, CHANNELS), dtype=np.float32)
+    clips[:, :S] = 0.1 * rng.standard_normal((B, S, n, CHANNELS))
+    clips[:, S] = (clips[:, :S] * np.linspace(0.5, 1.5, S, dtype=np.float32)[None, :, None, None]).sum(1)
     torch.manual_seed(0)
-    model = models_ref.RefResNet18(n_stems=N_STEMS, input_shape=(N_FFT // 2 + 1, 1 + N_SAMPLES // HOP)).train()
+    ctor = {'resnet': models_ref.RefResNet18, 'scalar_1s': models_ref.RefMixingModelScalar1s,
+            'scalar_2s': models_ref.RefMixingModelScalar2s}[cfg['model']]
+    model = ctor(n_stems=S, input_shape=(N_FFT // 2 + 1, t)).train()
     opt = torch.optim.Adam(model.parameters(), weight_decay=1e-5)
 
     def step():
-        feats = [[features_ref.compute_features(stems[b, s].mean(1), N_FFT, HOP, np.float32) for s in range(N_STEMS)]
-                 for b in range(BATCH)]
-        gts = [features_ref.compute_features(mix[b].mean(1), N_FFT, HOP, np.float32) for b in range(BATCH)]
-        x, gt = torch.from_numpy(np.asarray(feats)), torch.from_numpy(np.asarray(gts))
-        models_ref.train_step_ref(model, opt, x, gt)
-
-    step()
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_all) < seconds_budget:
         t0 = time.perf_counter()
+        items = [features_ref.clip_features(clips[b], N_FFT, hop, np.float32) for b in range(B)]
+        x, gt = torch.from_numpy(np.stack([i[0] for i in items])), torch.from_numpy(np.stack([i[1] for i in items]))
+        t1 = time.perf_counter()
+        models_ref.train_step_ref(model, opt, x, gt)
+        return t1 - t0, time.perf_counter() - t1
+
+    warm, timed = 2, 5
+    t_all = time.perf_counter()
+    for _ in range(warm):
         step()
-        times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
-    frames = BATCH * N_STEMS * (1 + N_SAMPLES // HOP)
-    return {'value': frames / med, 'unit': 'stem-spectrogram-frames/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d timed steps (median) of batch %d: numpy STFT front-end + PyTorch-CPU ResNet18(S=8) fwd+MSE+bwd+Adam, f32'
-                      % (len(times), BATCH), 's_per_step': med}
+    parts = []
+    while len(parts) < timed and (len(parts) < 3 or time.perf_counter() - t_all < 40.0):
+        parts.append(step())
+    med = lambda v: sorted(v)[len(v) // 2]
+    fe, mo, e2e = med([p[0] for p in parts]), med([p[1] for p in parts]), med([p[0] + p[1] for p in parts])
+    frames = B * S * t
+    legs = {'front_end_single_process_s': fe, 'model_train_step_s': mo, 'end_to_end_s': e2e,
+            'front_end_single_process_frames_per_s': frames / fe, 'model_train_step_frames_per_s': frames / mo}
+    try:        # the reference's arrangement: 6 DataLoader workers computing features (training.ipynb cell 6)
+        loader = torch.utils.data.DataLoader(_CpuClipFeatures([clips[b % B] for b in range(4 * B)], hop), batch_size=B,
+                                             num_workers=6, shuffle=False)
+        it = iter(loader)
+        next(it)
+        t0 = time.perf_counter()
+        k = sum(1 for _ in it)
+        fe6 = (time.perf_counter() - t0) / max(k, 1)
+        legs['front_end_6_workers_s'] = fe6
+        legs['front_end_6_workers_frames_per_s'] = frames / fe6
+    except Exception as e:      # worker processes unavailable on this host: the leg is reported as missing, not invented
+        legs['front_end_6_workers_error'] = repr(e)[:200]
+    return {'value': frames / e2e, 'unit': 'stem-spectrogram-frames/s', 'cores': cores, 'cores_visible': visible,
+            'kind': 'port',
+            'sample': '%d warm-up + %d timed steps (medians) of batch %d: numpy STFT front-end + PyTorch-CPU %s(S=%d) '
+                      'fwd+MSE+bwd+Adam, f32, single process, %d torch threads' % (warm, len(parts), B, cfg['model'], S, cores),
+            's_per_step': e2e, 'legs': legs}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-roofline', action='store_true')
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ runs
+def dist_env():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
 
-    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+
+def run_train(name, cfg, args):
+    import torch
+    rank, world, local = dist_env()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
     n_dev = torch.cuda.device_count()
-    local = local % max(n_dev, 1)                      # rehearsal only: more ranks than GPUs share a device (gloo)
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+    backend = os.environ.get('DAM_DIST_BACKEND', 'nccl')     # 'nccl' is RCCL on ROCm; 'gloo' for 1-GPU rehearsals
+    if world > 1 and backend == 'nccl' and n_dev < world:
+        raise SystemExit('%d ranks but %d GPUs: RCCL needs one GPU per rank' % (world, n_dev))
+    dev_index = local % max(n_dev, 1)                  # gloo rehearsal only: more ranks than GPUs share a device
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = os.environ.get('DAM_DIST_BACKEND', 'nccl')     # 'nccl' is RCCL on ROCm; 'gloo' for 1-GPU rehearsals
         if backend == 'nccl':
             torch.distributed.init_process_group('nccl', device_id=device)
         else:
@@ -173,84 +333,203 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     from deep_audio_mixer_amd.engine import TrainStep
-    from deep_audio_mixer_amd.models.model_resnet import ResNet18
     from deep_audio_mixer_amd.optim import Adam
+    from deep_audio_mixer_amd import staging
 
-    torch.manual_seed(0)
-    frames_t = 1 + N_SAMPLES // HOP
-    model = ResNet18(n_stems=N_STEMS, input_shape=(N_FFT // 2 + 1, frames_t)).to(device).train()
+    S, B, hop = cfg['n_stems'], cfg['batch'], cfg['hop']
+    n = cfg['sr'] * cfg['seconds']
+    t_frames = 1 + n // hop
+    model = build_model(cfg, device)
     if world > 1:     # identical replicas: broadcast rank 0's parameters and buffers
         for t in list(model.parameters()) + list(model.buffers()):
             torch.distributed.broadcast(t.data, 0)
     opt = Adam(model.parameters(), weight_decay=1e-5, world_size=world)
-    n_resident = 4 * BATCH
-    stems, mix = synth_clips(n_resident, device, 1234 + rank)
-    step = TrainStep(model, opt, N_STEMS, N_SAMPLES, CHANNELS, BATCH, N_FFT, HOP, use_graph=not args.no_graph)
-    step.load_batch(stems[:BATCH], mix[:BATCH])
+    n_resident = 4 * B
+    clips = synth_clips(n_resident, S, n, device, 1234 + rank)
+    step = TrainStep(model, opt, S, n, CHANNELS, B, N_FFT, hop, use_graph=not args.no_graph, overlap=not args.no_overlap)
+    step.load_clips(clips[:B])
     step.capture(warmup=2)
 
     def run(k, first):
         for i in range(k):
-            j = ((first + i) % (n_resident // BATCH)) * BATCH
-            step.load_batch(stems[j:j + BATCH], mix[j:j + BATCH])      # device-to-device: inputs stay in HBM
+            j = ((first + i) % (n_resident // B)) * B
+            step.load_clips(clips[j:j + B])      # device-to-device: inputs stay in HBM
             step()
 
+    def timed(fn, k, first):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(k, first)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = tt.item()
+        return dt
+
     run(args.warmup, 0)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = tt.item()
+    dt = timed(run, args.steps, args.warmup)
     loss = step.loss.item()
     frames_per_step = step.frames_per_step * world
     value = frames_per_step * args.steps / dt
+    gflop_step = cfg['gflop_fwd'] * 2.98 * B            # fwd+bwd algorithmic FLOPs per rank and step (SURVEY 8d ratio)
 
     result = {
         'metric': 'stem-spectrogram-frames/sec (train)', 'value': value, 'unit': 'stem-spectrogram-frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'C3: model_resnet (ResNet18, 8 stems) train step incl. STFT front-end, 8-stem 3 s @ 44.1 kHz '
-                               'stereo clips, n_fft 2048 hop 1024 -> 8x1025x130 per clip',
-                   'batch_per_gpu': BATCH, 'global_batch': BATCH * world, 'parallelism': 'dp%d' % world,
-                   'hip_graph': not args.no_graph, 'final_loss': loss},
+        'config': {'workload': cfg['workload'], 'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                   'hip_graph': not args.no_graph, 'final_loss': loss, 'world_size': world, 'device_index': dev_index,
+                   'dist_backend': (backend if world > 1 else None),
+                   'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == 'nccl' else None,
+                   'grad_buckets': opt.n_buckets, 'allreduce_overlap': bool(step.staged)},
     }
+    if args.breakdown and world > 1:
+        result['breakdown'] = ddp_breakdown(step, device)
+    # the same steps fed from page-locked HOST memory (512 clips in pinned host memory): batch k+1 is uploaded on
+    # a copy stream while step k runs.  PCIe-inclusive: reported beside `value`, never as `value`.
+    if not args.no_host_stream:
+        n_host = max(2 * B, min(N_HOST_CLIPS, args.host_clips) // B * B)
+        host = torch.empty((n_host, S + 1, n, CHANNELS), dtype=torch.float32, pin_memory=True)
+        for lo in range(0, n_host, n_resident):
+            hi = min(lo + n_resident, n_host)
+            host[lo:hi].copy_(synth_clips(hi - lo, S, n, device, 99 + rank + lo))
+        stager = staging.BatchStager(host, B, device)
+
+        def run_streamed(k, first):
+            for _ in range(k):
+                step.load_clips(stager.next())
+                step()
+        run_streamed(max(2, args.warmup), 0)
+        dts = timed(run_streamed, args.steps, 0)
+        result['pcie_inclusive'] = {'value': frames_per_step * args.steps / dts, 'ms_per_step': 1e3 * dts / args.steps,
+                                    'host_clips_pinned': n_host, 'h2d_bytes_per_step': float(host[:B].numel() * 4),
+                                    'note': 'batch k+1 uploaded from page-locked host memory on a copy stream during step k'}
+        del host, stager
     if rank == 0 and not args.no_roofline:
-        probe = roofline_probe(device)
-        k = probe['layer1_conv3x3_16x16']
-        # fwd+bwd algorithmic FLOPs of the whole step (29.5 GFLOP per clip) over the step time
-        # traffic: HBM bytes per launch from the committed PMC passes on this kernel at this shape
-        # (profiles/r01_layer1_conv_wgrad_pmc.csv: FETCH_SIZE 36,648 KB x 2 [gfx950 halves wide coalesced reads] + WRITE_SIZE 66,625 KB)
-        # achieved = algorithmic FLOPs per launch / the average duration of ALL launches of this kernel in a step (the nine
-        # layer1-shaped launches timed as the step issues them: what `rocprofv3 --kernel-trace --stats` of this command
-        # averages for conv_strip_kernel<4,1,1,true>); the plain forward launch alone is roofline.forward_only
-        result['roofline'] = {'bound': 'mfma', 'achieved': k['step_mix_tflops'], 'peak': PEAK_F32_MFMA / 1e12,
-                              'unit': 'TFLOP/s', 'frac': k['step_mix_tflops'] * 1e12 / PEAK_F32_MFMA, 'traffic': 139.9e6,
-                              'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC on the forward launch, profiles/r01_layer1_conv_wgrad_pmc.csv)',
-                              'kernel': 'conv_strip_kernel<4,1,1,true> (ResNet layer1 3x3 conv 16->16, 8x1025x130 px: 5 forward + 4 dgrad launches per step)',
-                              'avg_launch_s': k['step_mix_s'], 'flops_per_launch': k['flops_per_launch'],
-                              'forward_only': {'avg_launch_s': k['fwd_s'], 'achieved': k['fwd_tflops'],
-                                               'frac': k['fwd_tflops'] * 1e12 / PEAK_F32_MFMA},
-                              'hbm_alg_bytes_per_launch': k['alg_bytes_per_launch'],
-                              'hbm_alg_GBps': k['alg_bytes_per_launch'] / k['step_mix_s'] / 1e9,
-                              'hbm_frac_of_8TBps': k['alg_bytes_per_launch'] / k['step_mix_s'] / PEAK_HBM}
-        result['roofline_extra'] = {
-            'whole_step_tflops': 29.5e9 * BATCH * world * args.steps / dt / 1e12 / world,
-            'whole_step_frac_of_fp32_mfma_peak': 29.5e9 * BATCH * args.steps / dt / PEAK_F32_MFMA,
-            'kernels': probe}
+        result['roofline'] = roofline_object(name, cfg, device, t_frames)
+        result['roofline_extra'] = {'whole_step_tflops': gflop_step * 1e9 * args.steps / dt / 1e12,
+                                    'whole_step_frac_of_fp32_mfma_peak': gflop_step * 1e9 * args.steps / dt / PEAK_F32_MFMA}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline()
+        result['cpu_baseline'] = cpu_baseline(cfg)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def ddp_breakdown(step, device, iters=10):
+    """Where a multi-rank step spends its time: every phase bracketed by device synchronisation (diagnostic only)."""
+    import torch
+    if step._graphs is None or len(step._graphs) != 3:
+        return None
+    g, opt = step._graphs, step.opt
+    acc = {'graph_a1_ms': 0.0, 'allreduce_bucket1_ms': 0.0, 'graph_a2_ms': 0.0, 'allreduce_bucket0_ms': 0.0, 'graph_b_ms': 0.0}
+
+    def phase(key, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        acc[key] += (time.perf_counter() - t0) * 1e3 / iters
+    for _ in range(iters):
+        phase('graph_a1_ms', g[0].replay)
+        phase('allreduce_bucket1_ms', lambda: opt.all_reduce_grads(1))
+        phase('graph_a2_ms', g[1].replay)
+        phase('allreduce_bucket0_ms', lambda: opt.all_reduce_grads(0))
+        phase('graph_b_ms', g[2].replay)
+    acc['bucket_bytes'] = [int(opt.bucket_view(b).numel() * 4) for b in range(opt.n_buckets)]
+    return acc
+
+
+def run_inference(name, cfg, args):
+    """C5: one "step" = one whole song through the captured graph (PCM resident in HBM): strided front-end over 59 x 8
+    chunk tracks -> ResNet18 (eval) on the chunk batch -> gains -> Savitzky-Golay -> fused mixdown + peak normalise."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    torch.cuda.set_device(0)
+    device = torch.device('cuda', 0)
+    import deep_audio_mixer_amd  # noqa: F401
+    from deep_audio_mixer_amd import build, inference_utils
+    build.build_lib()
+    S, sr = cfg['n_stems'], cfg['sr']
+    n = sr * cfg['song_seconds']
+    chunk = sr * cfg['seconds']
+    model = build_model(cfg, device, train=False)
+    mixer = inference_utils.SongMixer(model, S, CHANNELS, n, torch.float32, chunk, 'master', True, torch.float32)
+    g = torch.Generator(device=device).manual_seed(1234)
+    mixer.pcm.copy_(0.1 * torch.randn(mixer.pcm.shape, generator=g, device=device))
+    for _ in range(max(1, args.warmup)):
+        mixer.launch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mixer.launch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t_frames = 1 + chunk // cfg['hop']
+    frames = mixer.n_proc * S * t_frames
+    result = {
+        'metric': 'stem-spectrogram-frames/sec (inference)', 'value': frames * args.steps / dt,
+        'unit': 'stem-spectrogram-frames/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': cfg['workload'], 'chunks': mixer.n_proc, 'hip_graph': mixer.graph is not None,
+                   'savgol_window': mixer.window},
+    }
+    # PCIe-inclusive: host arrays in, normalised master out (page-locked double-buffered staging both ways)
+    rng = np.random.default_rng(0)
+    tracks = [(0.1 * rng.standard_normal((CHANNELS, n))).astype(np.float32) for _ in range(S)]
+    mixer.run(tracks)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        mixer.run(tracks)
+    dth = (time.perf_counter() - t0) / reps
+    result['pcie_inclusive'] = {'ms_per_song': 1e3 * dth, 'value': frames / dth,
+                                'h2d_bytes': float(S * CHANNELS * n * 4), 'd2h_bytes': float(CHANNELS * n * 4)}
+    if not args.no_roofline:
+        result['roofline'] = roofline_object(name, cfg, device, t_frames)
+        result['roofline_extra'] = {'whole_step_tflops': cfg['gflop_fwd'] * mixer.n_proc * 1e9 * args.steps / dt / 1e12}
+    print(json.dumps(result), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='C3')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='N > 1: one un-overlapped all-reduce of the whole flat buffer')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-host-stream', action='store_true')
+    ap.add_argument('--host-clips', type=int, default=N_HOST_CLIPS)
+    ap.add_argument('--breakdown', action='store_true', help='N > 1: add per-phase timings of the step (diagnostic)')
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    world_env = os.environ.get('WORLD_SIZE')
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))            # before any GPU call in this process
+    world = int(world_env) if world_env is not None else 1
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    cfg = CONFIGS[args.config]
+    if args.config == 'C5':
+        if world != 1:
+            raise SystemExit('C5 (one song) runs on one GPU; songs shard over ranks as independent replicas')
+        run_inference(args.config, cfg, args)
+    else:
+        run_train(args.config, cfg, args)
 
 
 if __name__ == '__main__':

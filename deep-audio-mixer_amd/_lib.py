@@ -21,6 +21,9 @@ SIGNATURES = {
     'dam_stft_twiddle_count': (c_i64, [c_i]),
     'dam_stft_fill_twiddles_host': (c_i, [c_i, c_p]),
     'dam_stft_logmag_f32': (c_i, [c_p, c_i, c_i64, c_i64, c_i, c_i64, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p]),
+    'dam_stft_logmag_strided_f32': (c_i, [c_p, c_i, c_i64, c_i64, c_i64, c_i64, c_i64, c_i, c_i64, c_i64, c_p, c_p, c_p,
+                                          c_i, c_i, c_f, c_i, c_p, c_p, c_i, c_p]),
+    'dam_augment_gains_f32': (c_i, [ctypes.c_uint64, c_p, c_i64, c_i, c_i, c_f, c_f, c_p, c_p]),
     'dam_conv_packed_weight_count': (c_i64, [c_i, c_i, c_i, c_i]),
     'dam_conv_pack_weights_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'dam_conv_pack_weights_multi_f32': (c_i, [c_p, c_i, c_i64, c_p]),
@@ -45,10 +48,11 @@ SIGNATURES = {
     'dam_masksum_workspace_floats': (c_i64, [c_i, c_i]),
     'dam_masksum_bwd_f32': (c_i, [c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p]),
     'dam_masksum_mse_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p, c_p]),
-    'dam_adam_l2_step_f32': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
-    'dam_gain_ramp_apply': (c_i, [c_p, c_p, c_i, c_i64, c_i64, c_i, c_p, c_p]),
+    'dam_adam_l2_step_f32': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
+    'dam_gains_smooth': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'dam_gain_ramp_apply': (c_i, [c_p, c_i, c_p, c_i64, c_i64, c_i64, c_i, c_p, c_i, c_p]),
     'dam_mixdown_workspace_elems': (c_i64, [c_i64]),
-    'dam_mixdown_peak_normalize': (c_i, [c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    'dam_mixdown_peak_normalize': (c_i, [c_p, c_i, c_p, c_i, c_i64, c_i64, c_i, c_i, c_p, c_i, c_p, c_p]),
     'dam_nchw_to_nhwc16_f32': (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p]),
     'dam_loudness_kweight_coeffs': (c_i, [c_d, c_p]),
     'dam_loudness_workspace_bytes': (c_i64, [c_i64, c_i]),

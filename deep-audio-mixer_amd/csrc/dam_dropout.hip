@@ -40,8 +40,33 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, int64_t n4, fl
     }
 }
 
+// The augmentation draw of data/dataset.py:164-168 (`np.random.uniform(0.6, 1.4) * audio`, one draw per track of an
+// item, the mix included :198-199) as a counter-based function of (seed, global item index, track): reproducible whatever
+// the batch composition, the worker count or the rank sharding, and drawn where the STFT kernel consumes it.
+//   u = top 24 bits of splitmix64(seed * K + item * 4096 + track) / 2^24;  gain = lo + (hi - lo) * u
+__global__ void augment_gains_kernel(unsigned long long seed, const long long* __restrict__ items, long long first_item,
+                                     int n_items, int n_tracks, float lo, float hi, float* __restrict__ gains) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items * n_tracks) return;
+    const int it = i / n_tracks, k = i - it * n_tracks;
+    const unsigned long long item = (unsigned long long)(items ? items[it] : first_item + it);
+    const unsigned r = mix64(seed * 0xD1342543DE82EF95ull + item * 4096ull + (unsigned long long)k);
+    gains[i] = lo + (hi - lo) * ((float)(r >> 8) * (1.0f / 16777216.0f));
+}
+
 }  // namespace
 }  // namespace dam
+
+extern "C" int dam_augment_gains_f32(uint64_t seed, const int64_t* items, int64_t first_item, int n_items, int n_tracks,
+                                     float lo, float hi, float* gains, void* stream) {
+    if (!gains || n_items <= 0 || n_tracks <= 0 || n_tracks > 4096 || !(hi >= lo)) return DAM_ERR_BAD_ARG;
+    const int total = n_items * n_tracks;
+    hipLaunchKernelGGL(dam::augment_gains_kernel, dim3((unsigned)dam::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long)seed, (const long long*)items, (long long)first_item, n_items, n_tracks, lo, hi,
+                       gains);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
 
 extern "C" int dam_dropout_tick(int64_t* counter, int64_t n, int64_t* snapshot, void* stream) {
     if (!counter || !snapshot || n <= 0) return DAM_ERR_BAD_ARG;

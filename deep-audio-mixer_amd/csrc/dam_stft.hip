@@ -61,24 +61,31 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 }
 __device__ __forceinline__ constexpr int fft16_pos(int k) { return 4 * (k & 3) + (k >> 2); }
 
-template <typename PCM, int CH>
-__device__ __forceinline__ float mono_at(const PCM* __restrict__ trk, int64_t p) {
+// Channel layouts: interleaved (PLANAR = false: sample p of channel c at trk[CH*p + c], what soundfile / a WAV decoder
+// hands over) and planar (PLANAR = true: trk[c*cs + p], the [channels, n] arrays inference_utils.py works on).
+template <typename PCM, int CH, bool PLANAR>
+__device__ __forceinline__ float mono_at(const PCM* __restrict__ trk, int64_t cs, int64_t p) {
     if (CH == 1) return (float)trk[p];
+    if (PLANAR) return (float)((trk[p] + trk[cs + p]) * (PCM)0.5);
     return (float)((trk[2 * p] + trk[2 * p + 1]) * (PCM)0.5);
 }
 
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+
 // Loads complex point (x[p], x[p+1]) of the reflect-padded mono signal; interior = no mirroring.
-template <typename PCM, int CH>
-__device__ __forceinline__ float2 load_pair_interior(const PCM* __restrict__ trk, int64_t p) {
-    if constexpr (CH == 2 && sizeof(PCM) == 4) {
+template <typename PCM, int CH, bool PLANAR>
+__device__ __forceinline__ float2 load_pair_interior(const PCM* __restrict__ trk, int64_t cs, int64_t p) {
+    if constexpr (CH == 2 && sizeof(PCM) == 4 && !PLANAR) {
         f32x4_u q = *reinterpret_cast<const f32x4_u*>(trk + 2 * p);
         return make_float2((q.x + q.y) * 0.5f, (q.z + q.w) * 0.5f);
+    } else if constexpr (CH == 2 && sizeof(PCM) == 4 && PLANAR) {
+        f32x2_u a = *reinterpret_cast<const f32x2_u*>(trk + p), b = *reinterpret_cast<const f32x2_u*>(trk + cs + p);
+        return make_float2((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f);
     } else if constexpr (CH == 1 && sizeof(PCM) == 4) {
-        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-        f2u q = *reinterpret_cast<const f2u*>(trk + p);
+        f32x2_u q = *reinterpret_cast<const f32x2_u*>(trk + p);
         return make_float2(q.x, q.y);
     } else {
-        return make_float2(mono_at<PCM, CH>(trk, p), mono_at<PCM, CH>(trk, p + 1));
+        return make_float2(mono_at<PCM, CH, PLANAR>(trk, cs, p), mono_at<PCM, CH, PLANAR>(trk, cs, p + 1));
     }
 }
 __device__ __forceinline__ int64_t reflect(int64_t p, int64_t n) {
@@ -92,11 +99,12 @@ __device__ __forceinline__ float to_db(float m, float amin, float floor_db) {
     return m <= amin ? floor_db : 20.0f * log10f(m);
 }
 
-template <typename PCM, int CH>
+template <typename PCM, int CH, bool PLANAR>
 __global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
-    const PCM* __restrict__ pcm, int64_t n_samples, int64_t track_stride, const float* __restrict__ window,
+    const PCM* __restrict__ pcm, int64_t n_samples, int64_t outer_stride, int n_inner, int64_t inner_stride, int64_t cs,
+    const float* __restrict__ window,
     const float2* __restrict__ tw /* W_2048^k */, const float* __restrict__ gain, int hop, int n_frames,
-    float amin, float floor_db, int normalize, float* __restrict__ out) {
+    float amin, float floor_db, int normalize, float* __restrict__ out, float* __restrict__ out_tail, int n_tail) {
     __shared__ __attribute__((aligned(16))) float2 scratch_all[STFT_WAVES * SCRATCH];
     __shared__ float tile[NBINS * TF];
     __shared__ float colmax[TF * TF];
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t track = blockIdx.y;
     const int t0 = blockIdx.x * TF;
-    const PCM* trk = pcm + track * track_stride;
+    const PCM* trk = pcm + (track / n_inner) * outer_stride + (track % n_inner) * inner_stride;
     float2* S = scratch_all + wave * SCRATCH;
     const float g = gain ? gain[track] : 1.0f;
 
@@ -133,8 +141,15 @@ __global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
         if (PREFETCH && frame_interior(t)) {
             const int64_t p0 = (int64_t)t * hop - NFFT / 2;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1)
-                rawn[n1] = *reinterpret_cast<const raw_t*>(trk + (int64_t)CH * (p0 + 2 * (lane + 64 * n1)));
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int64_t p = p0 + 2 * (lane + 64 * n1);
+                if constexpr (PLANAR && CH == 2) {
+                    const f32x2_u a = *reinterpret_cast<const f32x2_u*>(trk + p), b = *reinterpret_cast<const f32x2_u*>(trk + cs + p);
+                    rawn[n1] = (raw_t){a.x, b.x, a.y, b.y};
+                } else {
+                    rawn[n1] = *reinterpret_cast<const raw_t*>(trk + (int64_t)CH * p);
+                }
+            }
         }
     };
     issue_frame(t0 + wave);
@@ -153,13 +168,13 @@ __global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
             }
         } else if (p0 >= 0 && p0 + NFFT <= n_samples) {
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) v[n1] = load_pair_interior<PCM, CH>(trk, p0 + 2 * (lane + 64 * n1));
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = load_pair_interior<PCM, CH, PLANAR>(trk, cs, p0 + 2 * (lane + 64 * n1));
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
                 const int64_t p = p0 + 2 * (lane + 64 * n1);
-                v[n1] = make_float2(mono_at<PCM, CH>(trk, reflect(p, n_samples)),
-                                    mono_at<PCM, CH>(trk, reflect(p + 1, n_samples)));
+                v[n1] = make_float2(mono_at<PCM, CH, PLANAR>(trk, cs, reflect(p, n_samples)),
+                                    mono_at<PCM, CH, PLANAR>(trk, cs, reflect(p + 1, n_samples)));
             }
         }
         if (q + 1 < TF / STFT_WAVES) issue_frame(t + STFT_WAVES);     // in flight during this frame's FFT
@@ -250,7 +265,11 @@ __global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
         scale = m;
     }
     if (col_ok) {
-        float* o = out + (track * NBINS) * (int64_t)n_frames + t0 + tl;
+        // the last n_tail tracks of every outer group go to out_tail (dataset item = (stems, mix), data/dataset.py:207-210)
+        const int64_t og = track / n_inner;
+        const int ig = (int)(track % n_inner), n_main = n_inner - n_tail;
+        float* o = (ig < n_main ? out + ((og * n_main + ig) * NBINS) * (int64_t)n_frames
+                                : out_tail + ((og * n_tail + (ig - n_main)) * NBINS) * (int64_t)n_frames) + t0 + tl;
         for (int f = f0; f < NBINS; f += 16) {
             float vdb = tile[f * TF + (tl ^ (f & 15))];
             if (normalize && scale >= 1.17549435e-38f) vdb = vdb / scale;
@@ -274,30 +293,57 @@ extern "C" int dam_stft_fill_twiddles_host(int n_fft, float* table_host) {
     return DAM_OK;
 }
 
-extern "C" int dam_stft_logmag_f32(const void* pcm, int pcm_dtype, int64_t n_tracks, int64_t n_samples, int channels,
-                                   int64_t pcm_track_stride, const float* window, const float* twiddles,
-                                   const float* gain, int n_fft, int hop, float amin, int normalize, float* out,
-                                   void* stream) {
+extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64_t n_outer, int64_t outer_stride,
+                                           int64_t n_inner, int64_t inner_stride, int64_t n_samples, int channels,
+                                           int64_t sample_stride, int64_t channel_stride, const float* window,
+                                           const float* twiddles, const float* gain, int n_fft, int hop, float amin,
+                                           int normalize, float* out, float* out_tail, int n_tail, void* stream) {
     using namespace dam;
-    if (!pcm || !window || !twiddles || !out || n_tracks <= 0 || hop <= 0) return DAM_ERR_BAD_ARG;
+    if (!pcm || !window || !twiddles || !out || n_outer <= 0 || n_inner <= 0 || hop <= 0) return DAM_ERR_BAD_ARG;
+    if (n_tail < 0 || n_tail >= n_inner || (n_tail > 0 && !out_tail)) return DAM_ERR_BAD_ARG;
     if (n_samples <= n_fft / 2) return DAM_ERR_BAD_ARG;   // reflect padding needs N > n_fft/2 (torch.stft raises too)
     if (n_fft != NFFT || (hop & 1) || (channels != 1 && channels != 2)) return DAM_ERR_UNSUPPORTED;
     if (pcm_dtype != DAM_PCM_F32 && pcm_dtype != DAM_PCM_F64) return DAM_ERR_UNSUPPORTED;
-    if (n_tracks > 65535) return DAM_ERR_UNSUPPORTED;
+    const int64_t n_tracks = n_outer * n_inner;
+    if (n_tracks > 65535 || n_inner > 0x7fffffff) return DAM_ERR_UNSUPPORTED;
+    bool planar;
+    if (channels == 1) {
+        if (sample_stride != 1) return DAM_ERR_UNSUPPORTED;
+        planar = false;
+    } else if (sample_stride == channels && channel_stride == 1) {
+        planar = false;
+    } else if (sample_stride == 1 && channel_stride >= n_samples) {
+        planar = true;
+    } else {
+        return DAM_ERR_UNSUPPORTED;
+    }
     const int n_frames = (int)(1 + n_samples / hop);
     dim3 grid((unsigned)cdiv(n_frames, TF), (unsigned)n_tracks), block(STFT_WAVES * WAVE);
     hipStream_t s = (hipStream_t)stream;
     const float2* tw = reinterpret_cast<const float2*>(twiddles);
     const float floor_db = (float)(20.0 * log10((double)amin));
-#define DAM_STFT_LAUNCH(T, C)                                                                          \
-    hipLaunchKernelGGL((stft_logmag_kernel<T, C>), grid, block, 0, s, (const T*)pcm, n_samples,        \
-                       pcm_track_stride, window, tw, gain, hop, n_frames, amin, floor_db, normalize, out)
+#define DAM_STFT_LAUNCH(T, C, P)                                                                              \
+    hipLaunchKernelGGL((stft_logmag_kernel<T, C, P>), grid, block, 0, s, (const T*)pcm, n_samples, outer_stride, \
+                       (int)n_inner, inner_stride, channel_stride, window, tw, gain, hop, n_frames, amin, floor_db, \
+                       normalize, out, out_tail, n_tail)
     if (pcm_dtype == DAM_PCM_F32) {
-        if (channels == 2) DAM_STFT_LAUNCH(float, 2); else DAM_STFT_LAUNCH(float, 1);
+        if (channels == 1) DAM_STFT_LAUNCH(float, 1, false);
+        else if (planar) DAM_STFT_LAUNCH(float, 2, true);
+        else DAM_STFT_LAUNCH(float, 2, false);
     } else {
-        if (channels == 2) DAM_STFT_LAUNCH(double, 2); else DAM_STFT_LAUNCH(double, 1);
+        if (channels == 1) DAM_STFT_LAUNCH(double, 1, false);
+        else if (planar) DAM_STFT_LAUNCH(double, 2, true);
+        else DAM_STFT_LAUNCH(double, 2, false);
     }
 #undef DAM_STFT_LAUNCH
     DAM_CHECK_LAUNCH();
     return DAM_OK;
+}
+
+extern "C" int dam_stft_logmag_f32(const void* pcm, int pcm_dtype, int64_t n_tracks, int64_t n_samples, int channels,
+                                   int64_t pcm_track_stride, const float* window, const float* twiddles,
+                                   const float* gain, int n_fft, int hop, float amin, int normalize, float* out,
+                                   void* stream) {
+    return dam_stft_logmag_strided_f32(pcm, pcm_dtype, n_tracks, pcm_track_stride, 1, 0, n_samples, channels, channels, 1,
+                                       window, twiddles, gain, n_fft, hop, amin, normalize, out, nullptr, 0, stream);
 }

@@ -12,7 +12,10 @@ Same constructor, ``__getitem__(i) -> (train_features [S,1025,T], gt_features [1
   * ``normalize=True`` enables the per-frame max-abs normalisation that is commented out at :159-160 (SURVEY F6);
   * ``compute_features=False`` reads the pre-computed feature cache written by ``_precompute_features()``; reader and
     writer agree on the writer's file names (they do not at the reference HEAD, SURVEY F10);
-  * ``tracklist`` may name any number of stems (last entry = the target mix).
+  * ``tracklist`` may name any number of stems (last entry = the target mix);
+  * ``iter_batches(batch_size)`` is the batched ingest path: WAV chunks are decoded by a thread pool straight into
+    page-locked staging buffers, travel on a copy stream while the previous batch is in use, and all B*(S+1) tracks of
+    a batch go through ONE front-end launch (the per-item ``__getitem__`` + DataLoader path stays for drop-in use).
 """
 import os
 import random
@@ -40,6 +43,7 @@ class MultitrackAudioDataset(data.Dataset):
         self._device = torch.device(device) if device is not None else torch.device('cuda')
         self._verbose = verbose
         self._arrays = _arrays
+        self._aug_seed = seed if seed else 0          # device-side augmentation draws are keyed by (seed, item, track)
         if _arrays is not None and not songlist:
             songlist = list(_arrays.keys())
         if not songlist:
@@ -63,12 +67,13 @@ class MultitrackAudioDataset(data.Dataset):
         return wav_num_frames(self._get_track_path(song_name, self._tracklist[-1]))
 
     def _calculate_dataset_length(self) -> tuple:
+        """data/dataset.py:56-75: whole seconds of the mix, trimmed to a multiple of the chunk length."""
         total, durations = 0, []
         for song_name in self.songlist:
             n, sr = self._track_frames(song_name)
-            dur = n / sr
-            durations.append(dur)
-            total += int(dur / self._chunk_length)
+            seconds = int(n / sr)
+            durations.append(seconds - seconds % self._chunk_length)
+            total += int(seconds / self._chunk_length)
         return total, durations
 
     def _get_track_path(self, song_name: str, track_name: str) -> str:
@@ -117,7 +122,7 @@ class MultitrackAudioDataset(data.Dataset):
             return np.asarray(self._arrays[song_name][track_name][lo:hi])
         return read_wav(self._get_track_path(song_name, track_name), lo, hi)[0]
 
-    def _process_on_the_fly(self, song_i: int, chunk_i: int) -> tuple:
+    def _process_on_the_fly(self, song_i: int, chunk_i: int, index: int = None) -> tuple:
         """data/dataset.py:185-210: all S+1 tracks of the chunk go through ONE front-end launch."""
         song_name = self.songlist[song_i]
         lo, hi = chunk_i * self._chunk_length * self._sr, (chunk_i + 1) * self._chunk_length * self._sr
@@ -125,10 +130,74 @@ class MultitrackAudioDataset(data.Dataset):
         chunks = [c[:, None] if c.ndim == 1 else c for c in chunks]
         pcm = torch.from_numpy(np.stack(chunks)).to(self._device)          # [S+1, n, channels]
         gain = None
-        if self._augment:        # one draw per track, the mix included (data/dataset.py:198-199)
-            gain = torch.tensor(np.random.uniform(0.6, 1.4, size=len(chunks)), dtype=torch.float32, device=self._device)
+        if self._augment:        # one draw per track, the mix included (data/dataset.py:198-199): drawn on the device,
+            # reproducibly, keyed by (dataset seed, global item index, track) instead of numpy's global state
+            item = index if index is not None else sum(int(d / self._chunk_length) for d in self.song_durations[:song_i]) + chunk_i
+            gain = features.augment_gains(self._aug_seed, len(chunks), first_item=item, n_items=1, device=self._device)[0]
         feats = features.stft_logmag(pcm, 2048, 1024, gain=gain, normalize=self._normalize)
         return feats[:-1], feats[-1]
+
+    # ---- batched ingest: decode threads -> page-locked staging -> copy stream -> one front-end launch per batch
+    def iter_batches(self, batch_size, indices=None, workers=8, drop_last=False):
+        """Yields (train_features [B,S,1025,T], gt_features [B,1025,T]) float32 CUDA tensors for consecutive groups of
+        `batch_size` items of `indices` (default: every item, in order) -- what ``DataLoader(self, batch_size)`` yields,
+        with the reads of data/dataset.py:192-196 done by `workers` threads into page-locked memory, the upload of batch
+        k+1 overlapped with the consumer's work on batch k, and the augmentation gains (data/dataset.py:198-199) drawn
+        on the device per (seed, item, track)."""
+        from concurrent.futures import ThreadPoolExecutor
+        idx = list(range(len(self))) if indices is None else [int(i) for i in indices]
+        groups = [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]
+        if drop_last and groups and len(groups[-1]) < batch_size:
+            groups.pop()
+        if not groups:
+            return
+        K, n = len(self._tracklist), self._chunk_length * self._sr
+        first = self._read_chunk_f32(self.songlist[self._calculate_song_index(idx[0])[0]], self._tracklist[0], 0, 1)
+        ch = first.shape[1]
+        host = [torch.empty((batch_size, K, n, ch), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        dev = [torch.empty((batch_size, K, n, ch), dtype=torch.float32, device=self._device) for _ in range(2)]
+        uploaded = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        copy_stream = torch.cuda.Stream(device=self._device)
+
+        def decode(slot, group):
+            view = host[slot].numpy()
+
+            def one(job):
+                b, k, item = job
+                song_i, chunk_i = self._calculate_song_index(item)
+                a = self._read_chunk_f32(self.songlist[song_i], self._tracklist[k], chunk_i * n, (chunk_i + 1) * n)
+                view[b, k] = a
+            list(pool.map(one, [(b, k, item) for b, item in enumerate(group) for k in range(K)]))
+
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            cur = torch.cuda.current_stream(self._device)
+            uploaded[0].synchronize()
+            decode(0, groups[0])
+            for j, group in enumerate(groups):
+                slot, B = j % 2, len(group)
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(consumed[slot])            # the launch that read dev[slot] two batches ago
+                    dev[slot][:B].copy_(host[slot][:B], non_blocking=True)
+                    uploaded[slot].record(copy_stream)
+                if j + 1 < len(groups):                                # decode the next batch while this one travels
+                    uploaded[1 - slot].synchronize()                   # its previous upload has left the host buffer
+                    decode(1 - slot, groups[j + 1])
+                cur = torch.cuda.current_stream(self._device)
+                cur.wait_event(uploaded[slot])
+                gain = None
+                if self._augment:
+                    gain = features.augment_gains(self._aug_seed, K, items=group, device=self._device)
+                x, gt = features.stft_logmag_clips(dev[slot][:B], 2048, 1024, gain=gain, normalize=self._normalize)
+                consumed[slot].record(cur)
+                yield x, gt
+
+    def _read_chunk_f32(self, song_name, track_name, lo, hi):
+        if self._arrays is not None:
+            a = np.asarray(self._arrays[song_name][track_name][lo:hi], dtype=np.float32)
+        else:
+            a = read_wav(self._get_track_path(song_name, track_name), lo, hi, dtype=np.float32)[0]
+        return a[:, None] if a.ndim == 1 else a
 
     # ---- pre-computed feature cache (data/dataset.py:213-268).  The reference's writer emits
     #      {song}_FEATURES/{i}_train_{len}s[_norm].npy / {i}_gt_{len}s[_norm].npy while its reader looks for
@@ -171,7 +240,7 @@ class MultitrackAudioDataset(data.Dataset):
         if not self._compute_features:
             return self._process_precomputed(song_i, chunk_i)
         tic = time.time()
-        train_features, gt_features = self._process_on_the_fly(song_i, chunk_i)
+        train_features, gt_features = self._process_on_the_fly(song_i, chunk_i, index)
         if self._verbose:
             print('Features: {}'.format(time.time() - tic))
         return train_features, gt_features

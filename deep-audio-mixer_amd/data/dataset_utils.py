@@ -1,6 +1,6 @@
 """Mirror of the reference's data/dataset_utils.py helpers that sit on the path."""
 import os
-import wave
+import struct
 
 import numpy as np
 
@@ -15,45 +15,139 @@ def scalar_dB_to_amplitude(x):
     return np.power(10.0, 0.5 * x)
 
 
-def read_wav(path, start=0, stop=None):
-    """PCM WAV -> (float64 [frames, channels] in [-1, 1), sample rate), with a partial read like
-    ``soundfile.read(path, start=, stop=)`` (data/dataset.py:194).  stdlib only (soundfile is not in the image);
-    8/16/24/32-bit integer PCM, the formats MedleyDB / MUSDB18-HQ ship."""
-    with wave.open(path, 'rb') as w:
-        n, ch, width, sr = w.getnframes(), w.getnchannels(), w.getsampwidth(), w.getframerate()
-        stop = n if stop is None else min(stop, n)
-        start = min(max(start, 0), stop)
-        w.setpos(start)
-        raw = w.readframes(stop - start)
+def split_songlist(songlist, train_val_test_split: tuple = (0.8, 0.2, 0.0), summary: bool = True) -> tuple:
+    """data/dataset_utils.py:6-36: random train / val / test split of a song list (numpy's global RNG, as the reference:
+    seed it with np.random.seed for a repeatable split).  Train and val are drawn without replacement in that order,
+    test is whatever is left."""
+    assert sum(train_val_test_split) == 1, 'train/val/test split should sum to 1'
+    sizes = [round(len(songlist) * share) for share in train_val_test_split]
+    pool, parts = set(songlist), []
+    for size in sizes[:2]:
+        drawn = list(np.random.choice(list(pool), size, replace=False))
+        pool = pool.difference(drawn)
+        parts.append(drawn)
+    parts.append(list(pool))
+    if summary:
+        print('Dataset split:')
+        print('=' * 80)
+        for k, (label, part) in enumerate(zip(('Train', 'Val', 'Test'), parts)):
+            if k:
+                print('-' * 80)
+            print('{}: {} tracks'.format(label, sizes[k]))
+            print(part)
+    return tuple(parts)
+
+
+# ---- WAV decoding (stands in for soundfile.read / librosa.load, which are not in the image) ------------------------
+_WAVE_FORMAT_PCM, _WAVE_FORMAT_IEEE_FLOAT, _WAVE_FORMAT_EXTENSIBLE = 1, 3, 0xFFFE
+_headers = {}
+
+
+def wav_header(path):
+    """Parses the RIFF chunks of a WAV file once: {'tag' (1 integer PCM / 3 IEEE float), 'channels', 'rate', 'bits',
+    'frame_bytes', 'data_offset', 'frames'}.  WAVE_FORMAT_EXTENSIBLE files (what DAWs write for 24-bit / multichannel
+    audio; the stdlib ``wave`` module rejects them) are resolved through their sub-format."""
+    st = os.stat(path)
+    key = (path, st.st_mtime_ns, st.st_size)
+    if key in _headers:
+        return _headers[key]
+    with open(path, 'rb') as fh:
+        riff = fh.read(12)
+        if len(riff) < 12 or riff[:4] != b'RIFF' or riff[8:12] != b'WAVE':
+            raise ValueError('%s is not a RIFF/WAVE file' % path)
+        fmt = data = None
+        while fmt is None or data is None:
+            hdr = fh.read(8)
+            if len(hdr) < 8:
+                break
+            cid, size = hdr[:4], struct.unpack('<I', hdr[4:])[0]
+            if cid == b'fmt ':
+                fmt = fh.read(size)
+                if size & 1:
+                    fh.seek(1, 1)
+            elif cid == b'data':
+                data = (fh.tell(), size)
+                fh.seek(size + (size & 1), 1)
+            else:
+                fh.seek(size + (size & 1), 1)
+    if fmt is None or data is None or len(fmt) < 16:
+        raise ValueError('%s: missing fmt or data chunk' % path)
+    tag, channels, rate, _, frame_bytes, bits = struct.unpack('<HHIIHH', fmt[:16])
+    if tag == _WAVE_FORMAT_EXTENSIBLE and len(fmt) >= 26:
+        tag = struct.unpack('<H', fmt[24:26])[0]          # first two bytes of the sub-format GUID
+    if tag not in (_WAVE_FORMAT_PCM, _WAVE_FORMAT_IEEE_FLOAT) or channels < 1 or frame_bytes != channels * ((bits + 7) // 8):
+        raise ValueError('%s: unsupported WAV encoding (format tag %d, %d bits)' % (path, tag, bits))
+    offset, size = data
+    size = min(size, st.st_size - offset)                  # streamed files may carry a placeholder size
+    h = dict(tag=tag, channels=channels, rate=rate, bits=bits, frame_bytes=frame_bytes, data_offset=offset,
+             frames=size // frame_bytes)
+    _headers[key] = h
+    return h
+
+
+def _decode(raw, h, dtype):
+    """Interleaved sample bytes -> dtype array in [-1, 1) with soundfile's integer normalisation (divide by 2^(bits-1))."""
+    tag, width = h['tag'], (h['bits'] + 7) // 8
+    if tag == _WAVE_FORMAT_IEEE_FLOAT:
+        if width not in (4, 8):
+            raise ValueError('unsupported float sample width %d' % width)
+        return np.frombuffer(raw, dtype='<f4' if width == 4 else '<f8').astype(dtype)
     if width == 2:
-        a = np.frombuffer(raw, dtype='<i2').astype(np.float64) / 32768.0
-    elif width == 4:
-        a = np.frombuffer(raw, dtype='<i4').astype(np.float64) / 2147483648.0
-    elif width == 3:
+        return np.frombuffer(raw, dtype='<i2').astype(dtype) / dtype(32768.0)
+    if width == 4:
+        return (np.frombuffer(raw, dtype='<i4').astype(np.float64) / 2147483648.0).astype(dtype)
+    if width == 3:
         b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
         v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
-        a = (v - ((v & 0x800000) << 1)).astype(np.float64) / 8388608.0
-    elif width == 1:
-        a = (np.frombuffer(raw, dtype=np.uint8).astype(np.float64) - 128.0) / 128.0
-    else:
-        raise ValueError('unsupported sample width %d in %s' % (width, path))
-    return a.reshape(-1, ch), sr
+        return (v - ((v & 0x800000) << 1)).astype(dtype) / dtype(8388608.0)
+    if width == 1:
+        return (np.frombuffer(raw, dtype=np.uint8).astype(dtype) - dtype(128.0)) / dtype(128.0)
+    raise ValueError('unsupported sample width %d' % width)
+
+
+def read_wav(path, start=0, stop=None, dtype=np.float64):
+    """WAV -> (dtype [frames, channels] in [-1, 1), sample rate), with a partial read like
+    ``soundfile.read(path, start=, stop=)`` (data/dataset.py:194): only the requested frames are read from disk.
+    8/16/24/32-bit integer PCM and 32/64-bit float, plain or WAVE_FORMAT_EXTENSIBLE -- what MedleyDB / MUSDB18-HQ ship.
+    dtype=np.float32 is lossless for integer PCM up to 24 bits (and halves the bytes sent to the GPU)."""
+    h = wav_header(path)
+    n = h['frames']
+    stop = n if stop is None else min(stop, n)
+    start = min(max(start, 0), stop)
+    with open(path, 'rb') as fh:
+        fh.seek(h['data_offset'] + start * h['frame_bytes'])
+        raw = fh.read((stop - start) * h['frame_bytes'])
+    return _decode(raw, h, np.dtype(dtype).type).reshape(-1, h['channels']), h['rate']
 
 
 def wav_num_frames(path):
-    with wave.open(path, 'rb') as w:
-        return w.getnframes(), w.getframerate()
+    h = wav_header(path)
+    return h['frames'], h['rate']
 
 
-def load_tracks(base_path, song_name, tracklist=('bass', 'drums', 'vocals', 'other', 'mix')):
-    """data/dataset_utils.py:53-68 for the MedleyDB layout: {track: ndarray[channels, n]}."""
+def _load(path, sr):
+    a, rate = read_wav(path, dtype=np.float32)             # librosa.load yields float32
+    if rate != sr:
+        raise ValueError('%s is sampled at %d Hz, not %d (librosa.load would resample; resample the files offline)'
+                         % (path, rate, sr))
+    return a[:, 0].copy() if a.shape[1] == 1 else a.T.copy()   # mono=False: [n] for mono files, else [channels, n]
+
+
+def load_tracks(base_dir, song_name, tracklist=('bass', 'drums', 'vocals', 'other', 'mix'), sr=44100) -> dict:
+    """data/dataset_utils.py:53-68, MedleyDB layout: {track: float32 ndarray[channels, n]} (what
+    ``librosa.load(path, sr=sr, mono=False)`` returns for files already at `sr`)."""
     out = {}
     for track in tracklist:
         if track == 'mix':
-            p = os.path.join(base_path, song_name, '%s_MIX.wav' % song_name)
+            p = os.path.join(base_dir, song_name, '{}_MIX.wav'.format(song_name))
         else:
-            p = os.path.join(base_path, song_name, '%s_STEMS_JOINED' % song_name,
-                             '%s_STEM_%s.wav' % (song_name, track.upper()))
-        a, _ = read_wav(p)
-        out[track] = a.T.copy()
+            p = os.path.join(base_dir, song_name, '{}_STEMS_JOINED'.format(song_name),
+                             '{}_STEM_{}.wav'.format(song_name, track.upper()))
+        out[track] = _load(p, sr)
     return out
+
+
+def load_tracks_musdb18(base_dir, song_name, tracklist=('bass', 'drums', 'vocals', 'other', 'mix'), sr=44100) -> dict:
+    """data/dataset_utils.py:71-83, MUSDB18-HQ layout: {song}/{bass,drums,vocals,other,mixture}.wav."""
+    return {track: _load(os.path.join(base_dir, song_name, '{}.wav'.format('mixture' if track == 'mix' else track)), sr)
+            for track in tracklist}

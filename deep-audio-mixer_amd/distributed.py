@@ -61,6 +61,20 @@ def broadcast_module(module, src=0, group=None):
         dist.broadcast(t.data, src, group=group)
 
 
+def backward_late(loss, late_params, boundary):
+    """Stage 1 of the cut backward pass: gradients of `loss` w.r.t. the parameters BEHIND the bucket boundary (the deep
+    end of the trunk + heads) and w.r.t. the boundary activation; nothing in front of the boundary is touched.
+    Returns (list of parameter gradients, d loss / d boundary)."""
+    grads = torch.autograd.grad(loss, list(late_params) + [boundary])
+    return list(grads[:-1]), grads[-1]
+
+
+def backward_early(boundary, d_boundary, early_params):
+    """Stage 2: continues backward from the boundary activation into the layers in front of it; accumulates into the
+    .grad of `early_params` (meant to run while the late bucket is on the wire)."""
+    torch.autograd.backward([boundary], [d_boundary], inputs=list(early_params))
+
+
 class GradBucket:
     """One flat gradient bucket for an arbitrary list of parameters (works on CPU/gloo and GPU/RCCL), for use with
     any torch optimizer:   loss.backward(); bucket.all_reduce_mean(); optimizer.step().
@@ -80,15 +94,27 @@ class GradBucket:
             yield p, self.flat[off:off + k].view(p.shape)
             off += k
 
-    def all_reduce_mean(self):
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        for p, v in self._views():
-            if p.grad is None:
+    def fill(self, grads=None):
+        """p.grad (or the given gradients, parameter order) -> the flat bucket."""
+        for i, (p, v) in enumerate(self._views()):
+            g = p.grad if grads is None else grads[i]
+            if g is None:
                 v.zero_()
             else:
-                v.copy_(p.grad)
+                v.copy_(g)
+
+    def start_all_reduce(self):
+        """Asynchronous SUM over the group; returns the work handle (None on a single rank)."""
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    def finish(self, work=None):
+        """Waits for start_all_reduce, divides by the world size and writes the mean back into the .grad fields."""
+        if work is not None:
+            work.wait()
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(world)
         for p, v in self._views():
             if p.grad is None:
@@ -96,6 +122,10 @@ class GradBucket:
             else:
                 p.grad.copy_(v)
         return self.flat
+
+    def all_reduce_mean(self):
+        self.fill()
+        return self.finish(self.start_all_reduce())
 
 
 def all_gather_gains(local_gains, group=None):

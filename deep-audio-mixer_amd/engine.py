@@ -4,42 +4,68 @@
       -> dam_stft_logmag_f32 (features x [B,S,F,T], target gt [B,F,T])
       -> model.forward_mse (conv/BN/ReLU trunk, heads, fused masked-sum + MSE)
       -> backward (BN backward, dgrad, wgrad, heads)            [model_trainer.py:30-37 of the reference]
-      -> flat gradient bucket -> (RCCL all-reduce over the data-parallel group) -> Adam(+L2)
+      -> flat gradient buckets -> (RCCL all-reduce over the data-parallel group) -> Adam(+L2)
 
-The kernel sequence is static, so after a few eager warm-up steps it is captured into a hipGraph
-(torch.cuda.CUDAGraph on the ROCm build) and replayed: one host call per step instead of ~400 launches.
-With more than one rank the all-reduce stays outside the graph (graph A: front-end+forward+backward+bucket,
-eager all-reduce, graph B: Adam).
+The kernel sequence is static, so after a few eager warm-up steps it is captured into hipGraphs
+(torch.cuda.CUDAGraph on the ROCm build) and replayed: one host call per graph instead of ~400 launches.
+
+One rank: a single graph (front-end + forward + backward + bucket + Adam).
+
+N ranks (data parallel): backward is cut at the model's bucket boundary into two graphs and the all-reduces
+stay between them, on RCCL's own stream, so that the big bucket travels while the rest of backward runs:
+
+    graph A1: front-end, forward, backward of heads + deep layers  -> bucket 1 (ResNet18: layer5/6 + heads, 85 % of
+              the 12.6 MB, ready after the first tenth of backward)
+    all-reduce(bucket 1)  [async, overlaps A2]
+    graph A2: backward of the shallow layers                        -> bucket 0
+    all-reduce(bucket 0)  [async]; wait both
+    graph B : Adam over the whole flat buffer (1/world folded in)
+
+The cut uses autograd itself: stage 1 is torch.autograd.grad(loss, late parameters + [boundary activation]), stage 2
+torch.autograd.backward(boundary activation, its gradient, inputs=early parameters).
 """
 import torch
 
-from . import features
+from . import distributed, features
 
 
 class TrainStep:
     def __init__(self, model, optimizer, n_stems, n_samples, channels=2, batch=8, n_fft=2048, hop=1024,
-                 use_graph=True, device=None):
+                 use_graph=True, device=None, overlap=True):
         self.model, self.opt = model, optimizer
         self.device = device or next(model.parameters()).device
         self.n_fft, self.hop, self.batch, self.n_stems = n_fft, hop, batch, n_stems
         f, t = n_fft // 2 + 1, features.num_frames(n_samples, hop)
         dev = self.device
-        self.stems = torch.zeros((batch, n_stems, n_samples, channels), dtype=torch.float32, device=dev)
-        self.mix = torch.zeros((batch, n_samples, channels), dtype=torch.float32, device=dev)
+        # stems and mix of a batch live in ONE buffer ([B, S+1, n, ch], mix last): the front-end is one launch
+        self.pcm = torch.zeros((batch, n_stems + 1, n_samples, channels), dtype=torch.float32, device=dev)
         self.x = torch.empty((batch, n_stems, f, t), dtype=torch.float32, device=dev)
         self.gt = torch.empty((batch, f, t), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.use_graph = use_graph
-        self._graph_a = self._graph_b = None
+        self._graphs = None
         self._steps_run = 0
         self.frames_per_step = batch * n_stems * t          # BASELINE metric unit: stem-spectrogram frames
+        self.staged = optimizer.world_size > 1 and overlap
+        if self.staged:
+            late = model.ddp_late_parameters()
+            n_late = len(late)
+            if [id(p) for p in optimizer._params[-n_late:]] != [id(p) for p in late]:
+                raise ValueError('ddp_late_parameters() must be the tail of the optimizer\'s parameter list')
+            optimizer.set_bucket_boundaries([late[0]])
+        self._stage = None
+
+    @property
+    def stems(self):
+        return self.pcm[:, :self.n_stems]
+
+    @property
+    def mix(self):
+        return self.pcm[:, self.n_stems]
 
     # -- pieces ---------------------------------------------------------------------------------
     def _front_end(self):
-        b, s = self.batch, self.n_stems
-        features.stft_logmag(self.stems.view(b * s, *self.stems.shape[2:]), self.n_fft, self.hop,
-                             out=self.x.view(b * s, *self.x.shape[2:]))
-        features.stft_logmag(self.mix, self.n_fft, self.hop, out=self.gt)
+        features.stft_logmag_clips(self.pcm, self.n_fft, self.hop, out_stems=self.x, out_mix=self.gt)
 
     def _fwd_bwd(self):
         self._front_end()
@@ -49,26 +75,54 @@ class TrainStep:
         self.loss.copy_(loss.detach())
         self.opt.gather_grads()
 
+    def _stage1(self):
+        """Front-end, forward, backward down to the bucket boundary; fills bucket 1 (the deep layers + heads)."""
+        self._front_end()
+        self.opt.zero_grad(set_to_none=True)
+        tap = []
+        loss = self.model.forward_mse(self.x, self.gt, tap=tap)[0]
+        grads, dmid = distributed.backward_late(loss, self.opt.bucket_params(1), tap[0])
+        self.loss.copy_(loss.detach())
+        self.opt.gather_grads(1, grads=grads)
+        self._stage = (tap[0], dmid)
+
+    def _stage2(self):
+        """Backward from the boundary activation to the input; fills bucket 0."""
+        mid, dmid = self._stage
+        self._stage = None
+        distributed.backward_early(mid, dmid, self.opt.bucket_params(0))
+        self.opt.gather_grads(0)
+
     def _update(self):
-        from . import ops
-        g = self.opt.param_groups[0]
-        o = self.opt
-        ops.adam_l2_step(o._flat, o._grad, o._exp_avg, o._exp_avg_sq, o._step, o._derived, g['lr'], g['betas'][0],
-                         g['betas'][1], g['eps'], g['weight_decay'], 1.0 / o.world_size)
+        self.opt.launch_update()
 
     def _eager(self):
-        self._fwd_bwd()
-        self.opt.all_reduce_grads()
+        if self.staged:
+            self._stage1()
+            w1 = self.opt.all_reduce_grads(1, async_op=True)
+            self._stage2()
+            w0 = self.opt.all_reduce_grads(0, async_op=True)
+            w1.wait()
+            w0.wait()
+        else:
+            self._fwd_bwd()
+            self.opt.all_reduce_grads()
         self._update()
 
     # -- public ---------------------------------------------------------------------------------
     def load_batch(self, stems, mix):
-        """Copies one batch of PCM (already on the device) into the static input buffers."""
-        self.stems.copy_(stems, non_blocking=True)
-        self.mix.copy_(mix, non_blocking=True)
+        """Copies one batch of PCM (stems [B,S,n,ch] and mix [B,n,ch], already on the device) into the static input."""
+        self.pcm[:, :self.n_stems].copy_(stems, non_blocking=True)
+        self.pcm[:, self.n_stems].copy_(mix, non_blocking=True)
+
+    def load_clips(self, clips):
+        """Copies one batch of whole clips [B, S+1, n, ch] (mix last; device or page-locked host memory) into the
+        static input: one contiguous copy."""
+        self.pcm.copy_(clips, non_blocking=True)
 
     def capture(self, warmup=3):
         """Eager warm-up on a side stream (sizes every workspace), then capture."""
+        self.opt.sync_hyper()
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -78,28 +132,49 @@ class TrainStep:
         torch.cuda.synchronize(self.device)
         if not self.use_graph:
             return self
-        self._graph_a = torch.cuda.CUDAGraph()
-        if self.opt.world_size > 1:
-            self._graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_a):
-                self._fwd_bwd()
-            with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool()):
+        ga = torch.cuda.CUDAGraph()
+        if self.staged:
+            ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._stage1()
+            with torch.cuda.graph(ga2, pool=ga.pool()):
+                self._stage2()
+            with torch.cuda.graph(gb, pool=ga.pool()):
                 self._update()
+            self._graphs = (ga, ga2, gb)
+        elif self.opt.world_size > 1:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._fwd_bwd()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self._update()
+            self._graphs = (ga, gb)
         else:
-            with torch.cuda.graph(self._graph_a):
+            with torch.cuda.graph(ga):
                 self._fwd_bwd()
                 self._update()
+            self._graphs = (ga,)
         return self
 
     def __call__(self):
         """Runs one step on the data currently in the static buffers; returns the (device) loss tensor."""
-        if self._graph_a is None:
+        self.opt.sync_hyper()
+        g = self._graphs
+        if g is None:
             self._eager()
-        elif self._graph_b is None:
-            self._graph_a.replay()
-        else:
-            self._graph_a.replay()
+        elif len(g) == 1:
+            g[0].replay()
+        elif len(g) == 2:
+            g[0].replay()
             self.opt.all_reduce_grads()
-            self._graph_b.replay()
+            g[1].replay()
+        else:
+            g[0].replay()
+            w1 = self.opt.all_reduce_grads(1, async_op=True)      # RCCL's stream: runs beside graph A2
+            g[1].replay()
+            w0 = self.opt.all_reduce_grads(0, async_op=True)
+            w1.wait()
+            w0.wait()
+            g[2].replay()
         self._steps_run += 1
         return self.loss

@@ -60,3 +60,84 @@ def stft_logmag(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out=None)
                                         AMIN, 1 if normalize else 0, _lib.ptr(out), _lib.stream())
     _lib.check(st, 'dam_stft_logmag_f32')
     return out
+
+
+def stft_logmag_song_chunks(pcm, n_chunks, chunk_samples, n_fft=2048, hop=1024, out=None):
+    """pcm: CUDA [S, channels, n] planar (the reference's loaded_tracks[track] arrays, stacked) -> dB features of the
+    channel mean of chunks 0..n_chunks-1 of every stem, [n_chunks * S, n_fft/2+1, T] with row = chunk * S + stem --
+    the batch the chunk loop at inference_utils.py:111-123 builds one chunk at a time.  Reads the song in place
+    (strided launch, no gather copy)."""
+    _lib.require_cuda(pcm, out)
+    if pcm.dim() != 3 or pcm.dtype not in (torch.float32, torch.float64):
+        raise ValueError('pcm must be a float32/float64 [stems, channels, samples] tensor')
+    pcm = pcm.contiguous()
+    S, ch, n = pcm.shape
+    if n_chunks * chunk_samples > n:
+        raise ValueError('the song is shorter than n_chunks chunks')
+    t = num_frames(chunk_samples, hop)
+    win, tw = _get_tables(pcm.device, n_fft)
+    shape = (n_chunks * S, n_fft // 2 + 1, t)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=pcm.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError('bad out tensor')
+    st = _lib.lib().dam_stft_logmag_strided_f32(_lib.ptr(pcm), 0 if pcm.dtype == torch.float32 else 1, n_chunks, chunk_samples,
+                                                S, ch * n, chunk_samples, ch, 1, n, _lib.ptr(win), _lib.ptr(tw), None,
+                                                n_fft, hop, AMIN, 0, _lib.ptr(out), None, 0, _lib.stream())
+    _lib.check(st, 'dam_stft_logmag_strided_f32')
+    return out
+
+
+def stft_logmag_clips(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out_stems=None, out_mix=None):
+    """pcm: CUDA [B, S+1, n, channels] (or [B, S+1, n]) float32/float64 -- a batch of clips, every clip's S stems
+    followed by its mix, interleaved channels (what data/dataset.py:192-196 reads per item).  ONE launch for all
+    B*(S+1) tracks; returns (x [B, S, F, T], gt [B, F, T]) float32 dB -- the collated (train_features, gt_features) of
+    data/dataset.py:207-210.  gain: optional [B, S+1] augmentation draws (data/dataset.py:198-199, the mix included)."""
+    _lib.require_cuda(pcm, gain, out_stems, out_mix)
+    if pcm.dim() == 3:
+        pcm = pcm.unsqueeze(-1)
+    if pcm.dim() != 4 or pcm.dtype not in (torch.float32, torch.float64):
+        raise ValueError('pcm must be a float32/float64 [clips, tracks, samples(, channels)] tensor')
+    pcm = pcm.contiguous()
+    B, K, n, ch = pcm.shape
+    if K < 2:
+        raise ValueError('a clip needs at least one stem and the mix')
+    f, t = n_fft // 2 + 1, num_frames(n, hop)
+    win, tw = _get_tables(pcm.device, n_fft)
+    if out_stems is None:
+        out_stems = torch.empty((B, K - 1, f, t), dtype=torch.float32, device=pcm.device)
+    if out_mix is None:
+        out_mix = torch.empty((B, f, t), dtype=torch.float32, device=pcm.device)
+    for o, shape in ((out_stems, (B, K - 1, f, t)), (out_mix, (B, f, t))):
+        if tuple(o.shape) != shape or o.dtype != torch.float32 or not o.is_contiguous():
+            raise ValueError('bad out tensor')
+    if gain is not None:
+        gain = gain.to(device=pcm.device, dtype=torch.float32).contiguous()
+        if gain.numel() != B * K:
+            raise ValueError('gain must have one entry per track')
+    st = _lib.lib().dam_stft_logmag_strided_f32(_lib.ptr(pcm), 0 if pcm.dtype == torch.float32 else 1, B, K * n * ch, K,
+                                                n * ch, n, ch, ch, 1, _lib.ptr(win), _lib.ptr(tw), _lib.ptr(gain), n_fft,
+                                                hop, AMIN, 1 if normalize else 0, _lib.ptr(out_stems), _lib.ptr(out_mix), 1,
+                                                _lib.stream())
+    _lib.check(st, 'dam_stft_logmag_strided_f32')
+    return out_stems, out_mix
+
+
+def augment_gains(seed, n_tracks, items=None, first_item=0, n_items=None, lo=0.6, hi=1.4, device=None, out=None):
+    """[n_items, n_tracks] float32 gains in [lo, hi): the reference's per-track augmentation draw (data/dataset.py:164-168,
+    198-199) as a reproducible device-side function of (seed, global item index, track).  items: int64 tensor / list of
+    global item indices, or (first_item, n_items) for a consecutive run."""
+    if items is not None:
+        items = torch.as_tensor(items, dtype=torch.int64)
+        n_items = items.numel()
+        device = device or (items.device if items.is_cuda else None)
+    device = torch.device(device or 'cuda')
+    if items is not None:
+        items = items.to(device).contiguous()
+    if out is None:
+        out = torch.empty((n_items, n_tracks), dtype=torch.float32, device=device)
+    _lib.require_cuda(out)
+    _lib.check(_lib.lib().dam_augment_gains_f32(int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(items), int(first_item), int(n_items),
+                                                int(n_tracks), float(lo), float(hi), _lib.ptr(out), _lib.stream()),
+               'dam_augment_gains_f32')
+    return out

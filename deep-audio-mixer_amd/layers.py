@@ -379,7 +379,15 @@ class MixingNet(nn.Module):
         state_dict[prefix + '_heads.fc_w'] = torch.cat([t.reshape(1, -1) for t in parts['fc_head%d.weight']]).to(dev)
         state_dict[prefix + '_heads.fc_b'] = torch.cat([t.reshape(1) for t in parts['fc_head%d.bias']]).to(dev)
 
-    def trunk(self, x):
+    def trunk(self, x, tap=None):
+        """x [B,S,F,T] -> NHWC trunk features.  tap (optional list): the model appends the activation at its
+        data-parallel bucket boundary (see ddp_late_parameters) to it."""
+        raise NotImplementedError
+
+    def ddp_late_parameters(self):
+        """Parameters of the layers BEHIND the bucket boundary (the deep, parameter-heavy end of the trunk and the
+        heads), whose gradients backward produces first: the step engine all-reduces them while the rest of backward
+        runs.  They are the tail of model.parameters()."""
         raise NotImplementedError
 
     @staticmethod
@@ -411,10 +419,19 @@ class MixingNet(nn.Module):
         masked, g = self._heads(self.trunk(x), x)
         return masked, tuple(g[:, s:s + 1] for s in range(self.n_stems))
 
-    def forward_mse(self, x, gt):
-        """Fused fast path for criterion == nn.MSELoss(): returns (loss, masked, gains tuple); masked and the
-        gains are detached outputs, loss carries the gradient."""
+    def predict_gains(self, x):
+        """The gain heads alone, [B, S] raw outputs, without autograd and without the masked sum (full-song inference
+        only wants the gains: inference_utils.py:123 discards the first output of model(x))."""
         x = self._check_input(x)
         self._pack_weights()
-        loss, masked, g = self._heads.forward_mse(self.trunk(x), x, gt)
+        with torch.no_grad():
+            h = self._heads
+            return ops.heads_fwd(self.trunk(x), h.conv_w, h.conv_b, h.fc_w, h.fc_b)[1]
+
+    def forward_mse(self, x, gt, tap=None):
+        """Fused fast path for criterion == nn.MSELoss(): returns (loss, masked, gains tuple); masked and the
+        gains are detached outputs, loss carries the gradient.  tap: see trunk()."""
+        x = self._check_input(x)
+        self._pack_weights()
+        loss, masked, g = self._heads.forward_mse(self.trunk(x) if tap is None else self.trunk(x, tap), x, gt)
         return loss, masked, tuple(g[:, s:s + 1] for s in range(self.n_stems))

@@ -23,8 +23,18 @@ class ScalarMixingNet(MixingNet):
     def conv_pairs(self):
         return [(getattr(self, 'conv_b%d' % i).spec, getattr(self, 'conv_b%d' % i).conv.weight, i > 1) for i in range(1, 6)]
 
-    def trunk(self, x):
+    DDP_BOUNDARY = 3      # conv_b4 (7x7), conv_b5 (9x9) and the heads hold 88 % of the parameters
+
+    def trunk(self, x, tap=None):
         out = x
         for i in range(1, 6):
             out = getattr(self, 'conv_b%d' % i)(out)
+            if tap is not None and i == self.DDP_BOUNDARY:
+                tap.append(out)
         return out
+
+    def ddp_late_parameters(self):
+        late = []
+        for i in range(self.DDP_BOUNDARY + 1, 6):
+            late += list(getattr(self, 'conv_b%d' % i).parameters())
+        return late + list(self._heads.parameters())

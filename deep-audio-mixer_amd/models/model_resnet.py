@@ -51,12 +51,22 @@ class ResNet(MixingNet):
                     pairs.append((blk.spec_sc, blk.shortcut[0].weight, True))
         return pairs
 
-    def trunk(self, x):
+    DDP_BOUNDARY = 4      # layer5, layer6 and the heads hold 85 % of the parameters and come first in backward
+
+    def trunk(self, x, tap=None):
         out = ConvBnReluFn.apply(x, self.conv1.weight, None, self.bn1.weight, self.bn1.bias, self._stem, self.bn1,
                                  self.training)
         for i in range(1, 7):
             out = getattr(self, 'layer%d' % i)(out)
+            if tap is not None and i == self.DDP_BOUNDARY:
+                tap.append(out)
         return out
+
+    def ddp_late_parameters(self):
+        late = []
+        for i in range(self.DDP_BOUNDARY + 1, 7):
+            late += list(getattr(self, 'layer%d' % i).parameters())
+        return late + list(self._heads.parameters())
 
 
 def ResNet18(**kwargs):

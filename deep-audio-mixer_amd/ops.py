@@ -45,7 +45,9 @@ def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shi
              out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
              res=None, res_mask=None, bn_partial=None):
     parts = ctypes.c_int(0)
-    ws = _workspace(y.device, min(8 * y.numel(), 64 << 20))        # split-K scratch (grow-only, shared)
+    # split-K scratch: the host code only splits when no tile shape gives 400 workgroups, i.e. for outputs below
+    # 400 * 64 px * 64 ch = 1.64 M floats, and then at most 8 ways (dam_conv.hip) -- never more than 13.1 M floats
+    ws = _workspace(y.device, min(8 * y.numel(), 8 * 400 * 64 * 64))
     st = _lib.lib().dam_conv2d_tapgrid_f32(
         _lib.ptr(x), B, H, W, C, 1 if in_nchw else 0, _lib.ptr(wp), k_chunks, n_out, _lib.ptr(bias),
         _lib.ptr(in_scale), _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(y), OHt, OWt, Ho, Wo, out_stride,
@@ -129,16 +131,24 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
 
 
 _workspaces = {}
+_retired = []          # superseded buffers are kept: a captured hipGraph may have their address baked in
+
+
+def _grow(table, key, device, floats):
+    ws = table.get(key)
+    if ws is None or ws.numel() < floats:
+        if ws is not None:
+            _retired.append(ws)
+        ws = torch.empty(int(floats), dtype=torch.float32, device=device)
+        table[key] = ws
+    return ws
 
 
 def _workspace(device, floats):
-    """One grow-only scratch buffer per device; all users are ordered on the current stream."""
-    key = (device.type, device.index)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < floats:
-        ws = torch.empty(int(floats), dtype=torch.float32, device=device)
-        _workspaces[key] = ws
-    return ws
+    """One grow-only scratch buffer per device (split-K slabs, weight-gradient slabs, reduction scratch of the heads /
+    mask-sum); all users are ordered on the current stream.  A buffer that has to grow is never freed: hipGraphs
+    captured earlier keep replaying into the old one (the launches recorded there were sized for it)."""
+    return _grow(_workspaces, (device.type, device.index), device, floats)
 
 
 def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, relu_in=False,
@@ -177,6 +187,9 @@ def _bn_ws(device, C):
     return _workspace(device, _lib.lib().dam_bn_workspace_floats(C))
 
 
+_bn_partials = {}
+
+
 def bn_stats(x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps):
     """Training-mode statistics of NHWC x.  Returns (save_mean, save_invstd, scale, shift), updates the running buffers."""
     _lib.require_cuda(x)
@@ -192,8 +205,9 @@ def bn_stats(x, gamma, beta, running_mean, running_var, num_batches_tracked, mom
 
 
 def bn_partial_buffer(device, C):
-    """Scratch for the BatchNorm partial records a convolution launch can emit (one per device and width)."""
-    return _bn_ws(device, C)
+    """The BatchNorm partial records a convolution launch can emit: a buffer of their own per device and width (they
+    live from the convolution launch to the finalize launch and must not alias any kernel's scratch)."""
+    return _grow(_bn_partials, (device.type, device.index, C), device, _lib.lib().dam_bn_workspace_floats(C))
 
 
 def bn_finalize(partial, parts, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps):
@@ -325,43 +339,89 @@ def masksum_mse(x, gains, gt, want_masked=True):
 
 
 # ----------------------------------------------------------------------------- optimizer
-def adam_l2_step(params, grads, exp_avg, exp_avg_sq, step, derived, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
-    _lib.require_cuda(params, grads)
+def adam_l2_step(params, grads, exp_avg, exp_avg_sq, step, derived, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0,
+                 hyper=None):
+    """hyper: optional CUDA float32[6] {lr, beta1, beta2, eps, weight_decay, grad_scale} read by the kernel at run time
+    (a captured graph then follows hyper-parameter edits); the scalars are used when it is None."""
+    _lib.require_cuda(params, grads, hyper)
     _lib.check(_lib.lib().dam_adam_l2_step_f32(_lib.ptr(params), _lib.ptr(grads), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                                params.numel(), _lib.ptr(step), _lib.ptr(derived), float(lr), float(beta1),
                                                float(beta2), float(eps), float(weight_decay), float(grad_scale),
-                                               _lib.stream()), 'dam_adam_l2_step_f32')
+                                               _lib.ptr(hyper), _lib.stream()), 'dam_adam_l2_step_f32')
 
 
 # ----------------------------------------------------------------------------- inference tail
-def gain_ramp_apply(audio, gains):
-    """audio [rows, n] (float32 or float64, CUDA), gains [n_gains] same dtype -> audio * piecewise-constant gain."""
-    _lib.require_cuda(audio, gains)
-    if audio.dtype != gains.dtype or audio.dtype not in (torch.float32, torch.float64):
-        raise TypeError('audio and gains must both be float32 or float64')
+def _audio_kind(t, what):
+    if t.dtype not in (torch.float32, torch.float64):
+        raise TypeError('%s must be float32 or float64' % what)
+    return 1 if t.dtype == torch.float64 else 0
+
+
+def gains_smooth(raw_db, window, polyorder=2, out=None, want_f32=False):
+    """raw_db: CUDA float32 [n_chunks, S] (model outputs) -> out [2, S, n_chunks] float64 = (10 ** (0.5 * g),
+    scipy.signal.savgol_filter(that, window, polyorder) in its default mode 'interp'), computed on the device.
+    Returns (amp, smooth[, smooth as float32])."""
+    _lib.require_cuda(raw_db, out)
+    raw_db = _f32c(raw_db, 'raw_db')
+    n, S = raw_db.shape
+    if window % 2 == 0 or window <= polyorder or window > n:
+        # the conditions scipy.signal.savgol_filter rejects (inference_utils.py:140 would raise there too)
+        raise ValueError('savgol_filter needs an odd window with polyorder < window <= len(x): window=%d polyorder=%d '
+                         'len=%d' % (window, polyorder, n))
+    if out is None:
+        out = torch.empty((2, S, n), dtype=torch.float64, device=raw_db.device)
+    elif tuple(out.shape) != (2, S, n) or out.dtype != torch.float64 or not out.is_contiguous():
+        raise ValueError('bad out tensor')
+    s32 = torch.empty((S, n), dtype=torch.float32, device=raw_db.device) if want_f32 else None
+    _lib.check(_lib.lib().dam_gains_smooth(_lib.ptr(raw_db), n, S, window, polyorder, _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                           _lib.ptr(s32), _lib.stream()), 'dam_gains_smooth')
+    return (out[0], out[1], s32) if want_f32 else (out[0], out[1])
+
+
+def gain_ramp_apply(audio, gains, out=None, out_dtype=None):
+    """audio [G, rows_per_gain, n] or [rows, n] (CUDA float32/float64), gains [G, n_gains] or [n_gains] float64 ->
+    audio * piecewise-constant gain (one gain sequence per leading index); the result is float64 unless out_dtype says
+    float32 (numpy's float32-track * float64-mask product is float64, inference_utils.py:143)."""
+    _lib.require_cuda(audio, gains, out)
+    ak = _audio_kind(audio, 'audio')
+    if gains.dtype != torch.float64:
+        raise TypeError('gains must be float64')
     audio, gains = audio.contiguous(), gains.contiguous()
-    rows, n = audio.shape
-    out = torch.empty_like(audio)
-    _lib.check(_lib.lib().dam_gain_ramp_apply(_lib.ptr(audio), _lib.ptr(gains), 1 if audio.dtype == torch.float64 else 0,
-                                              rows, n, gains.numel(), _lib.ptr(out), _lib.stream()), 'dam_gain_ramp_apply')
+    if audio.dim() == 2:
+        rpg, rows, n = audio.shape[0], audio.shape[0], audio.shape[1]
+        n_gains = gains.numel()
+    else:
+        G, rpg, n = audio.shape
+        rows, n_gains = G * rpg, gains.shape[-1]
+        if gains.numel() != G * n_gains:
+            raise ValueError('one gain sequence per leading index expected')
+    if out is None:
+        out = torch.empty(audio.shape, dtype=out_dtype or torch.float64, device=audio.device)
+    elif out.shape != audio.shape or not out.is_contiguous():
+        raise ValueError('bad out tensor')
+    _lib.check(_lib.lib().dam_gain_ramp_apply(_lib.ptr(audio), ak, _lib.ptr(gains), rows, rpg, n, n_gains, _lib.ptr(out),
+                                              _audio_kind(out, 'out'), _lib.stream()), 'dam_gain_ramp_apply')
     return out
 
 
-def mixdown_peak_normalize(audio, gains, normalize=True):
-    """audio [S, rows, n], gains [S, n_gains] (same float dtype, CUDA) -> gain-ramped stem sum [rows, n], optionally
+def mixdown_peak_normalize(audio, gains, normalize=True, out=None, out_dtype=None, workspace=None):
+    """audio [S, rows, n] (CUDA float32/float64), gains [S, n_gains] float64 -> gain-ramped stem sum [rows, n], optionally
     divided row-wise by its max-abs."""
-    _lib.require_cuda(audio, gains)
-    if audio.dtype != gains.dtype or audio.dtype not in (torch.float32, torch.float64):
-        raise TypeError('audio and gains must both be float32 or float64')
+    _lib.require_cuda(audio, gains, out)
+    ak = _audio_kind(audio, 'audio')
+    if gains.dtype != torch.float64:
+        raise TypeError('gains must be float64')
     audio, gains = audio.contiguous(), gains.contiguous()
     S, rows, n = audio.shape
-    mix = torch.empty((rows, n), dtype=audio.dtype, device=audio.device)
+    if out is None:
+        out = torch.empty((rows, n), dtype=out_dtype or torch.float64, device=audio.device)
     L = _lib.lib()
-    ws = torch.empty(L.dam_mixdown_workspace_elems(rows), dtype=audio.dtype, device=audio.device)
-    _lib.check(L.dam_mixdown_peak_normalize(_lib.ptr(audio), _lib.ptr(gains), 1 if audio.dtype == torch.float64 else 0, S, rows, n,
-                                            gains.shape[1], 1 if normalize else 0, _lib.ptr(mix), _lib.ptr(ws), _lib.stream()),
-               'dam_mixdown_peak_normalize')
-    return mix
+    if workspace is None:
+        workspace = torch.empty(L.dam_mixdown_workspace_elems(rows), dtype=out.dtype, device=audio.device)
+    _lib.check(L.dam_mixdown_peak_normalize(_lib.ptr(audio), ak, _lib.ptr(gains), S, rows, n, gains.shape[1],
+                                            1 if normalize else 0, _lib.ptr(out), _audio_kind(out, 'out'),
+                                            _lib.ptr(workspace), _lib.stream()), 'dam_mixdown_peak_normalize')
+    return out
 
 
 # ----------------------------------------------------------------------------- dropout

@@ -1,0 +1,131 @@
+"""Host <-> HBM staging for the ingest side of the path.
+
+The reference hands pageable numpy arrays to ``tensor.to(device)`` (model_trainer.py:34, inference_utils.py:123): the
+driver then bounces them through its own small staging buffer, single-threaded, at a few GB/s.  Here the bounce is
+explicit: two page-locked buffers, the host copy into buffer k+1 (torch's multi-threaded CPU copy) runs while the DMA
+engine moves buffer k on a dedicated copy stream, and the compute stream only waits on an event.  The same pipe in
+reverse brings results back.  PyTorch supplies the page-locked memory, the streams and the events; nothing is
+computed here.
+"""
+import numpy as np
+import torch
+
+PIECE_BYTES = 32 << 20
+
+
+class PinnedPipe:
+    """Double-buffered page-locked staging between host arrays and device tensors on a private copy stream."""
+
+    def __init__(self, device, piece_bytes=PIECE_BYTES, n_buffers=2):
+        self.device = torch.device(device)
+        self.piece_bytes = int(piece_bytes)
+        self.bufs = [torch.empty(self.piece_bytes, dtype=torch.uint8, pin_memory=True) for _ in range(n_buffers)]
+        self.free = [torch.cuda.Event() for _ in range(n_buffers)]      # recorded when the DMA out of / into buffer i is done
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._turn = 0
+
+    def _next(self):
+        i = self._turn
+        self._turn = (i + 1) % len(self.bufs)
+        self.free[i].synchronize()              # the previous transfer through this buffer has finished
+        return i
+
+    def upload(self, dst, src):
+        """dst: contiguous device tensor; src: numpy array (or CPU tensor) of the same dtype and element count, any
+        pageable memory.  Returns after the last piece has been ENQUEUED; the current stream is made to wait for it."""
+        src_t = torch.from_numpy(np.ascontiguousarray(src)) if isinstance(src, np.ndarray) else src.contiguous()
+        if src_t.dtype != dst.dtype or src_t.numel() != dst.numel() or not dst.is_contiguous():
+            raise ValueError('upload: dtype / size mismatch or non-contiguous destination')
+        s8, d8 = src_t.view(-1).view(torch.uint8), dst.view(-1).view(torch.uint8)
+        n = s8.numel()
+        # the copy stream must not overtake earlier work on the destination
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        for lo in range(0, n, self.piece_bytes):
+            hi = min(lo + self.piece_bytes, n)
+            i = self._next()
+            self.bufs[i][:hi - lo].copy_(s8[lo:hi])                     # pageable -> page-locked (multi-threaded memcpy)
+            with torch.cuda.stream(self.stream):
+                d8[lo:hi].copy_(self.bufs[i][:hi - lo], non_blocking=True)
+                self.free[i].record(self.stream)
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return dst
+
+    def download(self, src, out=None):
+        """src: contiguous device tensor -> numpy array (a fresh pageable array, or `out`).  Synchronous."""
+        if not src.is_contiguous():
+            raise ValueError('download: non-contiguous source')
+        res = torch.empty(src.shape, dtype=src.dtype) if out is None else (
+            torch.from_numpy(out) if isinstance(out, np.ndarray) else out)
+        r8, s8 = res.view(-1).view(torch.uint8), src.view(-1).view(torch.uint8)
+        n = s8.numel()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        nb = len(self.bufs)
+        pieces = [(lo, min(lo + self.piece_bytes, n)) for lo in range(0, n, self.piece_bytes)]
+        for ev in self.free:
+            ev.synchronize()                                            # nothing else is in flight through the buffers
+
+        def drain(k):                                                   # page-locked -> pageable once piece k has landed
+            lo, hi = pieces[k]
+            self.free[k % nb].synchronize()
+            r8[lo:hi].copy_(self.bufs[k % nb][:hi - lo])
+
+        for k, (lo, hi) in enumerate(pieces):
+            if k >= nb:
+                drain(k - nb)                                           # overlaps the DMA of piece k-1
+            with torch.cuda.stream(self.stream):
+                self.bufs[k % nb][:hi - lo].copy_(s8[lo:hi], non_blocking=True)
+                self.free[k % nb].record(self.stream)
+        for k in range(max(0, len(pieces) - nb), len(pieces)):
+            drain(k)
+        return res.numpy() if out is None else out
+
+
+_pipes = {}
+
+
+def pipe_for(device):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _pipes:
+        _pipes[key] = PinnedPipe(device)
+    return _pipes[key]
+
+
+class BatchStager:
+    """Feeds device batches from a page-locked host dataset [N, ...]: while the consumer works on batch k, batch k+1
+    travels on a private copy stream into the other of two device buffers (the role the reference gives to
+    DataLoader(pin_memory=True) + ``.to(device)``, model_trainer.py:34 -- here without blocking the training stream).
+
+    ``next()`` returns the device tensor of the next batch; the caller must have enqueued everything that reads the
+    previously returned tensor on the current stream before calling ``next()`` again."""
+
+    def __init__(self, host, batch, device):
+        if not host.is_pinned():
+            raise ValueError('BatchStager needs page-locked host memory (torch.empty(..., pin_memory=True))')
+        self.host, self.batch, self.device = host, batch, torch.device(device)
+        self.n_batches = host.shape[0] // batch
+        if self.n_batches < 1:
+            raise ValueError('the host dataset holds less than one batch')
+        self.bufs = [torch.empty((batch,) + tuple(host.shape[1:]), dtype=host.dtype, device=self.device) for _ in range(2)]
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.k = 0
+        self._issue(0)
+
+    def _issue(self, k):
+        b = k % 2
+        lo = (k % self.n_batches) * self.batch
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(self.consumed[b])        # the reads of this buffer's previous batch are done
+            self.bufs[b].copy_(self.host[lo:lo + self.batch], non_blocking=True)
+            self.ready[b].record(self.stream)
+
+    def next(self):
+        k, cur = self.k, torch.cuda.current_stream(self.device)
+        if k > 0:
+            self.consumed[(k - 1) % 2].record(cur)          # everything enqueued so far has read batch k-1's buffer
+        cur.wait_event(self.ready[k % 2])
+        self._issue(k + 1)                                  # travels while the caller's step k runs
+        self.k = k + 1
+        return self.bufs[k % 2]

@@ -68,6 +68,29 @@ int dam_stft_logmag_f32(const void* pcm, int pcm_dtype, int64_t n_tracks, int64_
                         const float* gain, int n_fft, int hop, float amin, int normalize,
                         float* out, void* stream);
 
+/* The same front-end over strided PCM, so that tracks need not be gathered first.  Track (o, i), o < n_outer,
+ * i < n_inner, is output row o*n_inner + i and starts at pcm + o*outer_stride + i*inner_stride (elements); sample p of
+ * channel c is at + p*sample_stride + c*channel_stride.  Two layouts are implemented: interleaved channels
+ * (sample_stride == channels, channel_stride == 1: what a WAV decoder / soundfile hands over, data/dataset.py:194) and
+ * planar channels (sample_stride == 1, channel_stride >= n_samples: the [channels, n] arrays that
+ * inference_utils.py:116-119 slices chunk by chunk -- outer = chunk (stride chunk_samples), inner = stem).
+ * gain (optional) has one entry per track, index o*n_inner + i.
+ * n_tail > 0 splits the output the way a dataset item is split (data/dataset.py:207-210: train_features = the stems,
+ * gt_features = the mix): tracks i < n_inner - n_tail go to out [n_outer][n_inner - n_tail][F][T], the last n_tail
+ * tracks of every outer group to out_tail [n_outer][n_tail][F][T] -- one launch for a whole batch of clips. */
+int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64_t n_outer, int64_t outer_stride, int64_t n_inner,
+                                int64_t inner_stride, int64_t n_samples, int channels, int64_t sample_stride,
+                                int64_t channel_stride, const float* window, const float* twiddles, const float* gain,
+                                int n_fft, int hop, float amin, int normalize, float* out, float* out_tail, int n_tail,
+                                void* stream);
+
+/* The augmentation draw of data/dataset.py:164-168,198-199 (one uniform gain per track of an item, the mix included)
+ * made on the device and reproducibly: gains[i][k] = lo + (hi - lo) * u(seed, item_i, k), u in [0, 1) a counter-based
+ * hash (splitmix64) of (seed, GLOBAL item index, track).  items: optional DEVICE int64[n_items] of global item (chunk)
+ * indices; nullptr = first_item, first_item + 1, ...  gains [n_items][n_tracks] feeds dam_stft_logmag_*'s `gain`. */
+int dam_augment_gains_f32(uint64_t seed, const int64_t* items, int64_t first_item, int n_items, int n_tracks,
+                          float lo, float hi, float* gains, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Convolutions.  Replace nn.Conv2d forward and its autograd data-gradient in
  * models/model_resnet.py:11-21,64 (BasicBlock / stem convs) and
@@ -207,27 +230,46 @@ int dam_masksum_mse_f32(const float* x, const float* gains, const float* gt, int
  * weight_decay=wd) (training.ipynb cell 11; L2 folded into the gradient, not AdamW) over one flat
  * parameter buffer.  step: device int64 counter (incremented here); derived2: device float[2] scratch.
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce).
+ * hyper_dev (optional): DEVICE float[6] = {lr, beta1, beta2, eps, weight_decay, grad_scale} read at run time instead
+ * of the scalar arguments, so that a captured graph follows param_groups edits / LR schedulers.
+ * All four buffers must be 16-byte aligned.
  * --------------------------------------------------------------------------------- */
 int dam_adam_l2_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                          int64_t* step, float* derived2, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, float grad_scale, void* stream);
+                         float weight_decay, float grad_scale, const float* hyper_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------
- * Full-song inference tail.  Replaces inference_utils.py:12-41 (interpolate_mask) fused with :143
- * (loaded_tracks[track] * mask): out[r][n] = audio[r][n] * gains[min(n / (n_samples / n_gains), n_gains-1)]
- * for rows r (channels) of length n_samples; dtype float64 (is_f64) or float32.
+ * Full-song inference tail (BASELINE config C5), all on the device so that the whole of
+ * inference_utils.py:105-145 + the callers' sum / normalise is one hipGraph-capturable sequence.
  * --------------------------------------------------------------------------------- */
-int dam_gain_ramp_apply(const void* audio, const void* gains, int is_f64, int64_t rows, int64_t n_samples,
-                        int n_gains, void* out, void* stream);
+
+/* inference_utils.py:125-130 and :136-141.  raw_db [n_chunks][n_stems] float32 = the model's gain outputs per chunk;
+ *   amp[s][c]    = 10 ** (0.5 * raw_db[c][s])                       (data/dataset_utils.py:46-50, float64)
+ *   smooth[s][:] = scipy.signal.savgol_filter(amp[s], window, polyorder)   (default mode 'interp': the first / last
+ *                  window/2 outputs come from the polynomial fitted to the first / last window)
+ * amp, smooth: [n_stems][n_chunks] float64; smooth_f32 (optional): the same values rounded to float32.
+ * Argument rules are scipy's (odd window, polyorder < window <= n_chunks -> otherwise DAM_ERR_BAD_ARG);
+ * polyorder <= 5 and n_chunks <= 8192 are supported. */
+int dam_gains_smooth(const float* raw_db, int n_chunks, int n_stems, int window, int polyorder, double* amp,
+                     double* smooth, float* smooth_f32, void* stream);
+
+/* inference_utils.py:12-41 (interpolate_mask) fused with :143 (loaded_tracks[track] * mask):
+ *   out[r][n] = audio[r][n] * gains[r / rows_per_gain][min(n / (n_samples / n_gains), n_gains-1)]
+ * audio [rows][n_samples] float32 or float64 (audio_is_f64); gains [ceil(rows/rows_per_gain)][n_gains] float64 (one gain
+ * sequence per stem = per `rows_per_gain` channel rows); out float32 or float64 (out_is_f64; the reference's numpy
+ * product of a float32 track with the float64 mask is float64). */
+int dam_gain_ramp_apply(const void* audio, int audio_is_f64, const double* gains, int64_t rows, int64_t rows_per_gain,
+                        int64_t n_samples, int n_gains, void* out, int out_is_f64, void* stream);
 
 /* The caller's next step (inference.ipynb cells 9/11, evaluation.py:59-66) fused with the gain ramp:
  *   mix[r][n] = sum_s audio[s][r][n] * gains[s][min(n / (n_samples / n_gains), n_gains-1)]
  * and, if normalize, each row divided by its max-abs (librosa.util.normalize(track_sum, axis=1)).
- * audio [n_stems][rows][n_samples], gains [n_stems][n_gains], mix [rows][n_samples]; float64 or float32.
- * workspace: dam_mixdown_workspace_elems(rows) elements of the same dtype. */
+ * audio [n_stems][rows][n_samples] float32/float64, gains [n_stems][n_gains] float64, mix [rows][n_samples]
+ * float32/float64 (mix_is_f64).  workspace: dam_mixdown_workspace_elems(rows) elements of mix's dtype. */
 int64_t dam_mixdown_workspace_elems(int64_t rows);
-int dam_mixdown_peak_normalize(const void* audio, const void* gains, int is_f64, int n_stems, int64_t rows,
-                               int64_t n_samples, int n_gains, int normalize, void* mix, void* workspace, void* stream);
+int dam_mixdown_peak_normalize(const void* audio, int audio_is_f64, const double* gains, int n_stems, int64_t rows,
+                               int64_t n_samples, int n_gains, int normalize, void* mix, int mix_is_f64,
+                               void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * ITU-R BS.1770 loudness.  Replaces what the reference gets from the third-party pyloudnorm

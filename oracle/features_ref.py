@@ -102,3 +102,18 @@ def clip_features(pcm: np.ndarray, window_size: int = 2048, hop_length: int = 10
             a = augment_audio(a, gains[k])
         feats.append(compute_features(a.astype(dtype), window_size, hop_length, dtype, normalize))
     return np.stack(feats[:-1]), feats[-1]
+
+
+def augment_gain_ref(seed: int, item: int, track: int, lo: float = 0.6, hi: float = 1.4) -> np.float32:
+    """The product's reproducible stand-in for ``np.random.uniform(0.6, 1.4)`` at data/dataset.py:164-168 (the reference
+    draws from numpy's global state; there is nothing to match bit for bit): u = top 24 bits of
+    splitmix64(seed * K + item * 4096 + track) / 2^24, gain = lo + (hi - lo) * u, all in float32."""
+    m = (1 << 64) - 1
+    z = (seed * 0xD1342543DE82EF95 + item * 4096 + track) & m
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    z ^= z >> 31
+    r = z >> 32
+    u = np.float32(r >> 8) * np.float32(1.0 / 16777216.0)
+    return np.float32(lo) + (np.float32(hi) - np.float32(lo)) * u

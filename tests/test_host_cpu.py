@@ -35,7 +35,8 @@ def test_dataset_index_arithmetic():
     """data/dataset.py:56-75,97-113: len = sum floor(dur/chunk); chunks of a song are consecutive."""
     d = MultitrackAudioDataset.from_arrays(_songs([7.3, 2.0, 4.9]), chunk_length=2, sr=8000, seed=3, device='cpu')
     assert d.get_tracklist() == ['bass', 'drums', 'vocals', 'other', 'mix']
-    assert d.get_num_songs() == 3 and sorted(d.get_song_durations()) == [2.0, 4.9, 7.3]
+    assert d.get_num_songs() == 3 and sorted(d.get_song_durations()) == [2, 4, 6]     # int seconds, trimmed (:70-73)
+    assert all(isinstance(v, int) for v in d.get_song_durations())
     per_song = [int(x / 2) for x in d.get_song_durations()]
     assert len(d) == sum(per_song) == 6
     seen = [d._calculate_song_index(i) for i in range(len(d))]
@@ -59,8 +60,47 @@ def test_wav_partial_read(tmp_path):
     np.testing.assert_array_equal(a, x[1000:3000] / 32768.0)          # soundfile's int16 normalisation
     d = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr, device='cpu')
     assert len(d) == 0 and d.get_num_songs() == 1                     # 0.625 s < one chunk
-    tracks = dataset_utils.load_tracks(str(tmp_path), 'A')
-    assert tracks['drums'].shape == (2, n)
+    tracks = dataset_utils.load_tracks(str(tmp_path), 'A', sr=sr)
+    assert tracks['drums'].shape == (2, n) and tracks['drums'].dtype == np.float32     # librosa.load(mono=False)
+    with pytest.raises(ValueError, match='resample'):
+        dataset_utils.load_tracks(str(tmp_path), 'A')                 # 8 kHz files asked for at 44.1 kHz
+
+
+def test_wav_extensible_float_and_musdb_layout(tmp_path):
+    """WAVE_FORMAT_EXTENSIBLE (24-bit) and IEEE-float files, which the stdlib wave module rejects, decode like
+    soundfile; MUSDB18-HQ layout loader; split_songlist."""
+    import struct
+    rng = np.random.default_rng(2)
+    n, ch = 700, 2
+    v = rng.integers(-2 ** 23, 2 ** 23, (n, ch))
+    raw = b''.join(int(s).to_bytes(3, 'little', signed=True) for s in v.flatten())
+    guid_tail = b'\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71'
+    fmt = struct.pack('<HHIIHH', 0xFFFE, ch, 44100, 44100 * ch * 3, ch * 3, 24) + struct.pack('<HHI', 22, 24, 3) + \
+        struct.pack('<H', 1) + guid_tail
+    body = b'WAVE' + b'fmt ' + struct.pack('<I', len(fmt)) + fmt + b'LIST' + struct.pack('<I', 3) + b'abc\x00' + \
+        b'data' + struct.pack('<I', len(raw)) + raw
+    song = tmp_path / 'M'
+    song.mkdir()
+    for name in ('bass', 'drums', 'vocals', 'other', 'mixture'):
+        (song / (name + '.wav')).write_bytes(b'RIFF' + struct.pack('<I', len(body)) + body)
+    a, sr = dataset_utils.read_wav(str(song / 'bass.wav'), 10, 20)
+    assert sr == 44100 and np.array_equal(a, v[10:20] / 8388608.0)
+    a32, _ = dataset_utils.read_wav(str(song / 'bass.wav'), dtype=np.float32)
+    assert a32.dtype == np.float32 and np.array_equal(a32.astype(np.float64), v / 8388608.0)    # 24-bit PCM is exact in f32
+    tracks = dataset_utils.load_tracks_musdb18(str(tmp_path), 'M')
+    assert sorted(tracks) == ['bass', 'drums', 'mix', 'other', 'vocals'] and tracks['mix'].shape == (2, n)
+    f = rng.standard_normal((100, 1)).astype('<f4')
+    fmt = struct.pack('<HHIIHH', 3, 1, 16000, 16000 * 4, 4, 32)
+    body = b'WAVE' + b'fmt ' + struct.pack('<I', len(fmt)) + fmt + b'data' + struct.pack('<I', f.nbytes) + f.tobytes()
+    (tmp_path / 'f.wav').write_bytes(b'RIFF' + struct.pack('<I', len(body)) + body)
+    a, sr = dataset_utils.read_wav(str(tmp_path / 'f.wav'))
+    assert sr == 16000 and np.array_equal(a, f.astype(np.float64))
+    with pytest.raises(ValueError):
+        (tmp_path / 'bad.wav').write_bytes(b'RIFFxxxxWAVEjunk')
+        dataset_utils.read_wav(str(tmp_path / 'bad.wav'))
+    np.random.seed(0)
+    tr, va, te = dataset_utils.split_songlist(['s%d' % i for i in range(10)], (0.5, 0.25, 0.25), summary=False)
+    assert len(tr) == 5 and len(va) == 2 and len(te) == 3 and sorted(tr + va + te) == ['s%d' % i for i in range(10)]
 
 
 def test_reference_checkpoint_roundtrip():
@@ -145,3 +185,96 @@ def test_data_parallel_gloo_world2(tmp_path):
     assert torch.allclose(r0['flat'], want, rtol=1e-5, atol=1e-7)
     # gathered gains come back in chunk order (rank-strided)
     assert r0['gains'][:, 0].tolist() == [0.0, 1.0, 10.0, 11.0]
+
+
+class _CutNet(torch.nn.Module):
+    """Oracle RefMixingModelScalar1s with the activation at a bucket boundary exposed (what the product models' `tap` does)."""
+
+    def __init__(self):
+        super().__init__()
+        self.m = models_ref.RefMixingModelScalar1s(n_stems=2, input_shape=(64, 48))
+        for mod in self.m.modules():
+            if hasattr(mod, 'dropout_p'):
+                mod.dropout_p = -1
+
+    def forward(self, x, tap):
+        y = x
+        for i in range(1, 6):
+            y = getattr(self.m, 'conv_b%d' % i)(y)
+            if i == 3:
+                tap.append(y)
+        return self.m._run_heads(x, y)
+
+    def late(self):
+        return [p for n, p in self.m.named_parameters() if not n.startswith(('conv_b1.', 'conv_b2.', 'conv_b3.'))]
+
+    def early(self):
+        return [p for n, p in self.m.named_parameters() if n.startswith(('conv_b1.', 'conv_b2.', 'conv_b3.'))]
+
+
+def _staged_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    ddist.init_process_group('gloo')
+    torch.manual_seed(7)
+    net = _CutNet()
+    g = torch.Generator().manual_seed(5)
+    xs, gts = torch.randn(4, 2, 64, 48, generator=g), torch.randn(4, 64, 48, generator=g)
+    idx = ddist.shard_indices(4, rank, world)
+    tap = []
+    masked, _ = net(xs[idx], tap)
+    loss = torch.nn.functional.mse_loss(masked, gts[idx])
+    # the step engine's order: late bucket first and on the wire while the early layers' backward runs
+    late_b, early_b = ddist.GradBucket(net.late()), ddist.GradBucket(net.early())
+    grads, dmid = ddist.backward_late(loss, net.late(), tap[0])
+    assert all(p.grad is None for p in net.early())          # nothing in front of the boundary has been touched
+    late_b.fill(grads)
+    w1 = late_b.start_all_reduce()
+    ddist.backward_early(tap[0], dmid, net.early())
+    early_b.fill()
+    w0 = early_b.start_all_reduce()
+    late_b.finish(w1), early_b.finish(w0)
+    torch.save({'late': late_b.flat.clone(), 'early': early_b.flat.clone()}, os.path.join(out_dir, 's%d.pt' % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_staged_backward_two_buckets_gloo_world2(tmp_path):
+    """engine.TrainStep's multi-rank schedule on the CPU: backward cut at a bucket boundary (autograd.grad down to the
+    boundary, backward from it), each bucket all-reduced asynchronously as soon as it exists == one plain backward per
+    replica with the gradients averaged."""
+    port = _free_port()
+    mp.spawn(_staged_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 's0.pt'), torch.load(tmp_path / 's1.pt')
+    assert torch.equal(r0['late'], r1['late']) and torch.equal(r0['early'], r1['early'])
+    torch.manual_seed(7)
+    net = _CutNet()
+    g = torch.Generator().manual_seed(5)
+    xs, gts = torch.randn(4, 2, 64, 48, generator=g), torch.randn(4, 64, 48, generator=g)
+    acc = {'late': 0, 'early': 0}
+    for idx in ([0, 2], [1, 3]):
+        net.zero_grad()
+        masked, _ = net(xs[idx], [])
+        torch.nn.functional.mse_loss(masked, gts[idx]).backward()
+        acc['late'] = acc['late'] + torch.cat([p.grad.flatten() for p in net.late()]) / 2
+        acc['early'] = acc['early'] + torch.cat([p.grad.flatten() for p in net.early()]) / 2
+    # (conv biases in front of a training-mode BatchNorm have an exactly-zero true gradient: rounding noise only)
+    for k in ('late', 'early'):
+        assert torch.allclose(r0[k], acc[k], rtol=1e-4, atol=1e-5 * acc[k].abs().max().item()), k
+
+
+def test_bench_refuses_to_run_fewer_ranks():
+    """`python bench.py --gpus N` with no WORLD_SIZE must start N ranks itself or fail -- never report a 1-rank line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('multi-GPU host: the spawn path would run for real')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'refusing' in r.stderr and '{' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='1'),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'WORLD_SIZE' in r.stderr

@@ -1,0 +1,201 @@
+"""GPU: the full-song inference tail (BASELINE config C5) -- device-side 10**(0.5 g) + Savitzky-Golay against scipy,
+gain ramp / fused master against the numpy restatement, the strided front-end against the gathered one, and the whole
+of mix_song_smooth / mix_song_to_master at C5's full size (8 stems, 3 minutes @ 44.1 kHz stereo, 59 chunks in one
+eval-mode batch, one hipGraph) against oracle/inference_ref + RefResNet18."""
+import numpy as np
+import pytest
+import torch
+from scipy.signal import savgol_filter
+
+from oracle import features_ref, inference_ref, models_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dam(dam_lib):
+    import deep_audio_mixer_amd as pkg
+    return pkg
+
+
+@pytest.mark.parametrize('n,window,order', [(59, 15, 2), (11, 3, 2), (179, 45, 2), (59, 59, 2), (600, 151, 2),
+                                            (40, 9, 3), (33, 7, 0), (21, 5, 4), (8192, 101, 2)])
+def test_gains_smooth_matches_scipy(dam, n, window, order):
+    """dam_gains_smooth == savgol_filter(10 ** (0.5 * g), window, order) (mode 'interp', edges from the polynomial fit)."""
+    from deep_audio_mixer_amd import ops
+    rng = np.random.default_rng(n + window)
+    S = 5
+    g = (0.3 * rng.standard_normal((n, S)) + np.linspace(-1, 1, S)[None]).astype(np.float32)
+    amp, smooth, s32 = ops.gains_smooth(torch.from_numpy(g).cuda(), window, order, want_f32=True)
+    want_amp = np.power(10.0, 0.5 * g.astype(np.float64)).T
+    np.testing.assert_allclose(amp.cpu().numpy(), want_amp, rtol=1e-13)
+    want = np.stack([savgol_filter(want_amp[s], window, order) for s in range(S)])
+    np.testing.assert_allclose(smooth.cpu().numpy(), want, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(s32.cpu().numpy(), want.astype(np.float32), rtol=1e-6)
+
+
+def test_gains_smooth_rejects_what_scipy_rejects(dam):
+    from deep_audio_mixer_amd import ops
+    g = torch.zeros((7, 2), device='cuda')
+    for window, order in ((4, 2), (3, 3), (9, 2), (1, 2)):
+        with pytest.raises(ValueError):
+            savgol_filter(np.zeros(7), window, order)
+        with pytest.raises(ValueError):
+            ops.gains_smooth(g, window, order)
+
+
+@pytest.mark.parametrize('in_dt,out_dt', [(np.float32, np.float64), (np.float64, np.float64), (np.float32, np.float32),
+                                          (np.float64, np.float32)])
+@pytest.mark.parametrize('n,n_gains', [(100003, 7), (4097, 59), (1000, 1), (64, 64), (777777, 11)])
+def test_gain_ramp_and_master_match_numpy(dam, in_dt, out_dt, n, n_gains):
+    """dam_gain_ramp_apply == track * interpolate_mask(gains, n); dam_mixdown_peak_normalize == sum of those, rows
+    divided by their peak (the callers' librosa.util.normalize(track_sum, axis=1))."""
+    from deep_audio_mixer_amd import ops
+    rng = np.random.default_rng(n)
+    S, ch = 3, 2
+    audio = rng.standard_normal((S, ch, n)).astype(in_dt)
+    gains = rng.uniform(0.2, 2.0, (S, n_gains))
+    t_out = torch.float32 if out_dt == np.float32 else torch.float64
+    got = ops.gain_ramp_apply(torch.from_numpy(audio).cuda(), torch.from_numpy(gains).cuda(), out_dtype=t_out).cpu().numpy()
+    masks = np.stack([inference_ref.interpolate_mask(gains[s], n) if n_gains > 1 else np.full(n, gains[s, 0]) for s in range(S)])
+    want = audio.astype(np.float64) * masks[:, None, :]
+    tol = 1e-6 if out_dt == np.float32 else 1e-14
+    assert got.dtype == out_dt
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
+    one = ops.gain_ramp_apply(torch.from_numpy(audio[1]).cuda(), torch.from_numpy(gains[1]).cuda(), out_dtype=t_out).cpu().numpy()
+    assert np.array_equal(one, got[1])
+    for normalize in (False, True):
+        mix = ops.mixdown_peak_normalize(torch.from_numpy(audio).cuda(), torch.from_numpy(gains).cuda(), normalize=normalize,
+                                         out_dtype=t_out).cpu().numpy()
+        w = want.sum(0)
+        if normalize:
+            w = w / np.abs(w).max(axis=1, keepdims=True)
+        np.testing.assert_allclose(mix, w, rtol=10 * tol, atol=10 * tol)
+
+
+def test_interpolate_mask_host_version(dam):
+    from deep_audio_mixer_amd.inference_utils import interpolate_mask
+    np.testing.assert_array_equal(interpolate_mask(np.array([1., 2., 3.]), 10), [1, 1, 1, 2, 2, 2, 3, 3, 3, 3])
+    rng = np.random.default_rng(0)
+    for n_g, n in ((59, 7938000 // 50), (7, 1001), (5, 5), (1, 9)):
+        g = rng.standard_normal(n_g)
+        np.testing.assert_array_equal(interpolate_mask(g, n), inference_ref.interpolate_mask(g, n))
+
+
+@pytest.mark.parametrize('dtype,ch', [(np.float32, 2), (np.float64, 2), (np.float32, 1)])
+def test_strided_front_end_equals_gathered(dam, dtype, ch):
+    """The chunk batch read in place from the planar song == the same chunks gathered into interleaved tracks first."""
+    from deep_audio_mixer_amd import features
+    rng = np.random.default_rng(3)
+    S, chunk, n_chunks = 3, 16000, 4
+    n = chunk * n_chunks + 1234
+    song = (0.1 * rng.standard_normal((S, ch, n))).astype(dtype)
+    dev = torch.from_numpy(song).cuda()
+    got = features.stft_logmag_song_chunks(dev, n_chunks, chunk, hop=256)
+    tracks = dev[:, :, :n_chunks * chunk].reshape(S, ch, n_chunks, chunk).permute(2, 0, 3, 1).reshape(n_chunks * S, chunk, ch)
+    want = features.stft_logmag(tracks.contiguous(), hop=256)
+    assert got.shape == want.shape == (n_chunks * S, 1025, 63)
+    assert torch.equal(got, want)
+    f = features_ref.compute_features(song[1, :, chunk:2 * chunk].astype(np.float64).mean(0), 2048, 256)
+    from _inputs import feature_error
+    rel, db = feature_error(got[1 * S + 1].cpu().numpy(), f)
+    assert rel <= 2e-6 and db <= 2e-3
+
+
+def _c5_song(n_stems, seconds, sr, seed):
+    rng = np.random.default_rng(seed)
+    n = sr * seconds
+    env = 0.6 + 0.4 * np.sin(2 * np.pi * np.arange(n) / (sr * 17.0))        # slow level changes so the gains move
+    tracks = {}
+    for s in range(n_stems):
+        a = (0.05 + 0.03 * s) * rng.standard_normal((2, n)) * np.roll(env, s * sr * 2)[None]
+        tracks['s%d' % s] = a.astype(np.float32)
+    return tracks
+
+
+def test_c5_full_song_matches_oracle(dam):
+    """BASELINE config C5 at full size: 8 stems x 3 min @ 44.1 kHz stereo float32, chunk_length 3 -> 59 chunks of
+    8 x 1025 x 130 through ResNet18 in eval mode as ONE batch inside one hipGraph; raw gains of every chunk, the smoothed
+    gains, the mixed stems and the normalised master against the oracle (numpy STFT + PyTorch-CPU RefResNet18 chunk by
+    chunk + scipy savgol + numpy mask).  inference_utils.py:105-145, inference.ipynb cell 9."""
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    from deep_audio_mixer_amd import inference_utils
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    sr, seconds, n_stems, chunk_length = 44100, 180, 8, 3
+    stems = ['s%d' % i for i in range(n_stems)]
+    tracks = _c5_song(n_stems, seconds, sr, seed=5)
+    torch.manual_seed(4)
+    torch.set_num_threads(16)
+    ref = models_ref.RefResNet18(n_stems=n_stems, input_shape=(1025, 130))
+    # realistic BatchNorm running statistics: a few training-mode batches of real features on the CPU oracle
+    chunk = chunk_length * sr
+    ref.train()
+    with torch.no_grad():
+        for c in (0, 20, 40):
+            f = np.stack([features_ref.compute_features(tracks[t][:, c * chunk:(c + 1) * chunk].astype(np.float64).mean(0),
+                                                        2048, 1024) for t in stems])
+            ref(torch.from_numpy(f[None].astype(np.float32)))
+    ref.eval()
+    model = ResNet18(n_stems=n_stems, input_shape=(1025, 130))
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda().eval()
+    d = MultitrackAudioDataset.from_arrays({'song': {**{t: tracks[t][:, :sr].T for t in stems}, 'mix': tracks['s0'][:, :sr].T}},
+                                           tracklist=stems + ['mix'], chunk_length=chunk_length, sr=sr)
+
+    def model_fn(feats):
+        with torch.no_grad():
+            return torch.cat(ref(torch.from_numpy(feats))[1], 1)[0].numpy()
+    mixed_r, raw_r, smooth_r = inference_ref.mix_song_smooth(model_fn, tracks, stems, chunk_length, sr)
+
+    mixed, raw, smooth = inference_utils.mix_song_smooth(d, model, tracks, chunk_length=chunk_length, sr=sr)
+    mixer = next(iter(inference_utils._mixers.values()))
+    assert mixer.graph is not None and mixer.n_proc == 59 and mixer.window == 15
+    for t in stems:
+        assert len(raw[t]) == 59
+        np.testing.assert_allclose(raw[t], raw_r[t], rtol=1e-4)              # 1e-4 relative on every chunk's gain
+        np.testing.assert_allclose(smooth[t], smooth_r[t], rtol=1e-4)
+        assert mixed[t].shape == (2, sr * seconds) and mixed[t].dtype == np.float64
+        np.testing.assert_allclose(mixed[t], mixed_r[t], rtol=2e-4, atol=1e-9)
+    # raw gains really differ from chunk to chunk and stem to stem (the comparison above is not trivially satisfied)
+    assert np.std([raw_r[t] for t in stems]) > 1e-3 * np.mean([raw_r[t] for t in stems])
+    # a second song through the same captured graph: replay only
+    graph = mixer.graph
+    tracks2 = {t: np.ascontiguousarray(v[:, ::-1]) for t, v in tracks.items()}
+    _, raw2, _ = inference_utils.mix_song_smooth(d, model, tracks2, chunk_length=chunk_length, sr=sr)
+    assert next(iter(inference_utils._mixers.values())).graph is graph
+    assert not np.allclose(raw2['s0'], raw['s0'])
+    del mixed, mixer
+    # the callers' next step fused: stem sum + per-channel peak normalisation, one graph, one download
+    master, raw_m, smooth_m = inference_utils.mix_song_to_master(d, model, tracks, chunk_length=chunk_length, sr=sr)
+    want = np.sum(np.array([mixed_r[t] for t in stems]), axis=0)
+    want = want / np.abs(want).max(axis=1, keepdims=True)
+    assert master.shape == want.shape and master.dtype == np.float64
+    np.testing.assert_allclose(raw_m['s3'], raw['s3'], rtol=1e-6)
+    np.testing.assert_allclose(master, want, rtol=2e-4, atol=2e-6)
+    assert np.allclose(np.abs(master).max(axis=1), 1.0)
+    m32, _, _ = inference_utils.mix_song_to_master(d, model, tracks, chunk_length=chunk_length, sr=sr, dtype=np.float32)
+    assert m32.dtype == np.float32
+    np.testing.assert_allclose(m32, want, rtol=2e-4, atol=4e-6)
+    inference_utils._mixers.clear()
+
+
+def test_training_mode_model_runs_chunk_by_chunk(dam):
+    """A model left in training mode (the reference never calls .eval()) is applied one chunk at a time
+    with batch statistics, as the reference loop does; no graph."""
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    from deep_audio_mixer_amd import inference_utils
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    sr, n_chunks = 16000, 13
+    rng = np.random.default_rng(8)
+    tracks = {t: 0.1 * rng.standard_normal((2, sr * n_chunks + 77)) for t in ('bass', 'drums')}
+    torch.manual_seed(2)
+    model = ResNet18(n_stems=2, input_shape=(1025, 16)).cuda().train()
+    d = MultitrackAudioDataset.from_arrays({'x': {**{t: v.T for t, v in tracks.items()}, 'mix': tracks['bass'].T}},
+                                           chunk_length=1, sr=sr, tracklist=['bass', 'drums', 'mix'])
+    before = model.bn1.num_batches_tracked.item()
+    mixed, raw, smooth = inference_utils.mix_song_smooth(d, model, tracks, chunk_length=1, sr=sr)
+    assert len(raw['bass']) == n_chunks - 1 and model.bn1.num_batches_tracked.item() == before + n_chunks - 1
+    assert next(iter(inference_utils._mixers.values())).graph is None
+    want = tracks['drums'] * inference_ref.interpolate_mask(smooth['drums'], tracks['drums'].shape[1])
+    np.testing.assert_allclose(mixed['drums'], want, rtol=1e-12)
+    inference_utils._mixers.clear()

@@ -128,6 +128,43 @@ def test_baseline_configs_against_oracle(dam, name, n_stems, shape):
         assert (a - b).norm().item() <= 2e-2 * b.norm().item() + 1e-5 * gmax, n
 
 
+@pytest.mark.parametrize('name', ['resnet18', 'scalar1s', 'scalar2s'])
+def test_gradients_against_f32_cpu_oracle(dam, name, golden_dir):
+    """Composition-level gradient check at float32 against float32: the same fill, the same input, the oracle on the CPU
+    in float32.  Both sides then take (almost always) the same ReLU decisions, so the bounds can be two orders tighter
+    than against the float64 goldens: per-tensor gradient norms within 2e-3, and a COUNT bound on entries that are off
+    by more than 1e-3 of the tensor's largest entry -- ReLU flips are sparse, a wrong tap or halo is not."""
+    meta = json.load(open(os.path.join(golden_dir, 'models.json')))
+    ctor, ref_ctor = dam[name]
+    x, gt = model_input(*meta[name]['shape'], seed=meta[name]['seed'])
+    ref = no_dropout(models_ref.closed_form_fill(ref_ctor())).train()
+    model = no_dropout(ctor())
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda().train()
+    torch.set_num_threads(16)
+    masked_r, gains_r = ref(torch.from_numpy(x))
+    loss_r = torch.nn.functional.mse_loss(masked_r, torch.from_numpy(gt))
+    loss_r.backward()
+    loss, masked, gains = model.forward_mse(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda())
+    loss.backward()
+    assert rel_err(torch.cat(gains, 1).detach().cpu().numpy(), torch.cat(gains_r, 1).detach().numpy()) <= GAIN_RTOL
+    assert abs(loss.item() - loss_r.item()) <= 1e-4 * abs(loss_r.item())
+    grads = ref_named_grads(model)
+    gmax = max(p.grad.norm().item() for p in ref.parameters())
+    worst_norm, worst_frac, total_bad, total = 0.0, 0.0, 0, 0
+    for n, p in ref.named_parameters():
+        a, b = grads[n].detach().double().cpu().flatten(), p.grad.double().flatten()
+        # conv biases in front of a training-mode BatchNorm have an exactly-zero true gradient: absolute term
+        nerr = abs(a.norm().item() - b.norm().item()) / (b.norm().item() + 1e-5 * gmax)
+        off = ((a - b).abs() > 1e-3 * b.abs().max().item() + 1e-6 * gmax).sum().item()
+        worst_norm, worst_frac = max(worst_norm, nerr), max(worst_frac, off / a.numel())
+        total_bad, total = total_bad + off, total + a.numel()
+        assert nerr <= 2e-3, (n, nerr)
+        assert off <= max(2, 0.02 * a.numel()), (n, off, a.numel())
+    assert total_bad <= 2e-3 * total, (total_bad, total)
+    print('%s: worst norm err %.2e, worst off-fraction %.2e, off entries %d / %d' % (name, worst_norm, worst_frac, total_bad, total))
+
+
 def test_forward_mse_equals_unfused(dam):
     ctor, _ = dam['resnet18']
     torch.manual_seed(0)
