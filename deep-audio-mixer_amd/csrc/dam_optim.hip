@@ -10,12 +10,13 @@
 namespace dam {
 namespace {
 
-// hyper (optional, device): {lr, beta1, beta2, eps, weight_decay, grad_scale} -- read at run time so that a captured
-// hipGraph follows param_groups edits / LR schedulers; nullptr = the scalar arguments (baked into the launch).
-struct AdamHyper { float lr, beta1, beta2, eps, wd, gscale; };
+// hyper (optional, device): {lr, beta1, beta2, eps, weight_decay, grad_scale, 1-beta1, 1-beta2} -- read at run time so
+// that a captured hipGraph follows param_groups edits / LR schedulers; nullptr = the scalar arguments (baked into the
+// launch).  1-beta is formed in double on the host, as torch does (1.0f - 0.999f is off by 5e-5 relative).
+struct AdamHyper { float lr, beta1, beta2, eps, wd, gscale, omb1, omb2; };
 
 __device__ __forceinline__ AdamHyper load_hyper(const float* __restrict__ h, AdamHyper k) {
-    if (h) { k.lr = h[0]; k.beta1 = h[1]; k.beta2 = h[2]; k.eps = h[3]; k.wd = h[4]; k.gscale = h[5]; }
+    if (h) { k.lr = h[0]; k.beta1 = h[1]; k.beta2 = h[2]; k.eps = h[3]; k.wd = h[4]; k.gscale = h[5]; k.omb1 = h[6]; k.omb2 = h[7]; }
     return k;
 }
 
@@ -32,8 +33,8 @@ __global__ void adam_tick_kernel(long long* __restrict__ step, float* __restrict
 
 __device__ __forceinline__ void adam_one(float& pv, float gv, float& mv, float& vv, const AdamHyper& k, float step_size, float bc2s) {
     gv = fmaf(k.wd, pv, gv * k.gscale);
-    mv = fmaf(k.beta1, mv, (1.0f - k.beta1) * gv);         // lerp form: m + (g - m)*(1-b1) differs by rounding only
-    vv = fmaf(k.beta2, vv, (1.0f - k.beta2) * gv * gv);
+    mv = fmaf(k.beta1, mv, k.omb1 * gv);         // lerp form: m + (g - m)*(1-b1) differs by rounding only
+    vv = fmaf(k.beta2, vv, k.omb2 * gv * gv);
     const float denom = sqrtf(vv) / bc2s + k.eps;
     pv = pv - step_size * (mv / denom);
 }
@@ -71,7 +72,7 @@ extern "C" int dam_adam_l2_step_f32(float* params, const float* grads, float* ex
     if (!params || !grads || !exp_avg || !exp_avg_sq || !step || !derived2 || n <= 0) return DAM_ERR_BAD_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return DAM_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const AdamHyper k{lr, beta1, beta2, eps, weight_decay, grad_scale};
+    const AdamHyper k{lr, beta1, beta2, eps, weight_decay, grad_scale, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2)};
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, (long long*)step, derived2, hyper_dev, k);
     DAM_CHECK_LAUNCH();
     int64_t blocks = cdiv(n / 4 + 1, 256);

@@ -341,7 +341,7 @@ def masksum_mse(x, gains, gt, want_masked=True):
 # ----------------------------------------------------------------------------- optimizer
 def adam_l2_step(params, grads, exp_avg, exp_avg_sq, step, derived, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0,
                  hyper=None):
-    """hyper: optional CUDA float32[6] {lr, beta1, beta2, eps, weight_decay, grad_scale} read by the kernel at run time
+    """hyper: optional CUDA float32[8] {lr, beta1, beta2, eps, weight_decay, grad_scale, 1-beta1, 1-beta2} read by the kernel at run time
     (a captured graph then follows hyper-parameter edits); the scalars are used when it is None."""
     _lib.require_cuda(params, grads, hyper)
     _lib.check(_lib.lib().dam_adam_l2_step_f32(_lib.ptr(params), _lib.ptr(grads), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),

@@ -51,7 +51,7 @@ class Adam(torch.optim.Optimizer):
         self._exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self._step = torch.zeros(1, dtype=torch.int64, device=dev)
         self._derived = torch.zeros(2, dtype=torch.float32, device=dev)
-        self._hyper = torch.zeros(6, dtype=torch.float32, device=dev)
+        self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._hyper_host = None
         self.process_group, self.world_size = process_group, world_size
         self._bucket_params = [(0, len(self._params))]           # parameter index ranges, in flat-buffer order
@@ -60,8 +60,8 @@ class Adam(torch.optim.Optimizer):
     # ---- hyper-parameters on the device
     def _hyper_tuple(self):
         g = self.param_groups[0]
-        return (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']),
-                1.0 / self.world_size)
+        b1, b2 = float(g['betas'][0]), float(g['betas'][1])
+        return (float(g['lr']), b1, b2, float(g['eps']), float(g['weight_decay']), 1.0 / self.world_size, 1.0 - b1, 1.0 - b2)
 
     def sync_hyper(self):
         """Uploads {lr, betas, eps, weight_decay, 1/world} if param_groups changed since the last call (six floats;

@@ -230,8 +230,9 @@ int dam_masksum_mse_f32(const float* x, const float* gains, const float* gt, int
  * weight_decay=wd) (training.ipynb cell 11; L2 folded into the gradient, not AdamW) over one flat
  * parameter buffer.  step: device int64 counter (incremented here); derived2: device float[2] scratch.
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce).
- * hyper_dev (optional): DEVICE float[6] = {lr, beta1, beta2, eps, weight_decay, grad_scale} read at run time instead
- * of the scalar arguments, so that a captured graph follows param_groups edits / LR schedulers.
+ * hyper_dev (optional): DEVICE float[8] = {lr, beta1, beta2, eps, weight_decay, grad_scale, 1-beta1, 1-beta2} read at
+ * run time instead of the scalar arguments, so that a captured graph follows param_groups edits / LR schedulers
+ * (1-beta formed in double by the caller, as torch does).
  * All four buffers must be 16-byte aligned.
  * --------------------------------------------------------------------------------- */
 int dam_adam_l2_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -128,41 +128,53 @@ def test_baseline_configs_against_oracle(dam, name, n_stems, shape):
         assert (a - b).norm().item() <= 2e-2 * b.norm().item() + 1e-5 * gmax, n
 
 
-@pytest.mark.parametrize('name', ['resnet18', 'scalar1s', 'scalar2s'])
-def test_gradients_against_f32_cpu_oracle(dam, name, golden_dir):
-    """Composition-level gradient check at float32 against float32: the same fill, the same input, the oracle on the CPU
-    in float32.  Both sides then take (almost always) the same ReLU decisions, so the bounds can be two orders tighter
-    than against the float64 goldens: per-tensor gradient norms within 2e-3, and a COUNT bound on entries that are off
-    by more than 1e-3 of the tensor's largest entry -- ReLU flips are sparse, a wrong tap or halo is not."""
-    meta = json.load(open(os.path.join(golden_dir, 'models.json')))
+@pytest.mark.parametrize('name,shape', [('resnet18', (2, 4, 257, 64)), ('scalar1s', (2, 4, 257, 87)), ('scalar2s', (2, 4, 257, 93))])
+def test_gradients_tight_when_no_relu_flips(dam, name, shape):
+    """Composition-level gradient check at float32 tightness.  Measured (tools/grad_accuracy_probe.py): without a ReLU
+    decision flipping, the HIP path's activation gradients agree with the float64 oracle to ~1.5e-6 through all twelve
+    blocks -- and so does the CPU float32 oracle; ONE flipped decision (|pre-activation| below the ~1e-6 forward rounding
+    error: a handful of the ~10 M activations of a full-size clip) moves every gradient upstream of it by 2-5e-3, in the
+    CPU float32 run exactly as in the HIP run.  That is why the checks against the float64 goldens sit at 1e-2.
+    Here the flips are taken out of the comparison instead: moderate shapes (few activations near zero), four seeds, and
+    for every parameter tensor the BEST agreement over the seeds -- a tensor only needs the layers behind it to be
+    flip-free in one of the runs -- must reach float32 level: 3x the CPU float32 oracle's own best distance to the
+    float64 truth, floor 2e-5 of the tensor norm.  A wrong tap, halo, stride or mask is off by O(1) in every run."""
     ctor, ref_ctor = dam[name]
-    x, gt = model_input(*meta[name]['shape'], seed=meta[name]['seed'])
-    ref = no_dropout(models_ref.closed_form_fill(ref_ctor())).train()
-    model = no_dropout(ctor())
-    model.load_state_dict(ref.state_dict())
-    model = model.cuda().train()
     torch.set_num_threads(16)
-    masked_r, gains_r = ref(torch.from_numpy(x))
-    loss_r = torch.nn.functional.mse_loss(masked_r, torch.from_numpy(gt))
-    loss_r.backward()
-    loss, masked, gains = model.forward_mse(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda())
-    loss.backward()
-    assert rel_err(torch.cat(gains, 1).detach().cpu().numpy(), torch.cat(gains_r, 1).detach().numpy()) <= GAIN_RTOL
-    assert abs(loss.item() - loss_r.item()) <= 1e-4 * abs(loss_r.item())
-    grads = ref_named_grads(model)
-    gmax = max(p.grad.norm().item() for p in ref.parameters())
-    worst_norm, worst_frac, total_bad, total = 0.0, 0.0, 0, 0
-    for n, p in ref.named_parameters():
-        a, b = grads[n].detach().double().cpu().flatten(), p.grad.double().flatten()
-        # conv biases in front of a training-mode BatchNorm have an exactly-zero true gradient: absolute term
-        nerr = abs(a.norm().item() - b.norm().item()) / (b.norm().item() + 1e-5 * gmax)
-        off = ((a - b).abs() > 1e-3 * b.abs().max().item() + 1e-6 * gmax).sum().item()
-        worst_norm, worst_frac = max(worst_norm, nerr), max(worst_frac, off / a.numel())
-        total_bad, total = total_bad + off, total + a.numel()
-        assert nerr <= 2e-3, (n, nerr)
-        assert off <= max(2, 0.02 * a.numel()), (n, off, a.numel())
-    assert total_bad <= 2e-3 * total, (total_bad, total)
-    print('%s: worst norm err %.2e, worst off-fraction %.2e, off entries %d / %d' % (name, worst_norm, worst_frac, total_bad, total))
+    s, hw = shape[1], shape[2:]
+    ref32 = no_dropout(models_ref.closed_form_fill(ref_ctor(n_stems=s, input_shape=hw))).train()
+    ref64 = no_dropout(models_ref.closed_form_fill(ref_ctor(n_stems=s, input_shape=hw))).double().train()
+    model = no_dropout(ctor(n_stems=s, input_shape=hw))
+    model.load_state_dict(ref32.state_dict())
+    model = model.cuda().train()
+    state = {k: v.clone() for k, v in ref32.state_dict().items()}
+    names = [n for n, _ in ref64.named_parameters()]
+    best_hip, best_cpu = {n: np.inf for n in names}, {n: np.inf for n in names}
+    for seed in (31, 32, 33, 34):
+        x, gt = model_input(*shape, seed=seed)
+        for m in (ref32, ref64, model):
+            m.load_state_dict(state)              # BatchNorm running statistics back to the start; same parameters
+            m.zero_grad()
+        for ref, dt in ((ref32, torch.float32), (ref64, torch.float64)):
+            masked_r, _ = ref(torch.from_numpy(x).to(dt))
+            torch.nn.functional.mse_loss(masked_r, torch.from_numpy(gt).to(dt)).backward()
+        model.forward_mse(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda())[0].backward()
+        grads = ref_named_grads(model)
+        p32 = dict(ref32.named_parameters())
+        gmax = max(p.grad.norm().item() for p in ref64.parameters())
+        for n, p in ref64.named_parameters():
+            truth = p.grad.flatten()
+            scale = truth.norm().item() + 1e-5 * gmax   # conv biases in front of a training-mode BatchNorm: true gradient 0
+            e_hip = (grads[n].detach().double().cpu().flatten() - truth).norm().item() / scale
+            e_cpu = (p32[n].grad.double().flatten() - truth).norm().item() / scale
+            assert e_hip <= 1e-1, (n, seed, e_hip)    # with a flip or two in the run: sanity bound only
+            best_hip[n], best_cpu[n] = min(best_hip[n], e_hip), min(best_cpu[n], e_cpu)
+    rows = sorted(((best_hip[n] / max(best_cpu[n], 2e-5 / 3), n, best_hip[n], best_cpu[n]) for n in names), reverse=True)
+    print('%s: worst (ratio, tensor, best hip err, best cpu-f32 err): %s'
+          % (name, [(round(r, 2), n, '%.1e' % a, '%.1e' % b) for r, n, a, b in rows[:4]]))
+    print('%s: median best hip err %.1e, cpu-f32 %.1e' % (name, np.median([r[2] for r in rows]), np.median([r[3] for r in rows])))
+    bad = [(n, a, b) for r, n, a, b in rows if a > max(3 * b, 2e-5)]
+    assert not bad, bad[:5]
 
 
 def test_forward_mse_equals_unfused(dam):
