@@ -25,7 +25,7 @@ import numpy as np
 import torch
 from torch.utils import data
 
-from .. import features
+from .. import features, staging
 from .dataset_utils import read_wav, wav_num_frames
 
 
@@ -172,7 +172,7 @@ class MultitrackAudioDataset(data.Dataset):
 
         with ThreadPoolExecutor(max_workers=workers) as pool:
             cur = torch.cuda.current_stream(self._device)
-            uploaded[0].synchronize()
+            staging._wait(uploaded[0])
             decode(0, groups[0])
             for j, group in enumerate(groups):
                 slot, B = j % 2, len(group)
@@ -181,7 +181,7 @@ class MultitrackAudioDataset(data.Dataset):
                     dev[slot][:B].copy_(host[slot][:B], non_blocking=True)
                     uploaded[slot].record(copy_stream)
                 if j + 1 < len(groups):                                # decode the next batch while this one travels
-                    uploaded[1 - slot].synchronize()                   # its previous upload has left the host buffer
+                    staging._wait(uploaded[1 - slot])                  # its previous upload has left the host buffer
                     decode(1 - slot, groups[j + 1])
                 cur = torch.cuda.current_stream(self._device)
                 cur.wait_event(uploaded[slot])

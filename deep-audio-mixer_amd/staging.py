@@ -2,7 +2,7 @@
 
 The reference hands pageable numpy arrays to ``tensor.to(device)`` (model_trainer.py:34, inference_utils.py:123): the
 driver then bounces them through its own small staging buffer, single-threaded, at a few GB/s.  Here the bounce is
-explicit: two page-locked buffers, the host copy into buffer k+1 (torch's multi-threaded CPU copy) runs while the DMA
+explicit: two page-locked buffers, the host copy into buffer k+1 (a few numpy-copy threads) runs while the DMA
 engine moves buffer k on a dedicated copy stream, and the compute stream only waits on an event.  The same pipe in
 reverse brings results back.  PyTorch supplies the page-locked memory, the streams and the events; nothing is
 computed here.
@@ -11,6 +11,35 @@ import numpy as np
 import torch
 
 PIECE_BYTES = 32 << 20
+
+
+_copy_pool = None
+HOST_COPY_THREADS = 4
+
+
+def _wait(event):
+    """Host-side wait for a recorded event (DMA pieces that take well under a millisecond): poll, do not sleep."""
+    while not event.query():
+        pass
+
+
+def _host_copy(dst, src):
+    """dst, src: equally long contiguous uint8 CPU tensors.  A few plain threads doing numpy copies (the GIL is released
+    inside), NOT torch's copy_: that fans out over every OpenMP thread torch was given -- 128 on a box whose cgroup grants
+    a 16-core share -- and the spinning team burns the process's CPU quota: the kernel then throttles the whole process
+    for the rest of its 100 ms period (measured as one or two 70-95 ms stalls per song, landing in whatever host call
+    came next; tools/c5_phase_probe.py)."""
+    global _copy_pool
+    d, s = dst.numpy(), src.numpy()
+    n = d.shape[0]
+    if n < (4 << 20):
+        np.copyto(d, s)
+        return
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _copy_pool = ThreadPoolExecutor(max_workers=HOST_COPY_THREADS)
+    step = -(-n // HOST_COPY_THREADS)
+    list(_copy_pool.map(lambda lo: np.copyto(d[lo:lo + step], s[lo:lo + step]), range(0, n, step)))
 
 
 class PinnedPipe:
@@ -27,7 +56,7 @@ class PinnedPipe:
     def _next(self):
         i = self._turn
         self._turn = (i + 1) % len(self.bufs)
-        self.free[i].synchronize()              # the previous transfer through this buffer has finished
+        _wait(self.free[i])                     # the previous transfer through this buffer has finished
         return i
 
     def upload(self, dst, src):
@@ -43,7 +72,7 @@ class PinnedPipe:
         for lo in range(0, n, self.piece_bytes):
             hi = min(lo + self.piece_bytes, n)
             i = self._next()
-            self.bufs[i][:hi - lo].copy_(s8[lo:hi])                     # pageable -> page-locked (multi-threaded memcpy)
+            _host_copy(self.bufs[i][:hi - lo], s8[lo:hi])               # pageable -> page-locked
             with torch.cuda.stream(self.stream):
                 d8[lo:hi].copy_(self.bufs[i][:hi - lo], non_blocking=True)
                 self.free[i].record(self.stream)
@@ -62,12 +91,12 @@ class PinnedPipe:
         nb = len(self.bufs)
         pieces = [(lo, min(lo + self.piece_bytes, n)) for lo in range(0, n, self.piece_bytes)]
         for ev in self.free:
-            ev.synchronize()                                            # nothing else is in flight through the buffers
+            _wait(ev)                                                   # nothing else is in flight through the buffers
 
         def drain(k):                                                   # page-locked -> pageable once piece k has landed
             lo, hi = pieces[k]
-            self.free[k % nb].synchronize()
-            r8[lo:hi].copy_(self.bufs[k % nb][:hi - lo])
+            _wait(self.free[k % nb])
+            _host_copy(r8[lo:hi], self.bufs[k % nb][:hi - lo])
 
         for k, (lo, hi) in enumerate(pieces):
             if k >= nb:
