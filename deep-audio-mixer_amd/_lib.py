@@ -28,16 +28,16 @@ SIGNATURES = {
     'dam_conv_pack_weights_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'dam_conv_pack_weights_multi_f32': (c_i, [c_p, c_i, c_i64, c_p]),
     'dam_conv2d_tapgrid_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p] +
-                               [c_i] * 17 + [c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+                               [c_i] * 17 + [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     'dam_conv2d_wgrad_workspace_floats': (c_i64, [c_i, c_i, c_i, c_i]),
     'dam_conv2d_wgrad_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p] + [c_i] * 9 +
-                             [c_p, c_p, c_i64, c_p]),
+                             [c_p, c_i, c_p, c_i64, c_p]),
     'dam_bn_workspace_floats': (c_i64, [c_i]),
-    'dam_bn_stats_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'dam_bn_stats_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_finalize_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_eval_affine_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_apply_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
-    'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'dam_channel_sum_f32': (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
     'dam_dropout_tick': (c_i, [c_p, c_i64, c_p, c_p]),
     'dam_dropout_apply_f32': (c_i, [c_p, c_i64, c_f, ctypes.c_uint64, c_p, c_p, c_p]),
@@ -58,6 +58,15 @@ SIGNATURES = {
     'dam_loudness_workspace_bytes': (c_i64, [c_i64, c_i]),
     'dam_loudness_block_energy': (c_i, [c_p, c_i, c_i64, c_i, c_i64, c_i64, c_p, c_p, c_p, c_i, c_d, c_p, c_p, c_p]),
 }
+
+
+
+class BnFin(ctypes.Structure):
+    """struct dam_bn_fin (include/dam_hip.h): device pointers for an in-kernel BatchNorm finalize."""
+    _fields_ = [('gamma', c_p), ('beta', c_p), ('running_mean', c_p), ('running_var', c_p), ('num_batches_tracked', c_p),
+                ('momentum', c_f), ('eps', c_f), ('save_mean', c_p), ('save_invstd', c_p), ('scale', c_p), ('shift', c_p),
+                ('counter', c_p)]
+
 
 _lib = None
 

@@ -16,6 +16,7 @@
 //   * backward: one reduction pass (sum dz, sum dz*xhat; dz = dy * (y > 0)) and one apply pass
 //     dx = c1*dz + c2*x + c3 with per-channel constants.
 #include "dam_common.h"
+#include "dam_bn_fin.h"
 
 namespace dam {
 namespace {
@@ -39,8 +40,8 @@ inline BnLaunch bn_plan(int64_t P, int C) {
 }
 
 __global__ void bn_stats_partial_kernel(const float* __restrict__ x, int64_t P, int C, int Q, int R, int64_t ppb,
-                                        float* __restrict__ partial /* [parts][C][3] */) {
-    extern __shared__ float sm[];    // [R][C][3]
+                                        float* __restrict__ partial /* [parts][C][3] */, const BnFinArgs fin) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];    // [R][C][3]
     const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
     const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
     float k[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -103,8 +104,13 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ x, int64_t P, 
             const int c = cq * 4 + i;
             const float* a = sm + (size_t)c * 3;
             float* out = partial + ((size_t)blockIdx.x * C + c) * 3;
-            out[0] = a[0]; out[1] = a[1]; out[2] = a[2];
+            store_sc1(out, a[0]); store_sc1(out + 1, a[1]); store_sc1(out + 2, a[2]);
         }
+    }
+    if (fin.counter) {      // the last workgroup to arrive merges all records (dam_bn_fin.h): no finalize launch
+        __shared__ unsigned ticket;
+        if (block_arrive_last(fin.counter, gridDim.x, &ticket))
+            bn_stats_finalize_block(partial, (int)gridDim.x, C, fin, reinterpret_cast<double*>(sm), threadIdx.x, blockDim.x);
     }
 }
 
@@ -117,27 +123,39 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __re
                                          float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c == 0 && lane == 0 && num_batches) *num_batches += 1;
-    double na = 0, ma = 0, qa = 0;
-    for (int p = lane; p < parts; p += 64) {
+    // Every lane requests ALL its records (<= 16: parts <= 1024) before it touches the first: the records come from other
+    // XCDs' workgroups, each load is a memory-side round trip, and a load-merge-load chain made this 5 us kernel cost 5-7 us.
+    // Merging is two plain wave reductions instead of a chain of Chan updates (no divide per record):
+    //   N = sum n_i,  mu = sum n_i mean_i / N,  M2 = sum (m2_i + n_i (mean_i - mu)^2).
+    constexpr int U = 16;
+    float rn[U], rmn[U], rq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = lane + 64 * u;
+        const float* o = partial + ((size_t)(p < parts ? p : 0) * C + c) * 3;
+        rn[u] = o[0]; rmn[u] = o[1]; rq[u] = o[2];
+        if (p >= parts) rn[u] = 0.f;
+    }
+    double na = 0, sa = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { na += (double)rn[u]; sa += (double)rn[u] * (double)rmn[u]; }
+    for (int p = lane + 64 * U; p < parts; p += 64) {        // more than 1024 records: not produced by this library
         const float* o = partial + ((size_t)p * C + c) * 3;
-        const double nb = o[0];
-        if (nb == 0) continue;
-        const double nn = na + nb, d = (double)o[1] - ma;
-        ma += d * (nb / nn);
-        qa += (double)o[2] + d * d * (na * nb / nn);
-        na = nn;
+        na += (double)o[0]; sa += (double)o[0] * (double)o[1];
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double nb = __shfl_down(na, off), mb = __shfl_down(ma, off), qb = __shfl_down(qa, off);
-        const double nn = na + nb;
-        if (nb != 0) {
-            const double d = mb - ma;
-            ma += d * (nb / nn);
-            qa += qb + d * d * (na * nb / nn);
-            na = nn;
-        }
+    for (int off = 32; off >= 1; off >>= 1) { na += __shfl_xor(na, off); sa += __shfl_xor(sa, off); }
+    const double ma = sa / na;
+    double qa = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const double d = (double)rmn[u] - ma; qa += (double)rq[u] * (rn[u] != 0.f ? 1.0 : 0.0) + (double)rn[u] * d * d; }
+    for (int p = lane + 64 * U; p < parts; p += 64) {
+        const float* o = partial + ((size_t)p * C + c) * 3;
+        const double d = (double)o[1] - ma;
+        qa += (double)o[2] + (double)o[0] * d * d;
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) qa += __shfl_xor(qa, off);
     if (lane != 0) return;
     const double var = qa / na;
     const float mean = (float)ma;
@@ -190,6 +208,55 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t nquads, int
     }
 }
 
+struct BnBwdFin {
+    double count;
+    const float* gamma; const float* mean; const float* invstd;
+    int training;
+    float* dgamma; float* dbeta; float* coef;      // coef [3][C]
+    unsigned* counter;                             // null: separate finalize launch
+};
+
+// dgamma / dbeta and the three per-channel constants of the apply pass from the partial sums [parts][C][2].
+// Thread layout as bn_stats_finalize_block: channel = t % W, slice = t / W; scratch >= nthreads * 2 doubles.
+__device__ __forceinline__ void bn_bwd_finalize_block(const float* partial, int parts, int C, const BnBwdFin& f,
+                                                      double* scratch, int tid, int nthreads) {
+    const int W = C < nthreads ? C : nthreads, S = nthreads / W;
+    for (int c0 = 0; c0 < C; c0 += nthreads) {
+        const int c = c0 + tid % W, sl = tid / W;
+        double s1 = 0, s2 = 0;
+        if (c < C && sl < S) {
+            constexpr int U = 8;            // eight records in flight per thread (see bn_stats_finalize_block)
+            for (int p0 = sl; p0 < parts; p0 += S * U) {
+                float ra[U], rb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * S;
+                    const float* o = partial + ((size_t)(p < parts ? p : sl) * C + c) * 2;
+                    ra[u] = load_sc1(o); rb[u] = load_sc1(o + 1);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (p0 + u * S < parts) { s1 += (double)ra[u]; s2 += (double)rb[u]; }
+            }
+        }
+        scratch[tid * 2] = s1; scratch[tid * 2 + 1] = s2;
+        __syncthreads();
+        if (sl == 0 && c < C) {
+            for (int s = 1; s < S; ++s) { s1 += scratch[(size_t)(tid + s * W) * 2]; s2 += scratch[(size_t)(tid + s * W) * 2 + 1]; }
+            f.dbeta[c] = (float)s1;
+            f.dgamma[c] = (float)s2;
+            const double g = (double)f.gamma[c] * f.invstd[c];
+            double c2 = 0, c3 = 0;
+            if (f.training) {
+                c2 = -g * f.invstd[c] * s2 / f.count;
+                c3 = -g * s1 / f.count - c2 * f.mean[c];
+            }
+            f.coef[c] = (float)g; f.coef[C + c] = (float)c2; f.coef[2 * C + c] = (float)c3;
+        }
+        __syncthreads();
+    }
+}
+
 // partial[blk][c] = (sum dz, sum dz*xhat)
 // MASK: 0 none, 1 from y_mask (saved output), 2 recomputed as fma(x, mscale, mshift) > 0 -- the forward's own expression, so
 // the bits agree and the saved activation is not read at all
@@ -198,8 +265,8 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float*
                                       const float* __restrict__ x, int64_t P, int C, int Q, int R, int64_t ppb,
                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                       const float* __restrict__ mscale, const float* __restrict__ mshift,
-                                      float* __restrict__ partial /* [parts][C][2] */) {
-    extern __shared__ float sm[];    // [R][C][2]
+                                      float* __restrict__ partial /* [parts][C][2] */, const BnBwdFin fin) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];    // [R][C][2]
     const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
     const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
     const float4 mu = reinterpret_cast<const float4*>(mean)[cq], is = reinterpret_cast<const float4*>(invstd)[cq];
@@ -253,9 +320,14 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float*
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = cq * 4 + i;
-            partial[((size_t)blockIdx.x * C + c) * 2] = sm[(size_t)c * 2];
-            partial[((size_t)blockIdx.x * C + c) * 2 + 1] = sm[(size_t)c * 2 + 1];
+            store_sc1(partial + ((size_t)blockIdx.x * C + c) * 2, sm[(size_t)c * 2]);
+            store_sc1(partial + ((size_t)blockIdx.x * C + c) * 2 + 1, sm[(size_t)c * 2 + 1]);
         }
+    }
+    if (fin.counter) {      // the last workgroup to arrive finalizes (dam_bn_fin.h)
+        __shared__ unsigned ticket;
+        if (block_arrive_last(fin.counter, gridDim.x, &ticket))
+            bn_bwd_finalize_block(partial, (int)gridDim.x, C, fin, reinterpret_cast<double*>(sm), threadIdx.x, blockDim.x);
     }
 }
 
@@ -272,7 +344,19 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
                                        float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0, s2 = 0;
-    for (int p = lane; p < parts; p += 64) { s1 += partial[((size_t)p * C + c) * 2]; s2 += partial[((size_t)p * C + c) * 2 + 1]; }
+    {   // all loads of the lane in flight before the first add (see bn_stats_finalize_kernel)
+        constexpr int U = 16;
+        float ra[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = lane + 64 * u;
+            const float* o = partial + ((size_t)(p < parts ? p : 0) * C + c) * 2;
+            ra[u] = p < parts ? o[0] : 0.f; rb[u] = p < parts ? o[1] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s1 += (double)ra[u]; s2 += (double)rb[u]; }
+        for (int p = lane + 64 * U; p < parts; p += 64) { s1 += partial[((size_t)p * C + c) * 2]; s2 += partial[((size_t)p * C + c) * 2 + 1]; }
+    }
     s1 = wave_sum64_f64(s1);
     s2 = wave_sum64_f64(s2);
     if (lane != 0) return;
@@ -374,19 +458,23 @@ extern "C" int64_t dam_bn_workspace_floats(int C) { return (int64_t)BN_MAX_PARTS
 extern "C" int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                 float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
-                                float* shift, float* workspace, void* stream) {
+                                float* shift, float* workspace, uint32_t* counter, void* stream) {
     if (!x || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift || !workspace || n_pixels <= 0)
         return DAM_ERR_BAD_ARG;
     if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
     const BnLaunch l = bn_plan(n_pixels, C);
     hipStream_t st = (hipStream_t)stream;
+    const BnFinArgs fin{gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
+                        save_mean, save_invstd, scale, shift, counter};
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st,
-                       x, n_pixels, C, l.q, l.r, l.ppb, workspace);
+                       x, n_pixels, C, l.q, l.r, l.ppb, workspace, fin);
     DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
-                       gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
-                       save_mean, save_invstd, scale, shift);
-    DAM_CHECK_LAUNCH();
+    if (!counter) {
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
+                           gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
+                           save_mean, save_invstd, scale, shift);
+        DAM_CHECK_LAUNCH();
+    }
     return DAM_OK;
 }
 
@@ -430,7 +518,7 @@ extern "C" int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const f
 extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
                                    const float* gamma, const float* save_mean, const float* save_invstd, int training,
                                    const float* mask_scale, const float* mask_shift, float* dx, float* dgamma, float* dbeta,
-                                   float* workspace, void* stream) {
+                                   float* workspace, uint32_t* counter, void* stream) {
     if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || n_pixels <= 0)
         return DAM_ERR_BAD_ARG;
     if ((mask_scale != nullptr) != (mask_shift != nullptr) || (y_mask && mask_scale)) return DAM_ERR_BAD_ARG;
@@ -439,15 +527,18 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + (size_t)BN_MAX_PARTS * C * 2;    // workspace holds [parts][C][2] then [3][C]
     const int mask = y_mask ? 1 : (mask_scale ? 2 : 0);
+    const BnBwdFin fin{(double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef, counter};
 #define DAM_BN_PARTIAL(M_)                                                                                                   \
     hipLaunchKernelGGL(bn_bwd_partial_kernel<M_>, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 2 * sizeof(float), st, dy, \
-                       y_mask, x, n_pixels, C, l.q, l.r, l.ppb, save_mean, save_invstd, mask_scale, mask_shift, workspace)
+                       y_mask, x, n_pixels, C, l.q, l.r, l.ppb, save_mean, save_invstd, mask_scale, mask_shift, workspace, fin)
     if (mask == 1) DAM_BN_PARTIAL(1); else if (mask == 2) DAM_BN_PARTIAL(2); else DAM_BN_PARTIAL(0);
 #undef DAM_BN_PARTIAL
     DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
-                       (double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef);
-    DAM_CHECK_LAUNCH();
+    if (!counter) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
+                           (double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef);
+        DAM_CHECK_LAUNCH();
+    }
     const int64_t nq = n_pixels * (C / 4);
 #define DAM_BN_APPLY(M_)                                                                                                     \
     hipLaunchKernelGGL(bn_bwd_apply_kernel<M_>, dim3(elt_blocks(nq)), dim3(256), 0, st, dy, y_mask, x, nq, C / 4, C, coef,   \

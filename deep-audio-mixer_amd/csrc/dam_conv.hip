@@ -24,6 +24,7 @@
 #include "dam_common.h"
 #include "dam_conv_geo.h"
 #include "dam_conv_stage.h"
+#include "dam_bn_fin.h"
 
 namespace dam {
 
@@ -391,9 +392,17 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
                                       int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                                       int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                                       const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
-                                      float* workspace, int64_t workspace_floats, void* stream) {
+                                      const dam_bn_fin* bn_fin, float* workspace, int64_t workspace_floats, void* stream) {
     using namespace dam;
     if (bn_parts_host) *bn_parts_host = 0;
+    BnFinArgs fin{};
+    if (bn_fin && bn_partial) {
+        if (!bn_fin->gamma || !bn_fin->beta || !bn_fin->save_mean || !bn_fin->save_invstd || !bn_fin->scale || !bn_fin->shift ||
+            !bn_fin->counter) return DAM_ERR_BAD_ARG;
+        fin = BnFinArgs{bn_fin->gamma, bn_fin->beta, bn_fin->running_mean, bn_fin->running_var,
+                        (long long*)bn_fin->num_batches_tracked, bn_fin->momentum, bn_fin->eps, bn_fin->save_mean,
+                        bn_fin->save_invstd, bn_fin->scale, bn_fin->shift, bn_fin->counter};
+    }
     if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || nA <= 0 || nB <= 0)
         return DAM_ERR_BAD_ARG;
     if (n_out % 16 || (in_stride != 1 && in_stride != 2) || out_stride < 1) return DAM_ERR_UNSUPPORTED;
@@ -429,14 +438,15 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     // persistent strip variant (LDS row ring fed by loader waves, optional fused BatchNorm statistics) when the layer fits it
     if (!in_nchw) {
         int parts = 0;
-        const int rc = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, bn_partial, &parts, in_scale, in_shift, st);
+        const int rc = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, bn_partial, &parts,
+                                      fin.counter ? &fin : nullptr, in_scale, in_shift, st);
         if (rc == DAM_OK) {
             if (bn_partial && bn_parts_host) *bn_parts_host = parts;
             return DAM_OK;
         }
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
         if (bn_partial) {       // maybe only the statistics did not fit: retry without them
-            const int rc2 = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, nullptr, nullptr, in_scale, in_shift, st);
+            const int rc2 = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, nullptr, nullptr, nullptr, in_scale, in_shift, st);
             if (rc2 == DAM_OK) return DAM_OK;
             if (rc2 != DAM_ERR_UNSUPPORTED) return rc2;
         }

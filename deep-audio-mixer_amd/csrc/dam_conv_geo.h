@@ -36,8 +36,9 @@ struct StripGeo {
 };
 
 // dam_conv_strip.hip
+struct BnFinArgs;
 int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
-                   const float* res, const float* res_mask, float* stats, int* stats_parts, const float* in_scale,
-                   const float* in_shift, hipStream_t st);
+                   const float* res, const float* res_mask, float* stats, int* stats_parts, const BnFinArgs* fin,
+                   const float* in_scale, const float* in_shift, hipStream_t st);
 
 }  // namespace dam

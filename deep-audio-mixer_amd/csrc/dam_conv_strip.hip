@@ -23,6 +23,7 @@
 //     bn_stats_finalize -- removes the statistics pass over the conv output.
 #include "dam_common.h"
 #include "dam_conv_geo.h"
+#include "dam_bn_fin.h"
 
 namespace dam {
 namespace {
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
                                                          const float* __restrict__ res_mask, float* __restrict__ stats,
-                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift) {
+                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                         const BnFinArgs fin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: role tests and loader arithmetic on the scalar ALU
@@ -625,8 +627,14 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
             if (ch < g.N) {
                 const size_t part = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
                 float* o = stats + (part * g.N + ch) * 3;
-                o[0] = n; o[1] = mean; o[2] = m2;
+                store_sc1(o, n); store_sc1(o + 1, mean); store_sc1(o + 2, m2);
             }
+        }
+        if (fin.counter) {      // the last workgroup to arrive merges all records (dam_bn_fin.h): no finalize launch
+            unsigned* ticket = reinterpret_cast<unsigned*>(smem + 16 * 1024);
+            const unsigned total = gridDim.x * gridDim.z;       // statistics launches have gridDim.y == 1 (host check)
+            if (block_arrive_last(fin.counter, total, ticket))
+                bn_stats_finalize_block(stats, (int)total, g.N, fin, reinterpret_cast<double*>(smem + 32 * 1024), tid, STRIP_THREADS);
         }
     }
 }
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 template <int MB, int NB, int NCH, bool T33, bool LW = false>
 static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, const float* Wp, const float* bias, float* Y,
                         const float* res, const float* res_mask, float* stats, const float* in_scale, const float* in_shift,
-                        hipStream_t st) {
+                        const BnFinArgs& fin, hipStream_t st) {
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
@@ -649,14 +657,16 @@ static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, co
     }
     dim3 grid((unsigned)sg.strips, (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
     hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33, LW>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
-                       Y, res, res_mask, stats, in_scale, in_shift);
+                       Y, res, res_mask, stats, in_scale, in_shift, fin);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
 
 int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
-                   const float* res, const float* res_mask, float* stats, int* stats_parts, const float* in_scale,
-                   const float* in_shift, hipStream_t st) {
+                   const float* res, const float* res_mask, float* stats, int* stats_parts, const BnFinArgs* fin_in,
+                   const float* in_scale, const float* in_shift, hipStream_t st) {
+    BnFinArgs fin{};
+    if (fin_in && stats) fin = *fin_in;
     ConvGeo g = g_in;                 // the caller's copy stays as it is for the tile kernel
     if (g.nB == 3 && g.step_w < 0) {  // same taps walked left to right: column step becomes +1, weight taps are re-indexed
         g.off_w += 2 * g.step_w; g.step_w = -g.step_w;
@@ -713,9 +723,10 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     if (stats_parts) *stats_parts = sg.strips * g.B;
     if (stats && (int64_t)sg.strips * g.B > 1024) return DAM_ERR_UNSUPPORTED;
     if (lds < (size_t)8 * NB * 16 * 3 * sizeof(float)) lds = (size_t)8 * NB * 16 * 3 * sizeof(float);
+    if (fin.counter && lds < (size_t)32 * 1024 + STRIP_THREADS * 3 * sizeof(double)) lds = (size_t)32 * 1024 + STRIP_THREADS * 3 * sizeof(double);
     // 3x3 taps, stride 1, unit column step: compile-time item grid with immediate operand offsets
     const bool t33 = g.nA == 3 && g.nB == 3 && g.s == 1 && g.step_w == 1;
-#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, in_scale, in_shift, st
+#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, in_scale, in_shift, fin, st
 #define DAM_STRIP_CASE(M_, N_)                                                                                           \
     if (MB == M_ && NB == N_) {                                                                                             \
         if (t33) return g.nchunks == 1 ? launch_strip<M_, N_, 1, true>(DAM_STRIP_ARGS) : launch_strip<M_, N_, 2, true>(DAM_STRIP_ARGS); \

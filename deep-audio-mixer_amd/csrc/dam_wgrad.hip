@@ -477,7 +477,7 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
 
 template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV = 1>
 int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* dY, const float* in_scale, const float* in_shift,
-                      int relu_in, float* partial, int64_t ws_floats, float* dw, int n_real, hipStream_t st) {
+                      int relu_in, float* partial, int64_t ws_floats, float* dw, int n_real, int k_real, hipStream_t st) {
     constexpr int NBLK = TNB * TKB * 9;
     RowsGeo g;
     g.B = B; g.H = H; g.W = W; g.C = C;
@@ -521,10 +521,10 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     const int64_t per_split = (int64_t)nx * NBLK * 256;
     if (nsplit >= 64) {
         const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, C, partial, dw, nx);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, k_real, partial, dw, nx);
     } else {
         const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, C, partial, dw, nx);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, k_real, partial, dw, nx);
     }
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
 
 template <int TNB, int TKB, int KH, int KW>
 int launch_wgrad_direct(int B, int H, int W, int C, int Ho, int Wo, int N, int s, int pad, int dil, const float* X,
-                        const float* dY, float* partial, int64_t ws_floats, float* dw, int n_real, hipStream_t st) {
+                        const float* dY, float* partial, int64_t ws_floats, float* dw, int n_real, int k_real, hipStream_t st) {
     constexpr int NBLK = TNB * TKB * KH * KW;
     const int nblk = N / 16, nch = C / 16;
     if (nblk % TNB || nch % TKB) return DAM_ERR_UNSUPPORTED;
@@ -638,10 +638,10 @@ int launch_wgrad_direct(int B, int H, int W, int C, int Ho, int Wo, int N, int s
     const int64_t per_split = (int64_t)nx * NBLK * 256;
     if (nsplit >= 64) {
         const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, KH, KW, n_real, C, partial, dw, nx);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, KH, KW, n_real, k_real, partial, dw, nx);
     } else {
         const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, KH, KW, n_real, C, partial, dw, nx);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, KH, KW, n_real, k_real, partial, dw, nx);
     }
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -700,10 +700,12 @@ extern "C" int64_t dam_conv2d_wgrad_workspace_floats(int n_out, int c_in, int kh
 
 extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* in_scale,
                                     const float* in_shift, int relu_in, const float* dy, int Ho, int Wo, int n_chan,
-                                    int n_out, int kh, int kw, int stride, int pad, int dil, float* dw,
+                                    int n_out, int kh, int kw, int stride, int pad, int dil, float* dw, int c_real,
                                     float* workspace, int64_t workspace_floats, void* stream) {
     using namespace dam;
     if (!x || !dy || !dw || !workspace || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return DAM_ERR_BAD_ARG;
+    if (c_real < 0 || c_real > C) return DAM_ERR_BAD_ARG;
+    const int k_real = c_real ? c_real : C;         // dw rows kept: the real input channels (the stem's zero-padded planes drop out)
     if (n_chan % 16 || n_out > n_chan || (stride != 1 && stride != 2)) return DAM_ERR_UNSUPPORTED;
     if (in_nchw ? C > 16 : C % 16) return DAM_ERR_UNSUPPORTED;
     if (in_scale && !in_shift) return DAM_ERR_BAD_ARG;
@@ -711,7 +713,7 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !in_nchw && Ho == H && Wo == W && C == n_chan) {
         // row-streaming kernel for the shapes of the ResNet stages; anything else takes the tile kernel below
         int rc = DAM_ERR_UNSUPPORTED;
-#define DAM_WGR(...) launch_wgrad_rows<__VA_ARGS__>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, st)
+#define DAM_WGR(...) launch_wgrad_rows<__VA_ARGS__>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, k_real, st)
         // <TN, TK, steps, planes per loader wave, pieces per plane, row parts>: the shapes of the ResNet stages at 130 frames
         // (3 s clips) and at the reference's native 216 frames
         if (C == 16) { rc = DAM_WGR(1, 1, 33, 1, 9); if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGR(1, 1, 28, 1, 14, 2); }
@@ -722,7 +724,7 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
 #define DAM_WGD(TN_, TK_, KH_, KW_) \
-    launch_wgrad_direct<TN_, TK_, KH_, KW_>(B, H, W, C, Ho, Wo, n_chan, stride, pad, dil, x, dy, workspace, workspace_floats, dw, n_out, st)
+    launch_wgrad_direct<TN_, TK_, KH_, KW_>(B, H, W, C, Ho, Wo, n_chan, stride, pad, dil, x, dy, workspace, workspace_floats, dw, n_out, k_real, st)
     if (kh == 1 && kw == 1 && pad == 0 && !in_nchw && !in_scale) {
         int rc = DAM_WGD(2, 2, 1, 1);
         if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGD(2, 1, 1, 1);
@@ -757,7 +759,6 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     g.nchunks = in_nchw ? 1 : C / 16;
     g.nblk = n_chan / 16;
     g.in_nchw = in_nchw; g.relu_in = relu_in;
-    const int k_real = C;
     // tile choice: 2x2 channel blocks when both sides have them and LDS allows two workgroups per CU
     bool small = g.nchunks == 1 || g.nblk == 1;
     set_tile(256);

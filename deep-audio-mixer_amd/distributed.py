@@ -65,8 +65,8 @@ def backward_late(loss, late_params, boundary):
     """Stage 1 of the cut backward pass: gradients of `loss` w.r.t. the parameters BEHIND the bucket boundary (the deep
     end of the trunk + heads) and w.r.t. the boundary activation; nothing in front of the boundary is touched.
     Returns (list of parameter gradients, d loss / d boundary)."""
-    grads = torch.autograd.grad(loss, list(late_params) + [boundary])
-    return list(grads[:-1]), grads[-1]
+    grads = torch.autograd.grad(loss, list(late_params) + [boundary], allow_unused=True)
+    return list(grads[:-1]), grads[-1]          # (None for parameters whose gradient went straight into a bound slot)
 
 
 def backward_early(boundary, d_boundary, early_params):

@@ -54,6 +54,8 @@ class TrainStep:
                 raise ValueError('ddp_late_parameters() must be the tail of the optimizer\'s parameter list')
             optimizer.set_bucket_boundaries([late[0]])
         self._stage = None
+        # gradients go straight from the backward kernels into the flat buckets (no .grad tensors, no gather launch)
+        optimizer.bind_grad_slots()
 
     @property
     def stems(self):

@@ -13,6 +13,14 @@ import torch.nn as nn
 from . import ops
 
 
+def _slot(p):
+    """The parameter's slice of a flat gradient buffer, if an optimizer bound one (optim.Adam.bind_grad_slots): the
+    backward kernels then write the gradient THERE and the autograd Function returns None for that input -- no .grad
+    tensor, no AccumulateGrad copy, no gather launch.  Overwrite semantics (one backward per zero_grad), which is what
+    the step engine does; without a bound slot the gradient flows through autograd as usual."""
+    return None if p is None else getattr(p, '_dam_grad', None)
+
+
 class ConvSpec:
     """Static description of one convolution (not a tensor)."""
 
@@ -44,22 +52,31 @@ class ConvSpec:
         if training and not self.in_nchw:
             n16 = (self.cout + 15) // 16 * 16
             buf = ops.bn_partial_buffer(x.device, n16)
-            c, parts = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
-                                      bn_partial=buf, **aff)
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            track = bn.track_running_stats
+            # the launch's last workgroup finalizes the statistics itself (no separate finalize launch)
+            c, parts, out4 = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
+                                            bn_partial=buf, bn=(bn.weight, bn.bias, bn.running_mean if track else None,
+                                                                bn.running_var if track else None,
+                                                                bn.num_batches_tracked if track else None, mom, bn.eps),
+                                            **aff)
             if parts > 0:
-                mom = bn.momentum if bn.momentum is not None else 0.1
-                track = bn.track_running_stats
-                return (c,) + tuple(ops.bn_finalize(buf, parts, bn.weight, bn.bias, bn.running_mean if track else None,
-                                                    bn.running_var if track else None,
-                                                    bn.num_batches_tracked if track else None, mom, bn.eps))
+                return c, out4[0], out4[1], out4[2], out4[3]
         else:
             c = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
                                in_nchw=self.in_nchw, **aff)
         return (c,) + tuple(_bn_fwd_stats(c, bn, training))
 
-    def wgrad(self, x, dy, in_affine=None):
+    def fwd_bn_apply(self, x, w, bn, training, in_affine=None, res=None, res_affine=None):
+        """fwd_bn followed by out = relu(bn(c) + res [* res_scale + res_shift]): (c, save_mean, save_invstd, scale, shift, out)."""
+        rs, rh = res_affine if res_affine is not None else (None, None)
+        c, m, i, sc, sh = self.fwd_bn(x, w, bn, training, in_affine=in_affine)
+        return c, m, i, sc, sh, ops.bn_apply(c, sc, sh, relu=True, res=res, res_scale=rs, res_shift=rh)
+
+    def wgrad(self, x, dy, in_affine=None, out=None):
         aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
-        return ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil, in_nchw=self.in_nchw, **aff)
+        return ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil, in_nchw=self.in_nchw,
+                                out=out, **aff)
 
     def dgrad(self, dy, w, hw, **kw):
         return ops.conv2d_dgrad(dy, self.packed(w, transpose=True), self.cin, hw[0], hw[1], self.k, self.k,
@@ -80,8 +97,9 @@ class _Nhwc16Spec(ConvSpec):
     def packed(self, w, transpose=False):
         return self.parent.packed(w, transpose)
 
-    def wgrad(self, x, dy):
-        return ConvSpec.wgrad(self, x, dy)[:, :self.parent.cin].contiguous()
+    def wgrad(self, x, dy, in_affine=None, out=None):
+        # only the real input planes are written ([cout, cin, 3, 3] = conv1.weight's shape): the zero-padded ones drop out
+        return ops.conv2d_wgrad(x, dy, self.cout, 3, 3, 1, 1, 1, out=out, c_real=self.parent.cin)
 
 
 class WeightPacker:
@@ -143,6 +161,7 @@ class ConvBnReluFn(torch.autograd.Function):
         a = ops.bn_apply(c, scale, shift, relu=True)
         ctx.save_for_backward(x, w, c, gamma, mean, invstd, scale, shift)
         ctx.spec, ctx.training, ctx.has_bias = spec, training, bias is not None
+        ctx.slots = (_slot(w), _slot(bias), _slot(gamma), _slot(beta))
         return a
 
     @staticmethod
@@ -150,12 +169,14 @@ class ConvBnReluFn(torch.autograd.Function):
         x, w, c, gamma, mean, invstd, scale, shift = ctx.saved_tensors
         spec = ctx.spec
         # relu mask recomputed from c and the forward's affine: the saved activation is not read (nor kept by this node)
+        sw, sb, sg, sbt = ctx.slots
         dc, dgamma, dbeta = ops.bn_backward(da.contiguous(), None, c, gamma, mean, invstd, ctx.training,
-                                            mask_affine=(scale, shift))
-        dw = spec.wgrad(x, dc)
-        dbias = ops.channel_sum(dc, spec.cout) if ctx.has_bias else None
+                                            mask_affine=(scale, shift), dgamma=sg, dbeta=sbt)
+        dw = spec.wgrad(x, dc, out=None if sw is None else sw.view(w.shape))
+        dbias = ops.channel_sum(dc, spec.cout, out=sb) if ctx.has_bias else None
         dx = spec.dgrad(dc, w, _hw(x, spec.in_nchw)) if ctx.needs_input_grad[0] else None
-        return dx, dw, dbias, dgamma, dbeta, None, None, None
+        return (dx, None if sw is not None else dw, None if sb is not None else dbias, None if sg is not None else dgamma,
+                None if sbt is not None else dbeta, None, None, None)
 
 
 class DropoutFn(torch.autograd.Function):
@@ -182,15 +203,16 @@ class BasicBlockFn(torch.autograd.Function):
         c1, m1, i1, sc1, sh1 = blk.spec1.fwd_bn(x, w1.detach(), blk.bn1, training)
         # a1 = relu(bn1(c1)) is never written: conv2 (and later its weight gradient and bn1's backward) read c1 and apply the
         # fused affine themselves
-        c2, m2, i2, sc2, sh2 = blk.spec2.fwd_bn(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1))
         if wsc is not None:
             cs, ms, is_, scs, shs = blk.spec_sc.fwd_bn(x, wsc.detach(), blk.shortcut[1], training)
-            out = ops.bn_apply(c2, sc2, sh2, relu=True, res=cs, res_scale=scs, res_shift=shs)
+            c2, m2, i2, sc2, sh2, out = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1),
+                                                               res=cs, res_affine=(scs, shs))
             ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_)
         else:
-            out = ops.bn_apply(c2, sc2, sh2, relu=True, res=x)
+            c2, m2, i2, sc2, sh2, out = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1), res=x)
             ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1)
         ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None
+        ctx.slots = tuple(_slot(p) for p in (w1, g1, b1, w2, g2, b2, wsc, gsc, bsc))
         return out
 
     @staticmethod
@@ -202,19 +224,24 @@ class BasicBlockFn(torch.autograd.Function):
             x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1 = ctx.saved_tensors
         dout = dout.contiguous()
         hw = (x.shape[1], x.shape[2])
-        dc2, dg2, db2 = ops.bn_backward(dout, out, c2, g2, m2, i2, tr)
-        dw2 = blk.spec2.wgrad(c1, dc2, in_affine=(sc1, sh1))
+        s_w1, s_g1, s_b1, s_w2, s_g2, s_b2, s_ws, s_gs, s_bs = ctx.slots
+        keep = lambda grad, slot: None if slot is not None else grad      # slotted gradients are already in place
+        wview = lambda slot, w: None if slot is None else slot.view(w.shape)
+        dc2, dg2, db2 = ops.bn_backward(dout, out, c2, g2, m2, i2, tr, dgamma=s_g2, dbeta=s_b2)
+        dw2 = blk.spec2.wgrad(c1, dc2, in_affine=(sc1, sh1), out=wview(s_w2, w2))
         da1 = blk.spec2.dgrad(dc2, w2, (c1.shape[1], c1.shape[2]))
-        dc1, dg1, db1 = ops.bn_backward(da1, None, c1, g1, m1, i1, tr, mask_affine=(sc1, sh1))   # mask = (bn1(c1) > 0)
-        dw1 = blk.spec1.wgrad(x, dc1)
+        dc1, dg1, db1 = ops.bn_backward(da1, None, c1, g1, m1, i1, tr, mask_affine=(sc1, sh1),   # mask = (bn1(c1) > 0)
+                                        dgamma=s_g1, dbeta=s_b1)
+        dw1 = blk.spec1.wgrad(x, dc1, out=wview(s_w1, w1))
+        first = (keep(dw1, s_w1), keep(dg1, s_g1), keep(db1, s_b1), keep(dw2, s_w2), keep(dg2, s_g2), keep(db2, s_b2))
         if ctx.has_sc:
-            dcs, dgs, dbs = ops.bn_backward(dout, out, cs, gsc, ms, is_, tr)
-            dws = blk.spec_sc.wgrad(x, dcs)
+            dcs, dgs, dbs = ops.bn_backward(dout, out, cs, gsc, ms, is_, tr, dgamma=s_gs, dbeta=s_bs)
+            dws = blk.spec_sc.wgrad(x, dcs, out=wview(s_ws, wsc))
             dx = blk.spec1.dgrad(dc1, w1, hw)
             blk.spec_sc.dgrad(dcs, wsc, hw, accumulate_into=dx)
-            return dx, dw1, dg1, db1, dw2, dg2, db2, dws, dgs, dbs, None, None
+            return (dx,) + first + (keep(dws, s_ws), keep(dgs, s_gs), keep(dbs, s_bs), None, None)
         dx = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out)      # + dout * (out > 0): identity shortcut
-        return dx, dw1, dg1, db1, dw2, dg2, db2, None, None, None, None, None
+        return (dx,) + first + (None, None, None, None, None)
 
 
 class HeadsFn(torch.autograd.Function):
@@ -226,6 +253,7 @@ class HeadsFn(torch.autograd.Function):
         masked = ops.masksum_fwd(x, g)
         ctx.save_for_backward(trunk, x, h, cw, fw)
         ctx.set_materialize_grads(False)
+        ctx.slots = (_slot(cw), _slot(cb), _slot(fw), _slot(fb))
         return masked, g
 
     @staticmethod
@@ -238,8 +266,10 @@ class HeadsFn(torch.autograd.Function):
             dg = dg_out.contiguous() if dg is None else dg + dg_out
         if dg is None:
             return None, None, None, None, None, None
-        dtrunk, dcw, dcb, dfw, dfb = ops.heads_bwd(dg, h, trunk, cw, fw)
-        return dtrunk, None, dcw, dcb, dfw, dfb
+        dtrunk, dcw, dcb, dfw, dfb = ops.heads_bwd(dg, h, trunk, cw, fw, outs=ctx.slots)
+        sl = ctx.slots
+        return (dtrunk, None, None if sl[0] is not None else dcw, None if sl[1] is not None else dcb,
+                None if sl[2] is not None else dfw, None if sl[3] is not None else dfb)
 
 
 class HeadsMseFn(torch.autograd.Function):
@@ -252,13 +282,16 @@ class HeadsMseFn(torch.autograd.Function):
         masked, loss, dg = ops.masksum_mse(x, g, gt.contiguous())
         ctx.save_for_backward(trunk, h, cw, fw, dg)
         ctx.mark_non_differentiable(masked, g)
+        ctx.slots = (_slot(cw), _slot(cb), _slot(fw), _slot(fb))
         return loss.reshape(()), masked, g
 
     @staticmethod
     def backward(ctx, dloss, _dm, _dg):
         trunk, h, cw, fw, dg = ctx.saved_tensors
-        dtrunk, dcw, dcb, dfw, dfb = ops.heads_bwd(dg * dloss, h, trunk, cw, fw)
-        return dtrunk, None, None, dcw, dcb, dfw, dfb
+        dtrunk, dcw, dcb, dfw, dfb = ops.heads_bwd(dg * dloss, h, trunk, cw, fw, outs=ctx.slots)
+        sl = ctx.slots
+        return (dtrunk, None, None, None if sl[0] is not None else dcw, None if sl[1] is not None else dcb,
+                None if sl[2] is not None else dfw, None if sl[3] is not None else dfb)
 
 
 class BasicBlock(nn.Module):

@@ -41,9 +41,37 @@ def pack_weights_multi(desc, n_tensors, max_total):
                'dam_conv_pack_weights_multi_f32')
 
 
+_counters = {}
+# "The last workgroup finalizes" (csrc/dam_bn_fin.h) is implemented, tested and OFF: measured on the ResNet18 step it is
+# slower than the separate finalize launches it replaces (5.83 -> 6.09 ms per step; the strip convolution 66 -> 72 us per
+# launch): the last workgroup's returning atomic + its fetch of the records that the sc1 stores pushed out of L2 cost more
+# than a 1.5-2 us kernel boundary.  Kernel boundaries are the cheap synchronisation on this part.
+INKERNEL_FINALIZE = False
+
+
+def arrival_counter(device):
+    """The zero-initialised device word of the "last workgroup finalizes" hand-off (include/dam_hip.h: dam_bn_fin): one per
+    device -- every launch that uses it returns it to zero and all of them are ordered on the current stream.  None while
+    the hand-off is switched off (two-launch form)."""
+    if not INKERNEL_FINALIZE:
+        return None
+    key = (device.type, device.index)
+    if key not in _counters:
+        _counters[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return _counters[key]
+
+
+def _bn_fin_struct(bn, out4, device):
+    """bn = (gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps); out4: [4, C] result rows."""
+    gamma, beta, rm, rv, nbt, mom, eps = bn
+    return _lib.BnFin(_lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(nbt), float(mom), float(eps),
+                      _lib.ptr(out4[0]), _lib.ptr(out4[1]), _lib.ptr(out4[2]), _lib.ptr(out4[3]),
+                      _lib.ptr(arrival_counter(device)))
+
+
 def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shift, relu_in, y, OHt, OWt, Ho, Wo,
              out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
-             res=None, res_mask=None, bn_partial=None):
+             res=None, res_mask=None, bn_partial=None, bn_fin=None):
     parts = ctypes.c_int(0)
     # split-K scratch: the host code only splits when no tile shape gives 400 workgroups, i.e. for outputs below
     # 400 * 64 px * 64 ch = 1.64 M floats, and then at most 8 ways (dam_conv.hip) -- never more than 13.1 M floats
@@ -53,13 +81,13 @@ def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shi
         _lib.ptr(in_scale), _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(y), OHt, OWt, Ho, Wo, out_stride,
         oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb, _lib.ptr(res),
         _lib.ptr(res_mask), _lib.ptr(bn_partial), ctypes.byref(parts) if bn_partial is not None else None,
-        _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctypes.byref(bn_fin) if bn_fin is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(st, 'dam_conv2d_tapgrid_f32')
     return parts.value
 
 
 def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale=None, in_shift=None,
-               relu_in=False, in_nchw=False, bn_partial=None):
+               relu_in=False, in_nchw=False, bn_partial=None, bn=None):
     """x: NHWC [B,H,W,C] (C % 16 == 0), or NCHW [B,C,H,W] with C <= 16 if in_nchw.  Returns NHWC
     [B,Ho,Wo,n_out] with n_out rounded up to a multiple of 16 (extra channels are zero)."""
     _lib.require_cuda(x, wp)
@@ -75,8 +103,17 @@ def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale
     if Ho <= 0 or Wo <= 0:
         raise ValueError('convolution output would be empty')
     y = torch.empty((B, Ho, Wo, n16), dtype=torch.float32, device=x.device)
+    out4 = fin = None
+    if bn is not None and bn_partial is not None and INKERNEL_FINALIZE:
+        # in-kernel finalize: the launch's last workgroup merges the partial records into (mean, invstd, scale, shift)
+        out4 = torch.empty((4, n16), dtype=torch.float32, device=x.device)
+        fin = _bn_fin_struct(bn, out4, x.device)
     parts = _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n16, bias, in_scale, in_shift, relu_in, y, Ho, Wo, Ho, Wo,
-                     1, 0, 0, stride, kh, kw, -pad, dil, -pad, dil, 0, kw, 1, bn_partial=bn_partial)
+                     1, 0, 0, stride, kh, kw, -pad, dil, -pad, dil, 0, kw, 1, bn_partial=bn_partial, bn_fin=fin)
+    if bn is not None and bn_partial is not None:
+        if parts > 0 and fin is None:      # two-launch form: merge the records with the finalize kernel
+            out4 = bn_finalize(bn_partial, parts, *bn)
+        return y, parts, out4    # parts == 0: no statistics from this launch (out4 is then unset)
     if bn_partial is not None:
         return y, parts          # parts == 0: the launch could not produce the statistics
     return y
@@ -152,8 +189,9 @@ def _workspace(device, floats):
 
 
 def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, relu_in=False,
-                 in_nchw=False, out=None):
-    """dW in torch layout [n_out, C, kh, kw] from x (NHWC, or NCHW first layer) and dy NHWC [B,Ho,Wo,n16]."""
+                 in_nchw=False, out=None, c_real=None):
+    """dW in torch layout [n_out, c_real or C, kh, kw] from x (NHWC, or NCHW first layer) and dy NHWC [B,Ho,Wo,n16].
+    out: where to write it (e.g. the parameter's slice of a flat gradient buffer)."""
     _lib.require_cuda(x, dy)
     _f32c(x, 'x'), _f32c(dy, 'dy')
     if in_nchw:
@@ -163,11 +201,14 @@ def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in
     _, Ho, Wo, n_chan = dy.shape
     L = _lib.lib()
     ws = _workspace(x.device, L.dam_conv2d_wgrad_workspace_floats(n_out, C, kh, kw))
+    cr = C if c_real is None else int(c_real)
     if out is None:
-        out = torch.empty((n_out, C, kh, kw), dtype=torch.float32, device=x.device)
+        out = torch.empty((n_out, cr, kh, kw), dtype=torch.float32, device=x.device)
+    elif out.numel() != n_out * cr * kh * kw or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError('bad out tensor for the weight gradient')
     _lib.check(L.dam_conv2d_wgrad_f32(_lib.ptr(x), B, H, W, C, 1 if in_nchw else 0, _lib.ptr(in_scale),
                                       _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(dy), Ho, Wo, n_chan, n_out,
-                                      kh, kw, stride, pad, dil, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                      kh, kw, stride, pad, dil, _lib.ptr(out), cr, _lib.ptr(ws), ws.numel(),
                                       _lib.stream()), 'dam_conv2d_wgrad_f32')
     return out
 
@@ -200,7 +241,7 @@ def bn_stats(x, gamma, beta, running_mean, running_var, num_batches_tracked, mom
     _lib.check(_lib.lib().dam_bn_stats_f32(_lib.ptr(x), P, C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
                                            _lib.ptr(running_var), _lib.ptr(num_batches_tracked), float(momentum), float(eps),
                                            _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
-                                           _lib.ptr(ws), _lib.stream()), 'dam_bn_stats_f32')
+                                           _lib.ptr(ws), _lib.ptr(arrival_counter(x.device)), _lib.stream()), 'dam_bn_stats_f32')
     return out[0], out[1], out[2], out[3]
 
 
@@ -241,7 +282,7 @@ def bn_apply(x, scale, shift, relu=True, res=None, res_scale=None, res_shift=Non
     return y
 
 
-def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mask_affine=None):
+def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mask_affine=None, dgamma=None, dbeta=None):
     """Returns (dx, dgamma, dbeta) for y = [relu](bn(x) + ...).  The ReLU mask comes from y_mask (the saved output), or --
     for a plain relu(bn(x)) -- from mask_affine=(scale, shift), the forward's fused affine (the saved output is not read),
     or there is none (both None)."""
@@ -250,22 +291,26 @@ def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mas
     dx = torch.empty_like(x)
     # two separate allocations: autograd takes ownership of a whole tensor it is handed as a .grad, but clones a view
     # (30 extra device copies per ResNet18 step when these were rows of one [2, C] tensor)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = _bn_ws(x.device, C)
     _lib.check(_lib.lib().dam_bn_backward_f32(_lib.ptr(dy), _lib.ptr(y_mask), _lib.ptr(x), x.numel() // C, C, _lib.ptr(gamma),
                                               _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
                                               _lib.ptr(mask_affine[0]) if mask_affine else None,
                                               _lib.ptr(mask_affine[1]) if mask_affine else None, _lib.ptr(dx),
-                                              _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.stream()),
+                                              _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
+                                              _lib.ptr(arrival_counter(x.device)), _lib.stream()),
                'dam_bn_backward_f32')
     return dx, dgamma, dbeta
 
 
-def channel_sum(x, n_real):
+def channel_sum(x, n_real, out=None):
     _lib.require_cuda(x)
     C = x.shape[-1]
-    out = torch.empty(n_real, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(n_real, dtype=torch.float32, device=x.device)
     ws = _bn_ws(x.device, C)
     _lib.check(_lib.lib().dam_channel_sum_f32(_lib.ptr(x), x.numel() // C, C, n_real, _lib.ptr(out), _lib.ptr(ws),
                                               _lib.stream()), 'dam_channel_sum_f32')
@@ -288,13 +333,17 @@ def heads_fwd(trunk, conv_w, conv_b, fc_w, fc_b):
     return h, g
 
 
-def heads_bwd(dgains, h, trunk, conv_w, fc_w):
+def heads_bwd(dgains, h, trunk, conv_w, fc_w, outs=None):
+    """outs: optional (dconv_w [S,C], dconv_b [S], dfc_w [S,P], dfc_b [S]) destinations (gradient slots)."""
     B, S, P = h.shape
     C = trunk.shape[-1]
     dev = trunk.device
     dtrunk = torch.empty_like(trunk)
-    dcw, dcb = torch.empty((S, C), dtype=torch.float32, device=dev), torch.empty(S, dtype=torch.float32, device=dev)
-    dfw, dfb = torch.empty((S, P), dtype=torch.float32, device=dev), torch.empty(S, dtype=torch.float32, device=dev)
+    o = outs or (None, None, None, None)
+    dcw = o[0] if o[0] is not None else torch.empty((S, C), dtype=torch.float32, device=dev)
+    dcb = o[1] if o[1] is not None else torch.empty(S, dtype=torch.float32, device=dev)
+    dfw = o[2] if o[2] is not None else torch.empty((S, P), dtype=torch.float32, device=dev)
+    dfb = o[3] if o[3] is not None else torch.empty(S, dtype=torch.float32, device=dev)
     L = _lib.lib()
     ws = _workspace(dev, L.dam_heads_bwd_workspace_floats(B, P, C, S))
     _lib.check(L.dam_heads_bwd_f32(_lib.ptr(dgains), _lib.ptr(h), _lib.ptr(trunk), B, P, C, S, _lib.ptr(conv_w), _lib.ptr(fc_w),

@@ -75,6 +75,7 @@ class Adam(torch.optim.Optimizer):
         self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._hyper_host = None
         self._host_grad = None
+        self.slots_bound = False
         self.process_group, self.world_size = process_group, world_size
         self._bucket_params = [(0, len(self._params))]           # parameter index ranges, in flat-buffer order
         self.sync_hyper()
@@ -117,6 +118,20 @@ class Adam(torch.optim.Optimizer):
         lo, hi = self._bucket_params[b]
         return self._grad[self._offsets[lo]:self._offsets[hi]]
 
+    def bind_grad_slots(self):
+        """Hands every parameter its slice of the flat gradient buffer (``p._dam_grad``): the backward kernels of
+        layers.py then write gradients straight into the bucket -- no .grad tensors, no copies, no gather launch.
+        Gradients OVERWRITE (one backward per step); ``p.grad`` stays None.  Undo with ``unbind_grad_slots()``."""
+        for i, p in enumerate(self._params):
+            p._dam_grad = self._grad[self._offsets[i]:self._offsets[i + 1]].view(p.shape)
+        self.slots_bound = True
+
+    def unbind_grad_slots(self):
+        for p in self._params:
+            if hasattr(p, '_dam_grad'):
+                del p._dam_grad
+        self.slots_bound = False
+
     def gather_grads(self, bucket=None, grads=None):
         """One launch: every p.grad (or the given list of gradient tensors, bucket order) -> its slice of the flat
         buffer (missing grads count as zero).  bucket=None: all parameters."""
@@ -126,6 +141,8 @@ class Adam(torch.optim.Optimizer):
             p = self._params[i]
             g = p.grad if grads is None else grads[i - lo]
             v = self._grad[self._offsets[i]:self._offsets[i + 1]]
+            if g is None and self.slots_bound and hasattr(p, '_dam_grad'):
+                continue                                  # the backward kernels wrote this slice themselves
             if g is None:
                 v.zero_()
             else:

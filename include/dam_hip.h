@@ -36,6 +36,7 @@ typedef enum dam_status {
 } dam_status;
 
 typedef enum dam_pcm_dtype { DAM_PCM_F32 = 0, DAM_PCM_F64 = 1 } dam_pcm_dtype;
+struct dam_bn_fin;      /* defined in the BatchNorm section */
 
 /* Library / build identification ("gfx950"). */
 const char* dam_arch(void);
@@ -125,7 +126,8 @@ int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int6
  * bn_partial (optional, >= dam_bn_workspace_floats(n_out) floats): if the launch can also produce the BatchNorm
  * partial statistics of y (records (n, mean, M2) per workgroup and channel) it does so and stores the record count
  * in *bn_parts_host (a HOST int); 0 there means "not produced" and the caller runs dam_bn_stats_f32 instead.
- * Feed the records to dam_bn_finalize_f32.
+ * Feed the records to dam_bn_finalize_f32 -- or pass bn_fin (see dam_bn_fin below): the launch's last workgroup then
+ * merges them itself and writes save_mean / save_invstd / scale / shift (+ running statistics), no finalize launch.
  * workspace (optional): scratch for split-K over the input channels (used for small-spatial, wide layers; at most
  * 8 * B*OHt*OWt*n_out floats are used, fewer if less is given); partial slabs are summed in a fixed order. */
 int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
@@ -134,20 +136,22 @@ int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nc
                            int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                            int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                            const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
-                           float* workspace, int64_t workspace_floats, void* stream);
+                           const struct dam_bn_fin* bn_fin, float* workspace, int64_t workspace_floats, void* stream);
 
 /* Weight gradient of the same convolutions (autograd of nn.Conv2d reached from loss.backward(),
  * model_trainer.py:36):  dw[n][k][kh][kw] = sum_{b,oh,ow} dy[b,oh,ow,n] * f(x[b, oh*stride+kh*dil-pad, ow*stride+kw*dil-pad, k])
  *   x  : as for dam_conv2d_tapgrid_f32 (NHWC, or in_nchw planes for the first layer), same fused f()
  *   dy : NHWC [B][Ho][Wo][n_chan], n_chan % 16 == 0; only the first n_out channels are real
- *   dw : torch layout [n_out][C][kh][kw] (C = real input channels), fully overwritten
+ *   dw : torch layout [n_out][c_real][kh][kw], fully overwritten; c_real <= C is the number of REAL input channels
+ *        (0 = C): the zero-padded planes of the re-laid stem input (dam_nchw_to_nhwc16_f32) drop out, so the result can
+ *        be written straight into the parameter's slice of a flat gradient buffer
  *   workspace : at least dam_conv2d_wgrad_workspace_floats(...) floats; holds the split-K slabs that a
  *               second kernel sums in a fixed order (bitwise reproducible, no float atomics)
  * Supported kernels: 3x3, 1x1, and kw in {5,7,9} with any kh; stride 1 or 2. */
 int64_t dam_conv2d_wgrad_workspace_floats(int n_out, int c_in, int kh, int kw);
 int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* in_scale,
                          const float* in_shift, int relu_in, const float* dy, int Ho, int Wo, int n_chan,
-                         int n_out, int kh, int kw, int stride, int pad, int dil, float* dw,
+                         int n_out, int kh, int kw, int stride, int pad, int dil, float* dw, int c_real,
                          float* workspace, int64_t workspace_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------
@@ -157,6 +161,19 @@ int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, int in_nchw
  * --------------------------------------------------------------------------------- */
 int64_t dam_bn_workspace_floats(int C);
 
+/* "The last workgroup finalizes": the kernels that produce per-workgroup partial records (BatchNorm statistics from a
+ * convolution epilogue or from dam_bn_stats_f32, the two sums of dam_bn_backward_f32) can merge them themselves in the
+ * workgroup that happens to finish last, instead of a separate 5-7 us finalize launch.  That needs one device word:
+ * `counter` -- ZERO-INITIALISED by the caller, returned to zero by every launch, shared only by launches that are
+ * ordered on one stream.  counter == NULL keeps the two-launch form. */
+typedef struct dam_bn_fin {       /* host struct of device pointers: what dam_bn_finalize_f32 takes, for an in-kernel finalize */
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;    /* may be NULL */
+    float momentum, eps;
+    float* save_mean; float* save_invstd; float* scale; float* shift;
+    uint32_t* counter;
+} dam_bn_fin;
+
 /* Training-mode statistics of x: save_mean, save_invstd = 1/sqrt(biased var + eps), the fused affine
  * scale = gamma*invstd, shift = beta - mean*scale, and torch's running-stat update
  * (running = (1-momentum)*running + momentum*stat, unbiased variance; ++*num_batches_tracked).
@@ -164,7 +181,7 @@ int64_t dam_bn_workspace_floats(int C);
 int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
                      float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
-                     float* shift, float* workspace, void* stream);
+                     float* shift, float* workspace, uint32_t* counter, void* stream);
 
 /* Second half of dam_bn_stats_f32 on its own: merges `parts` partial records [parts][C][3] = (n, mean, M2) (as written
  * by dam_conv2d_tapgrid_f32's bn_partial output) and produces the same outputs / running-stat update. */
@@ -191,7 +208,7 @@ int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const float* scale
 int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
                         const float* gamma, const float* save_mean, const float* save_invstd, int training,
                         const float* mask_scale, const float* mask_shift, float* dx, float* dgamma, float* dbeta,
-                        float* workspace, void* stream);
+                        float* workspace, uint32_t* counter, void* stream);
 
 /* out[c] = sum_p x[p][c] for c < n_real (gradient of a convolution bias, models/model_scalar_1s.py:167). */
 int dam_channel_sum_f32(const float* x, int64_t n_pixels, int C, int n_real, float* out, float* workspace,

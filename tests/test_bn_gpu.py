@@ -52,3 +52,4 @@ def test_bn_relu_forward_backward_mask_modes(ops, B, H, W, C):
     y2.backward(dy.double())
     dx0, _, _ = ops.bn_backward(dy.cuda(), None, xd, gamma.cuda(), sm, si, True)
     close(dx0, xr2.grad, 1e-4)
+

@@ -206,3 +206,44 @@ def test_fused_bn_statistics_epilogue(ops):
     assert int(nbt.item()) == 1
     m2, i2, _, _ = ops.bn_stats(y, gamma, beta, None, None, None, 0.1, 1e-5)
     assert torch.allclose(mean, m2, rtol=1e-5, atol=1e-4) and torch.allclose(invstd, i2, rtol=1e-4)
+
+
+def test_in_kernel_finalize_matches_finalize_launch(ops):
+    """"The last workgroup finalizes" (dam_bn_fin.h): statistics + running-stat update produced inside the convolution
+    launch equal the separate dam_bn_finalize_f32 launch, over repeated launches (the arrival counter returns to zero) and
+    for the two-kernel statistics / backward paths that use the same hand-off."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(4, 16, 311, 130, generator=g) * 4 + 30
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12
+    xd, wp = nhwc(x).cuda(), ops.pack_weights(w.cuda())
+    gamma, beta = torch.rand(16, device='cuda') + 0.5, torch.randn(16, device='cuda')
+    buf = ops.bn_partial_buffer(torch.device('cuda'), 16)
+    y, parts = ops.conv2d_fwd(xd, wp, 16, 3, 3, 1, 1, 1, bn_partial=buf)
+    rm0, rv0, nb0 = torch.zeros(16, device='cuda'), torch.ones(16, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+    want = ops.bn_finalize(buf, parts, gamma, beta, rm0, rv0, nb0, 0.1, 1e-5)
+    rm, rv, nbt = torch.zeros(16, device='cuda'), torch.ones(16, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+    ops.INKERNEL_FINALIZE = True          # off by default (slower than the finalize launch, ops.py); still has to be right
+    try:
+        _check_in_kernel_finalize(ops, g, xd, wp, gamma, beta, buf, y, parts, want, rm, rv, nbt, rm0)
+    finally:
+        ops.INKERNEL_FINALIZE = False
+
+
+def _check_in_kernel_finalize(ops, g, xd, wp, gamma, beta, buf, y, parts, want, rm, rv, nbt, rm0):
+    for rep in range(3):
+        y2, parts2, out4 = ops.conv2d_fwd(xd, wp, 16, 3, 3, 1, 1, 1, bn_partial=buf, bn=(gamma, beta, rm, rv, nbt, 0.1, 1e-5))
+        assert parts2 == parts and torch.equal(y2, y)
+        for got, w_ in zip(out4, want):
+            assert torch.allclose(got, w_, rtol=1e-6, atol=1e-6)
+        assert int(ops.arrival_counter(torch.device('cuda'))[0].item()) == 0
+    assert int(nbt.item()) == 3
+    assert torch.allclose(rm, rm0 * (1 + 0.9 + 0.81), rtol=1e-5)              # three momentum updates towards the same mean
+    # the stand-alone statistics / backward kernels finalize in their last workgroup too: against float64
+    for C, P in ((16, 70001), (96, 5000), (256, 330), (1024, 50)):
+        t = torch.randn(P, C, generator=g) * 2 + 3
+        gm, bt = torch.rand(C) + 0.5, torch.randn(C)
+        mean, invstd, scale, shift = ops.bn_stats(t.cuda().view(1, P, 1, C), gm.cuda(), bt.cuda(), None, None, None, 0.1, 1e-5)
+        td = t.double()
+        close(mean, td.mean(0), 1e-6)
+        close(invstd, 1 / (td.var(0, unbiased=False) + 1e-5).sqrt(), 1e-5)
+        close(shift, bt.double() - td.mean(0) * gm.double() / (td.var(0, unbiased=False) + 1e-5).sqrt(), 2e-5)
