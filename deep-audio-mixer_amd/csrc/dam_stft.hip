@@ -278,6 +278,81 @@ __global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Any power-of-two window (data/dataset.py:132-133 exposes window_size / hop_length as parameters; every caller in the
+// reference leaves them at 2048 / 1024, which is what the kernel above is built for).  One workgroup = one frame:
+// M = n_fft/2 complex points z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1] in LDS, log2(M) autosort (Stockham) radix-2 passes,
+// the same real-FFT split and dB epilogue, bins written straight out.  Not tuned: correctness path.
+template <typename PCM, int CH, bool PLANAR>
+__global__ __launch_bounds__(256) void stft_generic_kernel(
+    const PCM* __restrict__ pcm, int64_t n_samples, int64_t outer_stride, int n_inner, int64_t inner_stride, int64_t cs,
+    const float* __restrict__ window, const float2* __restrict__ tw /* W_nfft^k */, const float* __restrict__ gain, int n_fft,
+    int hop, int n_frames, float amin, float floor_db, int normalize, float* __restrict__ out, float* __restrict__ out_tail,
+    int n_tail) {
+    extern __shared__ __attribute__((aligned(16))) float2 buf[];      // [2][M]
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int M = n_fft >> 1, nbins = M + 1;
+    const int64_t track = blockIdx.y;
+    const int t = blockIdx.x;
+    const PCM* trk = pcm + (track / n_inner) * outer_stride + (track % n_inner) * inner_stride;
+    const float g = gain ? gain[track] : 1.0f;
+    const int64_t p0 = (int64_t)t * hop - M;
+    for (int n = tid; n < M; n += 256) {
+        const int64_t a = reflect(p0 + 2 * n, n_samples), b = reflect(p0 + 2 * n + 1, n_samples);
+        buf[n] = make_float2(mono_at<PCM, CH, PLANAR>(trk, cs, a) * (window[2 * n] * g),
+                             mono_at<PCM, CH, PLANAR>(trk, cs, b) * (window[2 * n + 1] * g));
+    }
+    __syncthreads();
+    float2* x = buf;
+    float2* y = buf + M;
+    int sshift = 0;                                   // s = 1 << sshift
+    for (int n = M; n > 1; n >>= 1, ++sshift) {
+        const int m = n >> 1, s = 1 << sshift;
+        for (int e = tid; e < (M >> 1); e += 256) {
+            const int p = e >> sshift, q = e & (s - 1);
+            const float2 a = x[q + s * p], b = x[q + s * (p + m)];
+            const float2 w = tw[(2 * p * s) & (n_fft - 1)];                 // W_n^p = W_nfft^(2 p s)
+            y[q + s * (2 * p)] = cadd(a, b);
+            y[q + s * (2 * p + 1)] = cmul(csub(a, b), w);
+        }
+        __syncthreads();
+        float2* tmp = x; x = y; y = tmp;
+    }
+    // real-FFT split + dB; the result of bin f goes to y[] as a float (reusing the other buffer)
+    float* db = reinterpret_cast<float*>(y);
+    float mx = 0.f;
+    for (int k = tid; k <= M; k += 256) {
+        const float2 zk = x[k & (M - 1)], zn = x[(M - k) & (M - 1)];
+        const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const float2 wk = k < n_fft ? tw[k & (n_fft - 1)] : make_float2(1.f, 0.f);
+        const float2 xa = cadd(e, cmul(wk, o));
+        const float v = to_db(sqrtf(xa.x * xa.x + xa.y * xa.y), amin, floor_db);
+        db[k] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    float scale = 1.0f;
+    if (normalize) {
+        red[tid] = mx;
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if (tid < st) red[tid] = fmaxf(red[tid], red[tid + st]);
+            __syncthreads();
+        }
+        scale = red[0];
+    }
+    const int64_t og = track / n_inner;
+    const int ig = (int)(track % n_inner), n_main = n_inner - n_tail;
+    float* o = (ig < n_main ? out + ((og * n_main + ig) * (int64_t)nbins) * n_frames
+                            : out_tail + ((og * n_tail + (ig - n_main)) * (int64_t)nbins) * n_frames) + t;
+    for (int k = tid; k <= M; k += 256) {
+        float v = db[k];
+        if (normalize && scale >= 1.17549435e-38f) v = v / scale;
+        o[(int64_t)k * n_frames] = v;
+    }
+}
+
 }  // namespace
 }  // namespace dam
 
@@ -302,7 +377,9 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     if (!pcm || !window || !twiddles || !out || n_outer <= 0 || n_inner <= 0 || hop <= 0) return DAM_ERR_BAD_ARG;
     if (n_tail < 0 || n_tail >= n_inner || (n_tail > 0 && !out_tail)) return DAM_ERR_BAD_ARG;
     if (n_samples <= n_fft / 2) return DAM_ERR_BAD_ARG;   // reflect padding needs N > n_fft/2 (torch.stft raises too)
-    if (n_fft != NFFT || (hop & 1) || (channels != 1 && channels != 2)) return DAM_ERR_UNSUPPORTED;
+    if (channels != 1 && channels != 2) return DAM_ERR_UNSUPPORTED;
+    const bool fast = n_fft == NFFT && !(hop & 1);         // the tuned 2048-point kernel; else any power of two 64..4096
+    if (!fast && (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))) return DAM_ERR_UNSUPPORTED;
     if (pcm_dtype != DAM_PCM_F32 && pcm_dtype != DAM_PCM_F64) return DAM_ERR_UNSUPPORTED;
     const int64_t n_tracks = n_outer * n_inner;
     if (n_tracks > 65535 || n_inner > 0x7fffffff) return DAM_ERR_UNSUPPORTED;
@@ -322,6 +399,27 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     hipStream_t s = (hipStream_t)stream;
     const float2* tw = reinterpret_cast<const float2*>(twiddles);
     const float floor_db = (float)(20.0 * log10((double)amin));
+    if (!fast) {
+        if (n_frames > 0x7fffffff / 2) return DAM_ERR_UNSUPPORTED;
+        const dim3 ggrid((unsigned)n_frames, (unsigned)n_tracks);
+        const size_t lds = (size_t)n_fft * sizeof(float2);        // two buffers of n_fft/2 complex points
+#define DAM_STFT_GENERIC(T, C, P)                                                                                     \
+    hipLaunchKernelGGL((stft_generic_kernel<T, C, P>), ggrid, dim3(256), lds, s, (const T*)pcm, n_samples, outer_stride, \
+                       (int)n_inner, inner_stride, channel_stride, window, tw, gain, n_fft, hop, n_frames, amin, floor_db, \
+                       normalize, out, out_tail, n_tail)
+        if (pcm_dtype == DAM_PCM_F32) {
+            if (channels == 1) DAM_STFT_GENERIC(float, 1, false);
+            else if (planar) DAM_STFT_GENERIC(float, 2, true);
+            else DAM_STFT_GENERIC(float, 2, false);
+        } else {
+            if (channels == 1) DAM_STFT_GENERIC(double, 1, false);
+            else if (planar) DAM_STFT_GENERIC(double, 2, true);
+            else DAM_STFT_GENERIC(double, 2, false);
+        }
+#undef DAM_STFT_GENERIC
+        DAM_CHECK_LAUNCH();
+        return DAM_OK;
+    }
 #define DAM_STFT_LAUNCH(T, C, P)                                                                              \
     hipLaunchKernelGGL((stft_logmag_kernel<T, C, P>), grid, block, 0, s, (const T*)pcm, n_samples, outer_stride, \
                        (int)n_inner, inner_stride, channel_stride, window, tw, gain, hop, n_frames, amin, floor_db, \

@@ -36,14 +36,15 @@ def test_golden_cases(feats, golden_dir):
             continue
         a = make_audio(c['kind'], c['n'], c['seed'])
         for tdt in (torch.float64, torch.float32):
-            out = feats.stft_logmag(torch.from_numpy(a).to(tdt).cuda()[None], hop=c['hop'])[0].cpu().numpy()
+            n_fft = c.get('n_fft', 2048)        # 2048 / even hop: the tuned kernel; anything else: the generic power-of-two one
+            out = feats.stft_logmag(torch.from_numpy(a).to(tdt).cuda()[None], n_fft=n_fft, hop=c['hop'])[0].cpu().numpy()
             assert list(out.shape) == c['shape']
             if c['kind'] == 'silence':
                 assert np.all(out == -100.0)
                 continue
             if c['key'] + '_full' in data:
                 _check(out, data[c['key'] + '_full'])
-            want = features_ref.compute_features(a, 2048, c['hop'])
+            want = features_ref.compute_features(a, n_fft, c['hop'])
             _check(out, want)
             samp = data[c['key'] + '_sample']        # straight dB comparison away from spectral nulls
             strong = samp > samp.max() - 60.0
@@ -73,7 +74,9 @@ def test_normalize_and_edges(feats):
     with pytest.raises(RuntimeError, match='DAM_ERR_BAD_ARG'):
         feats.stft_logmag(torch.zeros(1, 1024, device='cuda'), hop=1024)      # N <= n_fft/2: torch.stft raises too
     with pytest.raises(RuntimeError, match='DAM_ERR_UNSUPPORTED'):
-        feats.stft_logmag(torch.zeros(1, 4096, device='cuda'), n_fft=1024, hop=256)
+        feats.stft_logmag(torch.zeros(1, 40960, device='cuda'), n_fft=1000, hop=256)      # not a power of two
+    with pytest.raises(RuntimeError, match='DAM_ERR_UNSUPPORTED'):
+        feats.stft_logmag(torch.zeros(1, 40960, device='cuda'), n_fft=8192, hop=256)
     with pytest.raises(RuntimeError, match='GPU only'):
         feats.stft_logmag(torch.zeros(1, 4096), hop=1024)
 
@@ -91,3 +94,25 @@ def test_full_size_properties(feats):
     assert torch.equal(single[0], out[17])
     want = features_ref.compute_features(pcm[40].double().mean(1).cpu().numpy(), 2048, 1024)
     _check(out[40].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('n_fft,hop,channels,dtype', [(1024, 256, 2, np.float32), (4096, 1024, 1, np.float64), (512, 100, 2, np.float64),
+                                                      (2048, 441, 2, np.float32), (64, 16, 1, np.float32)])
+def test_other_window_sizes(feats, n_fft, hop, channels, dtype):
+    """compute_features(audio, window_size, hop_length) for windows other than 2048 and odd hops (generic kernel): stereo mean,
+    gain, normalisation and the (stems, mix) output split behave as in the tuned kernel."""
+    rng = np.random.default_rng(n_fft + hop)
+    n = 20000 + 13
+    pcm = (0.1 * rng.standard_normal((4, n, channels))).astype(dtype)
+    gains = rng.uniform(0.6, 1.4, 4)
+    out = feats.stft_logmag(torch.from_numpy(pcm).cuda(), n_fft=n_fft, hop=hop, gain=torch.from_numpy(gains).cuda()).cpu().numpy()
+    assert out.shape == (4, n_fft // 2 + 1, 1 + n // hop)
+    for k in (0, 3):
+        mono = features_ref.stereo_to_mono(pcm[k].astype(np.float64))
+        _check(out[k], features_ref.compute_features(features_ref.augment_audio(mono, gains[k]), n_fft, hop))
+    nrm = feats.stft_logmag(torch.from_numpy(pcm[:1]).cuda(), n_fft=n_fft, hop=hop, normalize=True)[0].cpu().numpy()
+    want = features_ref.compute_features(features_ref.stereo_to_mono(pcm[0].astype(np.float64)), n_fft, hop, normalize=True)
+    np.testing.assert_allclose(nrm, want, rtol=0, atol=5e-4)
+    x, gt = feats.stft_logmag_clips(torch.from_numpy(pcm.reshape(2, 2, n, channels)).cuda(), n_fft=n_fft, hop=hop)
+    plain = feats.stft_logmag(torch.from_numpy(pcm).cuda(), n_fft=n_fft, hop=hop)
+    assert torch.equal(x[:, 0], plain[[0, 2]]) and torch.equal(gt, plain[[1, 3]])

@@ -30,6 +30,17 @@ elif which == 'layer3':
     x = torch.randn((B, 257, 33, 64), device=dev)
     wp = ops.pack_weights(torch.randn((64, 64, 3, 3), device=dev) * 0.05)
     fn = lambda: ops.conv2d_fwd(x, wp, 64, 3, 3, 1, 1, 1)
+elif which in ('layer4', 'layer5', 'layer6'):
+    hw, c = {'layer4': ((129, 17), 96), 'layer5': ((65, 9), 128), 'layer6': ((33, 5), 256)}[which]
+    x = torch.randn((B, hw[0], hw[1], c), device=dev)
+    wp = ops.pack_weights(torch.randn((c, c, 3, 3), device=dev) * 0.05)
+    fn = lambda: ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1)
+elif which in ('layer3_wgrad', 'layer4_wgrad', 'layer5_wgrad', 'layer6_wgrad'):
+    hw, c = {'layer3_wgrad': ((257, 33), 64), 'layer4_wgrad': ((129, 17), 96), 'layer5_wgrad': ((65, 9), 128),
+             'layer6_wgrad': ((33, 5), 256)}[which]
+    x = torch.randn((B, hw[0], hw[1], c), device=dev)
+    dy = torch.randn((B, hw[0], hw[1], c), device=dev)
+    fn = lambda: ops.conv2d_wgrad(x, dy, c, 3, 3, 1, 1, 1)
 elif which == 'conv1':
     x = torch.randn((B, 8, H, W), device=dev)
     wp = ops.pack_weights(torch.randn((16, 8, 3, 3), device=dev) * 0.05)
