@@ -33,6 +33,15 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// The same ordering without the fences' side effects: a workgroup-scope release also waits for the wave's outstanding
+// GLOBAL loads and stores (s_waitcnt vmcnt(0)), which a purely intra-wave LDS exchange does not need.  The LDS executes one
+// wave's instructions in order, so later ds_reads see earlier ds_writes; what is left is keeping the compiler from moving
+// LDS accesses across this point and draining the wave's own LDS queue.
+__device__ __forceinline__ void wave_lds_order() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lanes sharing lane>>4
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);

@@ -3,22 +3,11 @@
 // Replaces data/dataset.py:132-162 (compute_features), :181-183 (_stereo_to_mono),
 // :164-168 (_augment_audio) of the reference, for every track of a batch in one launch.
 //
-// Mapping (wave64, no port of a warp-32 design):
-//   * one workgroup = 4 waves = one tile of TF=16 consecutive frames of one track;
-//   * one WAVE owns one frame at a time: the 2048 real samples are packed as 1024
-//     complex points z[n] = x[2n] + i x[2n+1]; lane j keeps the 16 points z[j + 64*n1]
-//     in registers, read with 16 coalesced 16-byte loads straight from the interleaved
-//     stereo PCM (one load = L0 R0 L1 R1 = one complex point after the channel mean).
-//     The 50 % frame overlap is served by L2 (hop = n_fft/2 -> every sample is wanted by
-//     two frames of the same workgroup), so HBM sees each sample once;
-//   * 1024-point complex FFT = radix-16 (registers) x radix-16 (registers) x radix-4
-//     with three exchanges through a private 8.5 KB LDS scratch per wave (padded rows,
-//     conflict-free ds_read_b64); window, all twiddles of the three stages and of the
-//     real-FFT split are lane-invariant, so they live in registers for the whole kernel;
-//   * split post-pass produces bins k and 1024-k from Z[k], Z[1024-k], then
-//     20*log10(max(|X|, amin)) goes into an XOR-swizzled [1025][16] LDS tile;
-//   * the tile is written out with T contiguous (64-byte row segments) in the
-//     reference layout out[track][bin][frame]; optional per-frame max-abs normalise.
+// Mapping (wave64, no port of a warp-32 design): one WAVE owns one frame -- the 2048 real samples packed as 1024 complex
+// points, 16 per lane, read with coalesced 16-byte loads straight from the interleaved stereo PCM (one load = L0 R0 L1 R1
+// = one complex point after the channel mean); the 50 % frame overlap is served by L2, HBM sees each sample once.  A
+// workgroup = 8 waves = 8 consecutive frames of one track, whose dB values are transposed through LDS into the reference
+// layout out[track][bin][frame].  Details at stft2048_kernel below; other window sizes: stft_generic_kernel.
 #include "dam_common.h"
 
 namespace dam {
@@ -27,10 +16,7 @@ namespace {
 constexpr int NFFT = 2048;
 constexpr int NCPX = NFFT / 2;       // complex points per frame
 constexpr int NBINS = NFFT / 2 + 1;  // 1025
-constexpr int TF = 16;               // frames per workgroup
-constexpr int STFT_WAVES = 4;
-constexpr int ROW = 68;              // float2 per scratch row (64 + 4 pad: 8-dword bank shift per row)
-constexpr int SCRATCH = 16 * ROW;    // float2 per wave (>= 1024)
+constexpr int ROW = 68;              // floats per row of a wave's exchange plane (64 + 4 pad: conflict-free column reads)
 
 __device__ __forceinline__ void radix4(float2& a0, float2& a1, float2& a2, float2& a3) {
     float2 s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = csub(a1, a3);
@@ -99,182 +85,245 @@ __device__ __forceinline__ float to_db(float m, float amin, float floor_db) {
     return m <= amin ? floor_db : 20.0f * log10f(m);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 2048-point kernel, built for OCCUPANCY.  (Round 1's version kept every lane-invariant table and a prefetched frame in
+// registers: 256 VGPR + 68 AGPR and 101 KB of LDS per 4-wave workgroup = one wave per SIMD, nothing to hide an LDS or HBM
+// round trip behind: 77 + 27 us for the 72 tracks of a C3 batch.  This one: 127 VGPR, 76 KB, 16 waves per CU, 59 us in one
+// launch, of which 26 us are the [bin][frame] write-out in 32-byte pieces -- profiles/README.md.)
+//   * radix-16 x radix-16 x radix-4 over the 1024 complex points z[n] = x[2n] + i x[2n+1], lane j of a wave holds
+//     z[j + 64 n1]; same twiddles and the same window * gain product as before;
+//   * the lane-invariant tables are NOT in the register file: stage twiddles come from a 8.5 KB LDS copy shared by the
+//     workgroup, window and split twiddles from L1 (coalesced 8-byte loads); no register prefetch of the next frame --
+//     four waves per SIMD hide the latency instead;
+//   * the three in-wave exchanges go through ONE float plane per wave (real parts, then imaginary parts: 4.3 KB instead of
+//     8.7 KB), the real-FFT split fetches the partner Z[1024-k] through the same plane and every lane turns its own 16 points
+//     Z[lane + 64 i + 256 d] into 16 bins (+ Nyquist on lane 0);
+//   * a workgroup = 8 waves = 8 consecutive frames of one track; the [8][1025] dB tile is written out as 16-byte pieces
+//     (4 frames of one bin); persistent: the workgroup walks tiles blockIdx.x, + gridDim.x, ... so the tables load once.
+//   LDS 76 KB per workgroup -> 2 workgroups = 16 waves per CU; <= 128 VGPR.
+constexpr int TF2 = 8;                 // frames (= waves) per workgroup tile
+constexpr int TROW = NBINS + 3;        // tile row pitch in floats (1028: rows stay 16-byte aligned)
+constexpr int PLANE = 16 * ROW;        // floats of one exchange plane (1088 >= 1024)
+
 template <typename PCM, int CH, bool PLANAR>
-__global__ __launch_bounds__(STFT_WAVES* WAVE) void stft_logmag_kernel(
+__global__ __launch_bounds__(TF2* WAVE, 4) void stft2048_kernel(
     const PCM* __restrict__ pcm, int64_t n_samples, int64_t outer_stride, int n_inner, int64_t inner_stride, int64_t cs,
-    const float* __restrict__ window,
-    const float2* __restrict__ tw /* W_2048^k */, const float* __restrict__ gain, int hop, int n_frames,
-    float amin, float floor_db, int normalize, float* __restrict__ out, float* __restrict__ out_tail, int n_tail) {
-    __shared__ __attribute__((aligned(16))) float2 scratch_all[STFT_WAVES * SCRATCH];
-    __shared__ float tile[NBINS * TF];
-    __shared__ float colmax[TF * TF];
+    const float* __restrict__ window, const float2* __restrict__ tw /* W_2048^k */, const float* __restrict__ gain, int hop,
+    int n_frames, int tiles_per_track, int n_tiles, float amin, float floor_db, int normalize, float* __restrict__ out,
+    float* __restrict__ out_tail, int n_tail) {
+    __shared__ __attribute__((aligned(16))) float2 tw1s[16 * 64];      // [k1][lane]  W_1024^(lane*k1)
+    __shared__ __attribute__((aligned(16))) float2 tw2s[16 * 4];       // [c][b]      W_64^(b*c)
+    __shared__ __attribute__((aligned(16))) float planes[TF2 * PLANE];
+    __shared__ __attribute__((aligned(16))) float tile[TF2 * TROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 16 * 64; e += TF2 * WAVE) tw1s[e] = tw[(2 * (e & 63) * (e >> 6)) & (NFFT - 1)];
+    if (tid < 64) tw2s[tid] = tw[(32 * (tid & 3) * (tid >> 2)) & (NFFT - 1)];
+    __syncthreads();
+    float* P = planes + wave * PLANE;
+    const int n_main = n_inner - n_tail;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t track = blockIdx.y;
-    const int t0 = blockIdx.x * TF;
-    const PCM* trk = pcm + (track / n_inner) * outer_stride + (track % n_inner) * inner_stride;
-    float2* S = scratch_all + wave * SCRATCH;
-    const float g = gain ? gain[track] : 1.0f;
-
-    // lane-invariant tables -> registers
-    float2 win[16], tw1[16], tw2[16], tw3[8];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        const int n = lane + 64 * n1;
-        win[n1] = make_float2(window[2 * n] * g, window[2 * n + 1] * g);
-        tw1[n1] = tw[(2 * lane * n1) & (NFFT - 1)];          // W_1024^(lane*k1)
-        tw2[n1] = tw[(32 * (lane & 3) * n1) & (NFFT - 1)];   // W_64^(b*c)
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) tw3[i] = tw[lane + 64 * i];  // W_2048^k
-
-    // float32 input: the raw samples of the wave's NEXT frame are requested before the FFT of the current one and only
-    // converted (channel mean) when that frame's turn comes, so the HBM latency of a frame hides under the previous FFT.
-    constexpr bool PREFETCH = sizeof(PCM) == 4;
-    typedef float raw_t __attribute__((ext_vector_type(2 * CH), aligned(4)));
-    raw_t rawn[PREFETCH ? 16 : 1];
-    auto frame_interior = [&](int t) {
-        const int64_t p0 = (int64_t)t * hop - NFFT / 2;
-        return t < n_frames && p0 >= 0 && p0 + NFFT <= n_samples;
-    };
-    auto issue_frame = [&](int t) {
-        if (PREFETCH && frame_interior(t)) {
+    for (int tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
+        const int64_t track = tile_i / tiles_per_track;
+        const int t0 = (tile_i - (int)track * tiles_per_track) * TF2;
+        const int t = t0 + wave;
+        if (t < n_frames) {             // wave-uniform
+            const PCM* trk = pcm + (track / n_inner) * outer_stride + (track % n_inner) * inner_stride;
+            const float g = gain ? gain[track] : 1.0f;
             const int64_t p0 = (int64_t)t * hop - NFFT / 2;
+            float2 v[16];
+            const bool interior = p0 >= 0 && p0 + NFFT <= n_samples;
+            // window (and, for interleaved float32 PCM, the samples) through buffer loads: scalar base + ONE lane offset
+            // register + immediates, instead of sixteen 64-bit address pairs each (the register file is what limits occupancy)
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(window), 0, NFFT * 4, 0x00020000);
+            constexpr bool BUF = sizeof(PCM) == 4 && !PLANAR;
+            // two halves of eight points: samples and window of a half are requested together, the compiler must not hoist the
+            // second half's loads over the first half's arithmetic (it would spill)
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int64_t p = p0 + 2 * (lane + 64 * n1);
-                if constexpr (PLANAR && CH == 2) {
-                    const f32x2_u a = *reinterpret_cast<const f32x2_u*>(trk + p), b = *reinterpret_cast<const f32x2_u*>(trk + cs + p);
-                    rawn[n1] = (raw_t){a.x, b.x, a.y, b.y};
+            for (int half = 0; half < 2; ++half) {
+                if (interior) {
+                    if constexpr (BUF) {
+                        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<PCM*>(trk + (int64_t)CH * p0), 0, NFFT * CH * 4, 0x00020000);
+#pragma unroll
+                        for (int n1 = 8 * half; n1 < 8 * half + 8; ++n1) {
+                            if constexpr (CH == 2) {
+                                const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, n1 * 1024, 0));
+                                v[n1] = make_float2((q.x + q.y) * 0.5f, (q.z + q.w) * 0.5f);
+                            } else {
+                                const f32x2 q = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prs, lane * 8, n1 * 512, 0));
+                                v[n1] = make_float2(q.x, q.y);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int n1 = 8 * half; n1 < 8 * half + 8; ++n1)
+                            v[n1] = load_pair_interior<PCM, CH, PLANAR>(trk, cs, p0 + 2 * (lane + 64 * n1));
+                    }
                 } else {
-                    rawn[n1] = *reinterpret_cast<const raw_t*>(trk + (int64_t)CH * p);
+#pragma unroll
+                    for (int n1 = 8 * half; n1 < 8 * half + 8; ++n1) {
+                        const int64_t p = p0 + 2 * (lane + 64 * n1);
+                        v[n1] = make_float2(mono_at<PCM, CH, PLANAR>(trk, cs, reflect(p, n_samples)),
+                                            mono_at<PCM, CH, PLANAR>(trk, cs, reflect(p + 1, n_samples)));
+                    }
                 }
+#pragma unroll
+                for (int n1 = 8 * half; n1 < 8 * half + 8; ++n1) {
+                    const f32x2 w = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, n1 * 512, 0));
+                    v[n1] = make_float2(v[n1].x * (w.x * g), v[n1].y * (w.y * g));
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-    };
-    issue_frame(t0 + wave);
-
-    for (int q = 0; q < TF / STFT_WAVES; ++q) {
-        const int tl = q * STFT_WAVES + wave;
-        const int t = t0 + tl;
-        if (t >= n_frames) break;   // wave-uniform; no workgroup barrier inside this loop
-        const int64_t p0 = (int64_t)t * hop - NFFT / 2;
-        float2 v[16];
-        if (PREFETCH && frame_interior(t)) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                if constexpr (CH == 2) v[n1] = make_float2((rawn[n1].x + rawn[n1].y) * 0.5f, (rawn[n1].z + rawn[n1].w) * 0.5f);
-                else v[n1] = make_float2(rawn[n1].x, rawn[n1].y);
-            }
-        } else if (p0 >= 0 && p0 + NFFT <= n_samples) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) v[n1] = load_pair_interior<PCM, CH, PLANAR>(trk, cs, p0 + 2 * (lane + 64 * n1));
-        } else {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int64_t p = p0 + 2 * (lane + 64 * n1);
-                v[n1] = make_float2(mono_at<PCM, CH, PLANAR>(trk, cs, reflect(p, n_samples)),
-                                    mono_at<PCM, CH, PLANAR>(trk, cs, reflect(p + 1, n_samples)));
-            }
-        }
-        if (q + 1 < TF / STFT_WAVES) issue_frame(t + STFT_WAVES);     // in flight during this frame's FFT
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(v[n1].x * win[n1].x, v[n1].y * win[n1].y);
-
-        // stage 1: DFT16 over n1 (n = 64 n1 + lane), twiddle W_1024^(lane k1), scatter A[k1][lane]
-        fft16(v);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) {
-            float2 a = v[fft16_pos(k1)];
-            if (k1) a = cmul(a, tw1[k1]);
-            S[k1 * ROW + lane] = a;
-        }
-        wave_lds_sync();
-        // stage 2: lane = (k1, b); DFT16 over a (n2 = 4a + b), twiddle W_64^(b c)
-        {
-            const int k1 = lane >> 2, b = lane & 3;
-#pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = S[k1 * ROW + 4 * a + b];
+            // stage 1: DFT16 over n1 (n = 64 n1 + lane), twiddle W_1024^(lane k1), exchange A[k1][lane] -> lane (k1, b)
             fft16(v);
-            wave_lds_sync();
+            float re[16];
+            {
+                float2 a[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                float2 x = v[fft16_pos(c)];
-                if (c) x = cmul(x, tw2[c]);
-                S[k1 * ROW + 4 * c + b] = x;
-            }
-        }
-        wave_lds_sync();
-        // stage 3: lane handles (k1 = lane&15, c = (lane>>4) + 4i); radix-4 over b; Z[k1 + 16c + 256d]
-        {
-            const int k1 = lane & 15, cq = lane >> 4;
+                for (int k0 = 0; k0 < 16; k0 += 4) {          // four twiddles in flight at a time (register pressure)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = cq + 4 * i;
-                const float4 lo = *reinterpret_cast<const float4*>(&S[k1 * ROW + 4 * c]);
-                const float4 hi = *reinterpret_cast<const float4*>(&S[k1 * ROW + 4 * c + 2]);
-                v[4 * i + 0] = make_float2(lo.x, lo.y);
-                v[4 * i + 1] = make_float2(lo.z, lo.w);
-                v[4 * i + 2] = make_float2(hi.x, hi.y);
-                v[4 * i + 3] = make_float2(hi.z, hi.w);
-                radix4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+                    for (int k1 = k0; k1 < k0 + 4; ++k1) {
+                        a[k1] = v[fft16_pos(k1)];
+                        if (k1) a[k1] = cmul(a[k1], tw1s[k1 * 64 + lane]);
+                        P[k1 * ROW + lane] = a[k1].x;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wave_lds_order();
+#pragma unroll
+                for (int q = 0; q < 16; ++q) re[q] = P[(lane >> 2) * ROW + 4 * q + (lane & 3)];
+                wave_lds_order();
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) P[k1 * ROW + lane] = a[k1].y;
+                wave_lds_order();
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = make_float2(re[q], P[(lane >> 2) * ROW + 4 * q + (lane & 3)]);
+                wave_lds_order();
             }
-            wave_lds_sync();
+            // stage 2: lane = (k1, b); DFT16 over a (n2 = 4a + b), twiddle W_64^(b c); exchange -> lane (k1 = lane&15, cq)
+            fft16(v);
+            {
+                const int k1 = lane >> 2, b = lane & 3;
+                float2 x[16];
+#pragma unroll
+                for (int c0 = 0; c0 < 16; c0 += 4) {
+#pragma unroll
+                    for (int c = c0; c < c0 + 4; ++c) {
+                        x[c] = v[fft16_pos(c)];
+                        if (c) x[c] = cmul(x[c], tw2s[c * 4 + b]);
+                        P[k1 * ROW + 4 * c + b] = x[c].x;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wave_lds_order();
+                float4 r4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r4[i] = *reinterpret_cast<const float4*>(&P[(lane & 15) * ROW + 4 * ((lane >> 4) + 4 * i)]);
+                wave_lds_order();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) P[k1 * ROW + 4 * c + b] = x[c].y;
+                wave_lds_order();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 i4 = *reinterpret_cast<const float4*>(&P[(lane & 15) * ROW + 4 * ((lane >> 4) + 4 * i)]);
+                    v[4 * i + 0] = make_float2(r4[i].x, i4.x);
+                    v[4 * i + 1] = make_float2(r4[i].y, i4.y);
+                    v[4 * i + 2] = make_float2(r4[i].z, i4.z);
+                    v[4 * i + 3] = make_float2(r4[i].w, i4.w);
+                }
+                wave_lds_order();
+            }
+            // stage 3: radix-4 over b: v[4i + d] = Z[lane + 64 i + 256 d]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) radix4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            // real-FFT split: bin k of every point this lane holds needs Z[(1024 - k) & 1023], fetched through the plane
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int d = 0; d < 4; ++d) S[lane + 64 * i + 256 * d] = v[4 * i + d];
-        }
-        wave_lds_sync();
-        // real-FFT split: bins k and 1024-k from Z[k], Z[1024-k]
+                for (int d = 0; d < 4; ++d) P[lane + 64 * i + 256 * d] = v[4 * i + d].x;
+            wave_lds_order();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = lane + 64 * i;
-            const float2 zk = S[k], zn = S[(NCPX - k) & (NCPX - 1)];
-            const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-            const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-            const float2 tt = cmul(tw3[i], o);
-            const float2 xa = cadd(e, tt), xb = csub(e, tt);
-            const float ma = sqrtf(xa.x * xa.x + xa.y * xa.y), mb = sqrtf(xb.x * xb.x + xb.y * xb.y);
-            const int fa = k, fb = NCPX - k;
-            tile[fa * TF + (tl ^ (fa & 15))] = to_db(ma, amin, floor_db);
-            tile[fb * TF + (tl ^ (fb & 15))] = to_db(mb, amin, floor_db);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) re[4 * i + d] = P[(NCPX - (lane + 64 * i + 256 * d)) & (NCPX - 1)];
+            wave_lds_order();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) P[lane + 64 * i + 256 * d] = v[4 * i + d].y;
+            wave_lds_order();
+            float db[16], nyq = 0.f, mx = 0.f;
+            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(tw), 0, NFFT * 8, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_barrier(0);            // four bins at a time: twiddle + partner loads stay short-lived
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int k = lane + 64 * i + 256 * d;
+                    const float2 zk = v[4 * i + d], zn = make_float2(re[4 * i + d], P[(NCPX - k) & (NCPX - 1)]);
+                    const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+                    const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+                    const f32x2 wk = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(trs, lane * 8, (64 * i + 256 * d) * 8, 0));
+                    const float2 tt = cmul(make_float2(wk.x, wk.y), o);
+                    const float2 xa = cadd(e, tt);
+#ifdef DAM_STFT_DIAG_NO_LOG
+                    db[4 * i + d] = xa.x * xa.x + xa.y * xa.y;
+#else
+                    db[4 * i + d] = to_db(sqrtf(xa.x * xa.x + xa.y * xa.y), amin, floor_db);
+#endif
+                    mx = fmaxf(mx, fabsf(db[4 * i + d]));
+                    if (i == 0 && d == 0 && lane == 0) {          // k = 0: Nyquist bin X[1024] = e - tt
+                        const float2 xb = csub(e, tt);
+                        nyq = to_db(sqrtf(xb.x * xb.x + xb.y * xb.y), amin, floor_db);
+                    }
+                }
+            }
+            wave_lds_order();                                           // the plane is free again for the next frame
+            if (normalize) {        // librosa.util.normalize(features): each frame divided by its max-abs over the bins
+                mx = fmaxf(mx, fabsf(__shfl(nyq, 0)));
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                if (mx >= 1.17549435e-38f) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) db[q] = db[q] / mx;
+                    nyq = nyq / mx;
+                }
+            }
+            float* trow = tile + wave * TROW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) trow[lane + 64 * i + 256 * d] = db[4 * i + d];
+            if (lane == 0) trow[NCPX] = nyq;
         }
-        if (lane == 0) {
-            const float2 z = S[NCPX / 2];
-            const float m = sqrtf(z.x * z.x + z.y * z.y);
-            tile[(NCPX / 2) * TF + (tl ^ ((NCPX / 2) & 15))] = to_db(m, amin, floor_db);
-        }
-        wave_lds_sync();
-    }
-    __syncthreads();
-
-    // write-out: thread -> (frame tl = tid&15, bin f = tid>>4 + 16*it); rows of 16 frames = 64 B
-    const int tl = threadIdx.x & 15, f0 = threadIdx.x >> 4;
-    const bool col_ok = (t0 + tl) < n_frames;
-    float scale = 1.0f;
-    if (normalize) {
-        float m = 0.0f;
-        if (col_ok)
-            for (int f = f0; f < NBINS; f += 16) m = fmaxf(m, fabsf(tile[f * TF + (tl ^ (f & 15))]));
-        colmax[f0 * TF + tl] = m;
         __syncthreads();
-        m = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, colmax[r * TF + tl]);
-        scale = m;
-    }
-    if (col_ok) {
-        // the last n_tail tracks of every outer group go to out_tail (dataset item = (stems, mix), data/dataset.py:207-210)
-        const int64_t og = track / n_inner;
-        const int ig = (int)(track % n_inner), n_main = n_inner - n_tail;
-        float* o = (ig < n_main ? out + ((og * n_main + ig) * NBINS) * (int64_t)n_frames
-                                : out_tail + ((og * n_tail + (ig - n_main)) * NBINS) * (int64_t)n_frames) + t0 + tl;
-        for (int f = f0; f < NBINS; f += 16) {
-            float vdb = tile[f * TF + (tl ^ (f & 15))];
-            if (normalize && scale >= 1.17549435e-38f) vdb = vdb / scale;
-            o[(int64_t)f * n_frames] = vdb;
+#ifndef DAM_STFT_DIAG_NO_WRITEOUT
+        {   // write-out: (bin, half) -> 4 consecutive frames = one 16-byte piece of out[track][bin][t0 + 4 half ...]
+            const int64_t og = track / n_inner;
+            const int ig = (int)(track % n_inner);
+            float* obase = (ig < n_main ? out + ((og * n_main + ig) * NBINS) * (int64_t)n_frames
+                                        : out_tail + ((og * n_tail + (ig - n_main)) * NBINS) * (int64_t)n_frames) + t0;
+            for (int e = tid; e < NBINS * 2; e += TF2 * WAVE) {
+                const int f = e >> 1, h = e & 1;
+                const int left = n_frames - (t0 + 4 * h);                  // frames of this piece inside the track
+                if (left <= 0) continue;
+                f32x4_u q;
+                q.x = tile[(4 * h + 0) * TROW + f]; q.y = tile[(4 * h + 1) * TROW + f];
+                q.z = tile[(4 * h + 2) * TROW + f]; q.w = tile[(4 * h + 3) * TROW + f];
+                float* o = obase + (int64_t)f * n_frames + 4 * h;
+                if (left >= 4) {
+                    *reinterpret_cast<f32x4_u*>(o) = q;
+                } else {
+                    o[0] = q.x;
+                    if (left > 1) o[1] = q.y;
+                    if (left > 2) o[2] = q.z;
+                }
+            }
         }
+#else
+        if (tile_i == 0x7fffffff) out[tid] = tile[tid];
+#endif
+        __syncthreads();
     }
 }
 
@@ -395,7 +444,7 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
         return DAM_ERR_UNSUPPORTED;
     }
     const int n_frames = (int)(1 + n_samples / hop);
-    dim3 grid((unsigned)cdiv(n_frames, TF), (unsigned)n_tracks), block(STFT_WAVES * WAVE);
+    dim3 grid, block;
     hipStream_t s = (hipStream_t)stream;
     const float2* tw = reinterpret_cast<const float2*>(twiddles);
     const float floor_db = (float)(20.0 * log10((double)amin));
@@ -420,10 +469,16 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
         DAM_CHECK_LAUNCH();
         return DAM_OK;
     }
+    const int tiles_per_track = (int)cdiv(n_frames, TF2);
+    const int64_t n_tiles64 = (int64_t)tiles_per_track * n_tracks;
+    if (n_tiles64 > 0x7fffffff) return DAM_ERR_UNSUPPORTED;
+    const int n_tiles = (int)n_tiles64;
+    grid = dim3((unsigned)(n_tiles < 512 ? n_tiles : 512));           // persistent: two workgroups per CU
+    block = dim3(TF2 * WAVE);
 #define DAM_STFT_LAUNCH(T, C, P)                                                                              \
-    hipLaunchKernelGGL((stft_logmag_kernel<T, C, P>), grid, block, 0, s, (const T*)pcm, n_samples, outer_stride, \
-                       (int)n_inner, inner_stride, channel_stride, window, tw, gain, hop, n_frames, amin, floor_db, \
-                       normalize, out, out_tail, n_tail)
+    hipLaunchKernelGGL((stft2048_kernel<T, C, P>), grid, block, 0, s, (const T*)pcm, n_samples, outer_stride, \
+                       (int)n_inner, inner_stride, channel_stride, window, tw, gain, hop, n_frames, tiles_per_track, \
+                       n_tiles, amin, floor_db, normalize, out, out_tail, n_tail)
     if (pcm_dtype == DAM_PCM_F32) {
         if (channels == 1) DAM_STFT_LAUNCH(float, 1, false);
         else if (planar) DAM_STFT_LAUNCH(float, 2, true);
