@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: where do device-to-device copies in a training step come from?  Uses torch.profiler on one eager step."""
+"""Diagnostic (renamed from find_copies.py): where do device-to-device copies in a training step come from?  Uses torch.profiler on one eager step."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
