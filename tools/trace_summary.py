@@ -3,7 +3,7 @@
 
   trace_summary.py <dir> <n_steps> [<n_instances>]
 
-Only the LAST n_steps training steps are counted (a step starts at its stft_logmag_kernel launch), so one-off work --
+Only the LAST n_steps training steps are counted (a step starts at its STFT front-end launch), so one-off work --
 parameter flattening, synthetic-data generation, eager warm-up -- does not leak into the per-step figures.  Also prints
 the wall span of those steps (first kernel start to last kernel end) next to the sum of kernel durations: the
 difference is launch gaps / dependency bubbles."""
@@ -15,7 +15,7 @@ def short(n):
     m = re.match(r'([\w:]+(<[^>]*>)?)', n)
     return m.group(1) if m else n[:40]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-starts = [i for i, r in enumerate(rows) if 'stft_logmag_kernel' in r['Kernel_Name']]
+starts = [i for i, r in enumerate(rows) if 'stft2048_kernel' in r['Kernel_Name'] or 'stft_generic_kernel' in r['Kernel_Name']]
 if len(starts) > nsteps:
     # steps = [starts[-nsteps-1], starts[-1]): the last launch opens a step that is cut off by the end of the timed region
     lo, hi = starts[-nsteps - 1], starts[-1]
