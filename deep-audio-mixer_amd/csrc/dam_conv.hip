@@ -21,6 +21,7 @@
 //   * a "tap grid" (nA x nB taps with signed input steps, weight-tap strides and an output stride/offset)
 //     expresses forward, stride-1 dgrad (negative steps) and the four parity classes of a stride-2 dgrad
 //     with the same kernel.
+#include <cstdlib>
 #include "dam_common.h"
 #include "dam_conv_geo.h"
 #include "dam_conv_stage.h"
@@ -483,6 +484,9 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
             if (MB > 1 && (MB >= NB || NB == 1)) MB >>= 1; else NB >>= 1;
         }
     }
+    if (const char* e = getenv("DAM_TILE")) {          // diagnostic: "MBxNB"
+        MB = e[0] - '0'; NB = e[2] - '0'; split = false;
+    }
     // LDS: shrink the channel group, then the M tile, until the patch fits
     const size_t LDS_MAX = 64 * 1024;
     int CG = 1;
@@ -517,6 +521,21 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
         }
     }
     const size_t lds = (size_t)CG * g.PR * g.PWT * 64;
+    // thick 3x3 / stride-1 layers: the variant whose patch is staged chunk by chunk by loader waves beside the MFMAs
+    if (!getenv("DAM_NO_PIPE")) {
+        const int rc = conv_pipe_try(g, MB, NB, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st);
+        if (rc == DAM_OK) {
+            if (g.ksplit > 1) {
+                const int64_t n4 = (int64_t)g.B * g.OHt * g.OWt * g.N / 4;
+                const int blocks = (int)(cdiv(n4, 256) < 2048 ? cdiv(n4, 256) : 2048);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, g.ksplit, n4, g.N / 4, bias, res,
+                                   res_mask, y);
+                DAM_CHECK_LAUNCH();
+            }
+            return DAM_OK;
+        }
+        if (rc != DAM_ERR_UNSUPPORTED) return rc;
+    }
 #define DAM_CONV_CASE(M_, N_) \
     if (MB == M_ && NB == N_) return launch_conv<M_, N_>(g, lds, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st)
     DAM_CONV_CASE(4, 4); DAM_CONV_CASE(4, 2); DAM_CONV_CASE(4, 1);

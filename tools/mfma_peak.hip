@@ -1,51 +1,61 @@
-// Diagnostic (not part of the library): sustained v_mfma_f32_16x16x4_f32 rate, with and without ds_read_b128 feeding.
+// tools/mfma_peak.hip -- what v_mfma_f32_16x16x4_f32 sustains on this chip: a register-only loop (no memory), NACC independent
+// accumulators per wave, W waves per SIMD, G workgroups.  Prints time per MFMA per SIMD in ns (hipEvents) and in shader clocks
+// (s_memtime), so the sustained clock under matrix load and the issue cost of dependent chains can be read off separately.
+// build: hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o tools/mfma_peak
 #include <hip/hip_runtime.h>
-#include <stdio.h>
+#include <cstdio>
+#include <cstdlib>
 typedef float v4f __attribute__((ext_vector_type(4)));
-template <int NACC, bool LDS>
-__global__ __launch_bounds__(256) void k(float* out, int iters) {
-    __shared__ __attribute__((aligned(16))) float sm[16384];
-    for (int i = threadIdx.x; i < 16384; i += 256) sm[i] = (float)(i % 7) * 0.001f;
-    __syncthreads();
+
+template <int NACC>
+__global__ __launch_bounds__(1024) void mfma_loop(float* out, long long* clocks, int iters, float a0, float b0) {
     v4f acc[NACC];
-    for (int i = 0; i < NACC; ++i) acc[i] = (v4f){0, 0, 0, 0};
-    float4 a = make_float4(1.f, 2.f, 3.f, 4.f), b = make_float4(0.5f, 0.25f, 0.125f, 1.f);
-    const int lane = threadIdx.x & 63;
-    for (int it = 0; it < iters; ++it) {
-        if (LDS) {
-            b = *reinterpret_cast<const float4*>(&sm[((it * 64 + lane) * 4) & 16383]);
-        }
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    if (s == 123.456f) out[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) clocks[0] = t1 - t0;
+}
+
+template <int NACC>
+void run(int grid, int waves_per_simd, int iters) {
+    float* out; long long* clk;
+    hipMalloc(&out, 4); hipMalloc(&clk, 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int threads = 256 * waves_per_simd;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(mfma_loop<NACC>, dim3(grid), dim3(threads), 0, 0, out, clk, iters, 1.0f, 2.0f);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+    }
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+    const double per_simd = (double)iters * 4 * NACC * waves_per_simd * ((grid + 255) / 256);   // MFMAs through one SIMD's pipe
+    const double flops = (double)grid * threads / 64 * iters * 4 * NACC * 2048.0;
+    printf("nacc %d  grid %4d  waves/SIMD %d : %7.1f us  %6.2f ns/MFMA/SIMD  %6.1f clk/MFMA/SIMD (s_memtime)  %6.1f TFLOP/s\n", NACC, grid,
+           waves_per_simd, ms * 1e3, ms * 1e6 / per_simd, (double)c / (iters * 4.0 * NACC * waves_per_simd), flops / (ms * 1e-3) * 1e-12);
+    hipFree(out); hipFree(clk);
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+    for (int grid : {1, 64, 160, 256}) {
+        for (int w : {1, 2, 4}) {
+            run<1>(grid, w, iters);
+            run<4>(grid, w, iters);
+            run<8>(grid, w, iters);
         }
     }
-    float s = 0;
-    for (int i = 0; i < NACC; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
-    out[blockIdx.x * 256 + threadIdx.x] = s;
-}
-template <int NACC, bool LDS>
-void run(const char* name, int blocks, int iters) {
-    float* out; hipMalloc(&out, (size_t)blocks * 256 * 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, out, iters);
-    hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, out, iters);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-    double flop = (double)blocks * 4 * iters * NACC * 4 * 2048.0;
-    printf("%-28s blocks %5d: %.3f ms  %.1f TFLOP/s\n", name, blocks, ms, flop / ms / 1e9);
-    hipFree(out);
-}
-int main() {
-    run<4, false>("4 acc, regs only", 256, 20000);
-    run<4, false>("4 acc, regs only", 512, 20000);
-    run<4, false>("4 acc, regs only", 1024, 20000);
-    run<4, true>("4 acc + ds_read_b128", 512, 20000);
-    run<1, true>("1 acc + ds_read_b128", 512, 40000);
-    run<16, true>("16 acc + ds_read_b128", 512, 5000);
     return 0;
 }
