@@ -452,6 +452,12 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
             if (rc2 != DAM_ERR_UNSUPPORTED) return rc2;
         }
     }
+    // thick 3x3 layers: the persistent variant whose patches are staged chunk by chunk by loader waves beside the MFMAs
+    // (DAM_NO_PIPE: diagnostic switch for the A/B in tools/pipe_ab.sh)
+    if (!getenv("DAM_NO_PIPE")) {
+        const int rc = conv_pipe_try(g, h_hi - h_lo, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st);
+        if (rc != DAM_ERR_UNSUPPORTED) return rc;
+    }
     // tile choice.  With a workspace: keep big tiles (weights are streamed per workgroup: FLOPs per weight byte grow with
     // the tile) and get the workgroup count from split-K over channel groups; otherwise shrink tiles to fill the chip.
     const int64_t npix = (int64_t)Ho * Wo;
@@ -483,9 +489,6 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
         while (wgs(MB, NB) < 512 && (MB > 1 || NB > 1)) {
             if (MB > 1 && (MB >= NB || NB == 1)) MB >>= 1; else NB >>= 1;
         }
-    }
-    if (const char* e = getenv("DAM_TILE")) {          // diagnostic: "MBxNB"
-        MB = e[0] - '0'; NB = e[2] - '0'; split = false;
     }
     // LDS: shrink the channel group, then the M tile, until the patch fits
     const size_t LDS_MAX = 64 * 1024;
@@ -521,21 +524,6 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
         }
     }
     const size_t lds = (size_t)CG * g.PR * g.PWT * 64;
-    // thick 3x3 / stride-1 layers: the variant whose patch is staged chunk by chunk by loader waves beside the MFMAs
-    if (!getenv("DAM_NO_PIPE")) {
-        const int rc = conv_pipe_try(g, MB, NB, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st);
-        if (rc == DAM_OK) {
-            if (g.ksplit > 1) {
-                const int64_t n4 = (int64_t)g.B * g.OHt * g.OWt * g.N / 4;
-                const int blocks = (int)(cdiv(n4, 256) < 2048 ? cdiv(n4, 256) : 2048);
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, g.ksplit, n4, g.N / 4, bias, res,
-                                   res_mask, y);
-                DAM_CHECK_LAUNCH();
-            }
-            return DAM_OK;
-        }
-        if (rc != DAM_ERR_UNSUPPORTED) return rc;
-    }
 #define DAM_CONV_CASE(M_, N_) \
     if (MB == M_ && NB == N_) return launch_conv<M_, N_>(g, lds, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st)
     DAM_CONV_CASE(4, 4); DAM_CONV_CASE(4, 2); DAM_CONV_CASE(4, 1);

@@ -1,19 +1,27 @@
 // dam_conv_pipe.hip -- the tile convolution (dam_conv.hip: same GEMM mapping, packed weights, tap grid, epilogue) with the
-// input staging taken OFF the compute waves, for the thick 3x3 / stride-1 layers (ResNet layer3-6 forward and data gradient:
-// 64-256 channels on 33- to 5-pixel-wide rows).
+// input staging taken OFF the compute waves, for the thick 3x3 layers (ResNet layer3-6 forward and data gradient: 64-256
+// channels on 33- to 5-pixel-wide rows).
 //
-// What the PMC passes on conv_igemm_kernel showed (profiles/r02_pmc_thick_layers.csv, layer3): the matrix pipe is busy 55 % of
-// the launch; a workgroup stages its whole patch (all channel chunks, ~50 KB) before its first MFMA, every first-round
-// workgroup does so at the same time, and with that much LDS only three fit a CU, so 1064 workgroups need a second, 39 %-full
-// round that stages with nothing to overlap.  Here:
-//   * a workgroup = 4 compute waves + 2 LOADER waves.  The patch is staged one 16-channel chunk at a time into two alternating
-//     LDS buffers by the loader waves (own vmcnt queues: a compute wave that waited for its weights would otherwise also wait for
-//     every older patch load) while the compute waves run the nine taps of the previous chunk; one barrier per chunk;
-//   * the loaders' item geometry (patch row / column / channel quad -> global offset, LDS offset, in-tensor?) is chunk
-//     independent and computed once per workgroup; a chunk costs PIPE_U loads + PIPE_U LDS writes per loader thread;
-//   * two chunk buffers are 2 x 13 KB for layer3 instead of 54 KB: five workgroups per CU, every workgroup resident in one round;
-//   * the weight pipeline (L2 -> registers, two items ahead, three rotating operand sets) runs ACROSS chunk boundaries: only the
-//     LDS operand reads restart behind the barrier.
+// What the measurements on conv_igemm_kernel and on the first version of this kernel showed (profiles/r02_pmc_thick_layers.csv,
+// tools/pipe_stamps_probe.py, tools/mfma_peak.hip):
+//   * v_mfma_f32_16x16x4_f32 sustains 32 clocks per instruction per SIMD at 2.37 GHz on the whole chip (155 TFLOP/s), dependent
+//     accumulator chains included -- the matrix pipe itself is not the limit;
+//   * a workgroup that stages its whole patch before its first MFMA idles the pipe for 3-4 us, and the next workgroup the
+//     dispatcher starts in its place does so again: with ~4 tiles per CU and two resident workgroups that was a third of the launch;
+//   * a wave issues one instruction per ~4 clocks, so the ~40 scalar instructions and two branches of per-item bookkeeping
+//     (which packed-weight block is next?) cost the pipe ~7 clocks per MFMA.
+// Here:
+//   * a workgroup = 4 compute waves + 2 LOADER waves, and it is PERSISTENT: it walks work units (tile x output-block group x
+//     split-K slice) blockIdx.x, blockIdx.x + gridDim.x, ...  The stream of (unit, 16-channel chunk) stages flows through two
+//     alternating LDS buffers without a break at unit boundaries: while the compute waves run the last chunk of a unit and write
+//     its tile out, the loaders already stage the first chunks of the next one.  One raw barrier per chunk;
+//   * loader waves take whole 64-item segments of a patch row, so everything that changes from unit to unit is scalar (row
+//     base, row inside the tensor?); the per-lane part (column -> LDS slot, global column offset, column inside the tensor?) is
+//     computed once per launch.  A chunk costs a loader thread <= 16 loads + 16 LDS writes and ~3 vector instructions apiece;
+//   * the item grid is static: item (chunk, tap T) requests the packed weights of item T+2 (of the next chunk, or of the next
+//     unit's first chunk, behind the chunk boundary) at `tap constant + chunk scalar` -- two scalar adds, no branch -- and the
+//     weight pipeline (L2 -> registers, two items ahead, three rotating operand sets) runs across chunk and unit boundaries.
+#include <climits>
 #include <cstdlib>
 #include "dam_common.h"
 #include "dam_conv_geo.h"
@@ -24,12 +32,18 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int PIPE_U = 8;                       // float4 items per loader thread and half chunk
-constexpr int PIPE_H = 2;                       // a chunk is fetched as PIPE_H batches of PIPE_U items per loader thread
+constexpr int PIPE_LT = 256;                    // loader threads: 4 waves, one per SIMD beside a compute wave (a wave streaming MFMAs
+                                                // leaves its SIMD's other waves few issue slots: two loader waves on two SIMDs held
+                                                // back the two compute waves they shared with, and the barrier made all four wait)
+constexpr int PIPE_THREADS = 256 + PIPE_LT;
+constexpr int PIPE_U = 4;                       // float4 items per loader thread and chunk (a chunk of the patch <= 1024 items)
+constexpr int PIPE_BUF1 = 32768;                // LDS byte offset of the second chunk buffer: a compile-time constant, so the
+                                                // loaders' LDS writes carry it as an immediate
 
 // Raw barrier: the wave's LDS traffic is drained, its global loads are NOT (__syncthreads() would also wait for the patch /
 // weight loads that were just put in flight on purpose).
 #define DAM_PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // timing experiments (tools/build_variant.sh): results are wrong with any of these defined
 #ifdef DAM_PIPE_DIAG_W0
 #define DAM_PIPE_WOFF(x) ((x) & 0)              // every weight load hits the same 4 KB
@@ -37,7 +51,7 @@ constexpr int PIPE_H = 2;                       // a chunk is fetched as PIPE_H 
 #define DAM_PIPE_WOFF(x) (x)
 #endif
 
-// Diagnostic build only (-DDAM_PIPE_STAMPS, launches without split-K): the workspace receives s_memtime stamps of phase
+// Diagnostic build only (-DDAM_PIPE_STAMPS): the caller's workspace (`stamps`, otherwise unused here) receives s_memtime stamps of phase
 // boundaries, [workgroup][role: wave 0 / first loader wave][32] of (tag << 56 | time); read by tools/pipe_stamps_probe.py.
 #ifdef DAM_PIPE_STAMPS
 #define DAM_PSTAMP(role, tag)                                                                                         \
@@ -51,183 +65,210 @@ constexpr int PIPE_H = 2;                       // a chunk is fetched as PIPE_H 
 #define DAM_PSTAMP(role, tag) do { } while (0)
 #endif
 
-// NL = loader waves (1: patches up to 1024 float4 items per chunk, 2: up to 2048)
-template <int MB, int NB, int NL>
-__global__ __launch_bounds__(256 + 64 * NL) void conv_pipe_kernel(const ConvGeo g, const float* __restrict__ X,
+struct PipeUnit {            // one work unit, decoded (wave uniform)
+    int p0, img, nb0, oh_first;
+};
+
+template <int MB, int NB>
+__device__ __forceinline__ PipeUnit pipe_decode(const ConvGeo& g, int unit, int nby, float inv_wo) {
+    PipeUnit u;
+    const int r = unit / g.tiles_m, tm = unit - r * g.tiles_m;
+    u.img = r / nby;
+    u.nb0 = (r - u.img * nby) * NB;
+    u.p0 = tm * (64 * MB);
+    u.oh_first = fast_div(u.p0, g.Wo, inv_wo);
+    return u;
+}
+
+// The second launch bound is the register budget (waves per SIMD): without it the compiler hoists every loop-invariant address
+// of the loader's 16 segments into registers (198 VGPRs, one workgroup per CU).
+template <int MB, int NB>
+__global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g, const int nunits, const float* __restrict__ X,
                                                                  const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                                  const float* __restrict__ in_scale,
                                                                  const float* __restrict__ in_shift, float* __restrict__ Y,
                                                                  const float* __restrict__ res, const float* __restrict__ res_mask,
-                                                                 float* __restrict__ splitk_ws) {
+                                                                 float* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PIPE_LTHREADS = 64 * NL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, kq = lane >> 4;
-    constexpr int MW = 16 * MB, TM = 4 * MW;
-    const int ks = blockIdx.y % g.ksplit;
-    const int img = blockIdx.z, nb0 = (blockIdx.y / g.ksplit) * NB;
+    constexpr int MW = 16 * MB;
     const int HoWo = g.Ho * g.Wo;
-    const int p0 = blockIdx.x * TM;
     const float inv_wo = 1.0f / (float)g.Wo;
-    const int oh_first = fast_div(p0, g.Wo, inv_wo);
     const int chunk_bytes = g.PR * g.PWT * 64;
-    const int ih0 = oh_first * g.s + g.r0;
-    const int cg_lo = ks * g.gps, cg_hi = cg_lo + g.gps < g.nchunks ? cg_lo + g.gps : g.nchunks;     // CG == 1: group = chunk
-    const float* ximg = X + (size_t)img * g.H * g.W * g.C;
+    const int nby = g.N / 16 / NB;
+    const int G = gridDim.x;
+    const size_t img_floats = (size_t)g.H * g.W * g.C;
 #ifdef DAM_PIPE_STAMPS
-    unsigned long long* stamp_p = reinterpret_cast<unsigned long long*>(splitk_ws) +
-                                  (size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;
+    unsigned long long* stamp_p = reinterpret_cast<unsigned long long*>(stamps) + (size_t)blockIdx.x * 64;
     int stamp_n = 0;
 #endif
     DAM_PSTAMP(wave >> 2, 1);
 
     if (wave >= 4) {
         // ================= loader waves =================
+        // An item = one pixel's channel quad of the chunk (a float4); thread t of the 256 takes items t, t + 256, ... of the
+        // patch (<= PIPE_U of them).  Per item, computed once per launch: its LDS byte offset and its BYTE offset in the image
+        // relative to (patch row 0, column 0).  Everything that changes from unit to unit is scalar: a request adds the unit's
+        // row base and the chunk to the offsets and loads through a buffer resource that spans exactly the image -- rows above /
+        // below the tensor and the items of columns outside it (offset INT_MIN) fail the range check and read as zero, which
+        // is the padding.
         const int ltid = tid - 256;
-        const int ipr = g.PWin * 4;                              // float4 items per patch row (one 16-channel chunk)
+        const int WC = g.W * g.C;
+        const int ipr = g.PWin * 4;                              // items per patch row
         const int total = g.PR * ipr;
-        // items of this thread: e = ltid + PIPE_LTHREADS * u, u < nu (wave uniform: unused u cost nothing -- the geometry of an
-        // item is ~25 vector instructions, and a full set of 16 was 2 us of set-up in front of every workgroup's first load)
-        const int nu = (total + PIPE_LTHREADS - 1) / PIPE_LTHREADS;
-        const int step_r = PIPE_LTHREADS / ipr, step_c = PIPE_LTHREADS - step_r * ipr;      // e += LTHREADS in (row, column)
-        // global float index (chunk 0) or -1 = outside the tensor (zero); LDS byte offset (channel quad in bits 4-5) or -1
-        int goff[PIPE_H][PIPE_U], dst[PIPE_H][PIPE_U];
-        int pr = fast_div(ltid, ipr, 1.0f / (float)ipr), rem = ltid - pr * ipr;
-#pragma unroll
-        for (int h = 0; h < PIPE_H; ++h)
+        const int tab_off = PIPE_BUF1 + chunk_bytes;             // scale / shift tables (2 * C floats, only with in_scale)
+        const int dump_off = tab_off + (in_scale ? 2 * g.C * 4 : 0);    // 4 KB that absorb the writes of threads without an item
+        int dst[PIPE_U], gcol[PIPE_U];
+        {
+            const int step_r = PIPE_LT / ipr, step_c = PIPE_LT - step_r * ipr;  // e += PIPE_LT in (row, item of the row)
+            int pr = fast_div(ltid, ipr, 1.0f / (float)ipr), rem = ltid - pr * ipr;
 #pragma unroll
             for (int u = 0; u < PIPE_U; ++u) {
-                goff[h][u] = -1; dst[h][u] = -1;
-                if (h * PIPE_U + u < nu) {
-                    if (pr < g.PR) {
-                        const int pw = rem >> 2, cq = rem & 3;
-                        const int ih = ih0 + pr, iw = g.c0 + pw;
-                        const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
-                        dst[h][u] = ((pr * g.PWT + slot) * 16 + cq * 4) * 4;
-                        if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) goff[h][u] = (ih * g.W + iw) * g.C + cq * 4;
-                    }
-                    pr += step_r; rem += step_c;
-                    if (rem >= ipr) { rem -= ipr; ++pr; }
+                dst[u] = dump_off + ltid * 16; gcol[u] = INT_MIN;
+                if (ltid + PIPE_LT * u < total) {
+                    const int pw = rem >> 2, cq = rem & 3;
+                    const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
+                    dst[u] = ((pr * g.PWT + slot) * 16 + cq * 4) * 4;
+                    const int iw = g.c0 + pw;
+                    if (iw >= 0 && iw < g.W) gcol[u] = (pr * WC + iw * g.C + cq * 4) * 4;
                 }
+                pr += step_r; rem += step_c;
+                if (rem >= ipr) { rem -= ipr; ++pr; }
             }
-        float4 v[PIPE_U];
-#define DAM_PIPE_ISSUE(H_, CHUNK_)                                                                                         \
+        }
+        const int cq4 = (lane & 3) * 4;                          // an item's channel quad is its lane's (256 and ipr are multiples of 4)
+        // Two register sets hold two DIFFERENT chunks of the stream, so a chunk's loads are in flight for two compute periods
+        // (one measured period is ~2.3 us at one workgroup per CU, about the latency of the load itself: with one chunk in
+        // flight the loaders, not the MFMAs, set the pace).  A round = commit the older set, refill it from the head of the
+        // stream, barrier; a refill is ALWAYS PIPE_U loads (behind the end of the stream at an offset that fails the range
+        // check: no memory traffic), so the wait in front of a commit is the compile-time vmcnt(PIPE_U), not 0.
+        float4 v[2][PIPE_U];
+        int unit = blockIdx.x;                                   // head of the stream: the next chunk to request
+        PipeUnit cur = pipe_decode<MB, NB>(g, unit, nby, inv_wo);
+        int icg = 0;
+        int rowb = (cur.oh_first * g.s + g.r0) * WC * 4;         // byte offset of patch row 0 in the image (negative above it)
+        const unsigned img_bytes = (unsigned)img_floats * 4u;
+        __amdgpu_buffer_rsrc_t xrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (size_t)cur.img * img_floats), 0, img_bytes, 0x00020000);
+        bool head = true;
+        int s_sb[2] = {0, 0}, s_cg[2] = {0, 0};                  // per register set: byte base and chunk of what it holds
+        bool s_live[2] = {false, false};
+#define DAM_PIPE_REFILL(S_)                                                                                                \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int u = 0; u < PIPE_U; ++u) {                                                               \
-            if ((H_) * PIPE_U + u >= nu) break;                                                                            \
-            const int o_ = goff[H_][u] >= 0 ? goff[H_][u] + (CHUNK_) * 16 : 0;   /* unconditional load, clamped address */ \
-            v[u] = *reinterpret_cast<const float4*>(ximg + (unsigned)o_);                                                  \
-        }                                                                                                                  \
-    } while (0)
-#define DAM_PIPE_COMMIT(H_, CHUNK_, BUF_)                                                                                  \
-    do {                                                                                                                   \
-        _Pragma("unroll") for (int u = 0; u < PIPE_U; ++u) {                                                               \
-            if ((H_) * PIPE_U + u >= nu) break;                                                                            \
-            if (dst[H_][u] < 0) continue;                                                                                  \
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);                                                                    \
-            if (goff[H_][u] >= 0) {                                                                                        \
-                x = v[u];                                                                                                  \
-                if (in_scale) {                                                                                            \
-                    const int cq4_ = (dst[H_][u] >> 2) & 12;                                                               \
-                    const float4 sc = *reinterpret_cast<const float4*>(in_scale + (CHUNK_) * 16 + cq4_);                   \
-                    const float4 sh = *reinterpret_cast<const float4*>(in_shift + (CHUNK_) * 16 + cq4_);                   \
-                    x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y);                                              \
-                    x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);                                              \
-                    if (g.relu_in) {                                                                                       \
-                        x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);        \
-                    }                                                                                                      \
-                }                                                                                                          \
+        const int sb_ = head ? rowb + icg * 64 : INT_MIN;                                                                  \
+        _Pragma("unroll") for (int u = 0; u < PIPE_U; ++u)                                                                 \
+            v[S_][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, gcol[u] + sb_, 0, 0));      \
+        s_sb[S_] = sb_; s_cg[S_] = icg; s_live[S_] = head;                                                                 \
+        if (head) {                                         /* advance the head */                                         \
+            if (icg + 1 < g.nchunks) {                                                                                     \
+                ++icg;                                                                                                     \
+            } else if (unit + G < nunits) {                                                                                \
+                unit += G;                                                                                                 \
+                cur = pipe_decode<MB, NB>(g, unit, nby, inv_wo);                                                           \
+                icg = 0;                                                                                                   \
+                rowb = (cur.oh_first * g.s + g.r0) * WC * 4;                                                               \
+                xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (size_t)cur.img * img_floats), 0, img_bytes, \
+                                                          0x00020000);                                                     \
+            } else {                                                                                                       \
+                head = false;                                                                                              \
             }                                                                                                              \
-            *reinterpret_cast<float4*>(smem + (BUF_) + dst[H_][u]) = x;                                                    \
         }                                                                                                                  \
     } while (0)
-        DAM_PIPE_ISSUE(0, cg_lo);
-        // the slots of a stride-2 de-interleave that no item covers must read as zero: clear both buffers once (with stride 1
-        // every slot a valid pixel reads is an item).  One loader wave's LDS writes execute in order, so its commits land
-        // after its clear; two loader waves meet at barrier (0).
-        if (g.s != 1)
-            for (int e = ltid * 16; e < 2 * chunk_bytes; e += PIPE_LTHREADS * 16)
-                *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-        DAM_PSTAMP(1, 2);
-        if (NL > 1) DAM_PIPE_BARRIER();             // (0)
-        DAM_PSTAMP(1, 3);
-        DAM_PIPE_COMMIT(0, cg_lo, 0);
-        if (nu > PIPE_U) {
-            DAM_PIPE_ISSUE(1, cg_lo);
-            DAM_PIPE_COMMIT(1, cg_lo, 0);
-        }
-        if (cg_lo + 1 < cg_hi) DAM_PIPE_ISSUE(0, cg_lo + 1);
-        DAM_PSTAMP(1, 4);
-        DAM_PIPE_BARRIER();                         // (1) chunk cg_lo is staged
-        DAM_PSTAMP(1, 5);
-        for (int cg = cg_lo; cg < cg_hi; ++cg) {
-            const int nbuf = (((cg - cg_lo) & 1) ^ 1) * chunk_bytes;
-            if (cg + 1 < cg_hi) {
-                DAM_PIPE_COMMIT(0, cg + 1, nbuf);
-                if (nu > PIPE_U) {
-                    DAM_PIPE_ISSUE(1, cg + 1);
-                    DAM_PIPE_COMMIT(1, cg + 1, nbuf);
-                }
-                if (cg + 2 < cg_hi) DAM_PIPE_ISSUE(0, cg + 2);
+#define DAM_PIPE_COMMIT(S_)                                 /* set S_ -> buffer S_ (round i: chunk i, set and buffer i & 1) */ \
+    do {                                                                                                                   \
+        constexpr int boff_ = (S_) * PIPE_BUF1;                                                                            \
+        if (in_scale) {                                     /* relu(x * scale + shift) of what is inside the tensor */     \
+            const float4 sc = *reinterpret_cast<const float4*>(smem + tab_off + (s_cg[S_] * 16 + cq4) * 4);                \
+            const float4 sh = *reinterpret_cast<const float4*>(smem + tab_off + (g.C + s_cg[S_] * 16 + cq4) * 4);          \
+            _Pragma("unroll") for (int u = 0; u < PIPE_U; ++u) {                                                           \
+                float4 x = v[S_][u];                                                                                       \
+                x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y);                                                  \
+                x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);                                                  \
+                if (g.relu_in) {                                                                                           \
+                    x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);            \
+                }                                                                                                          \
+                if ((unsigned)(gcol[u] + s_sb[S_]) >= img_bytes) x = make_float4(0.f, 0.f, 0.f, 0.f);                      \
+                *reinterpret_cast<float4*>(smem + boff_ + dst[u]) = x;                                                     \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            _Pragma("unroll") for (int u = 0; u < PIPE_U; ++u)                                                             \
+                *reinterpret_cast<float4*>(smem + boff_ + dst[u]) = v[S_][u];                                              \
+        }                                                                                                                  \
+    } while (0)
+#define DAM_PIPE_ROUND_END()                                /* (1 + i): chunk i of the stream is staged, chunk i - 1 consumed */ \
+    do {                                                                                                                   \
+        DAM_PSTAMP(1, 6);                                                                                                  \
+        DAM_PIPE_BARRIER();                                                                                                \
+        DAM_PSTAMP(1, 7);                                                                                                  \
+    } while (0)
+        // (the table copy comes first: its loads would otherwise sit between the requests and the first commit, and the
+        // compiler's wait in front of every commit becomes vmcnt(0))
+        if (in_scale)
+            for (int e = ltid * 4; e < g.C; e += PIPE_LT * 4) {
+                *reinterpret_cast<float4*>(smem + tab_off + e * 4) = *reinterpret_cast<const float4*>(in_scale + e);
+                *reinterpret_cast<float4*>(smem + tab_off + (g.C + e) * 4) = *reinterpret_cast<const float4*>(in_shift + e);
             }
-            DAM_PSTAMP(1, 6);
-            DAM_PIPE_BARRIER();                     // (2 + i) chunk cg consumed, chunk cg + 1 staged
-            DAM_PSTAMP(1, 7);
+        // the slots of a stride-2 de-interleave that no item covers must read as zero: clear both buffers once (with stride 1
+        // every slot a valid pixel reads is an item); the two loader waves meet at barrier (0) before either commits
+        if (g.s != 1)
+            for (int e = ltid * 16; e < chunk_bytes; e += PIPE_LT * 16) {
+                *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(smem + PIPE_BUF1 + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        DAM_PIPE_REFILL(0);
+        __builtin_amdgcn_sched_barrier(0);          // set 0 is the OLDER request, as in every round of the loop
+        DAM_PIPE_REFILL(1);
+        __builtin_amdgcn_sched_barrier(0);
+        DAM_PSTAMP(1, 2);
+        DAM_PIPE_BARRIER();                         // (0)
+        DAM_PSTAMP(1, 3);
+        for (;;) {
+            DAM_PIPE_COMMIT(0);
+            DAM_PIPE_REFILL(0);
+            DAM_PIPE_ROUND_END();
+            if (!s_live[1]) break;
+            DAM_PIPE_COMMIT(1);
+            DAM_PIPE_REFILL(1);
+            DAM_PIPE_ROUND_END();
+            if (!s_live[0]) break;
         }
-#undef DAM_PIPE_ISSUE
+        DAM_PIPE_BARRIER();                         // the last chunk is consumed
+#undef DAM_PIPE_REFILL
 #undef DAM_PIPE_COMMIT
+#undef DAM_PIPE_ROUND_END
         return;
     }
 
     // ================= compute waves =================
-    int base_b[MB];
+    const int j = lane & 15, kq = lane >> 4;
+    // tap constants: packed-weight byte offset of (tap, chunk 0, block 0) and LDS byte offset of the tap inside the patch
+    int tapw[9], tapx[9];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        int p = p0 + wave * MW + mb * 16 + j;
-        p = p < HoWo ? p : HoWo - 1;
-        const int oh = fast_div(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
-        base_b[mb] = (((oh - oh_first) * g.s) * g.PWT + ow) * 64 + kq * 16;
+    for (int t = 0; t < 9; ++t) {
+        const int a = t / 3, b = t % 3;
+        tapw[t] = (g.wt_base + a * g.wt_sa + b * g.wt_sb) * g.nchunks * g.NBtot * 1024;
+        const int roff = g.off_h + a * g.step_h - g.r0, coff = g.off_w + b * g.step_w - g.c0;
+        const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
+        tapx[t] = (roff * g.PWT + slotoff) * 64;
     }
-    v4f acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
     const int lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp), 0, 0x7fffffff, 0x00020000);
+    v4f acc[MB][NB];
     float4 wa[3][NB], xv[3][MB];
-    // weight items in (chunk, tap a, tap b) order; the request pointer stops at the last item of this workgroup's K range
-    int wc = cg_lo, wa_i = 0, wb_i = 0;
-#ifdef DAM_PIPE_DIAG_NOW
-#define DAM_PIPE_WGATE if (wgate++ < 3)
-#else
-#define DAM_PIPE_WGATE
-#endif
-#ifdef DAM_PIPE_DIAG_NOX
-#define DAM_PIPE_XGATE if (xgate++ < 3)
-#else
-#define DAM_PIPE_XGATE
-#endif
-    int wgate = 0, xgate = 0;
-    (void)wgate; (void)xgate;
-#define DAM_PIPE_W(S_)                                                                                                     \
-    DAM_PIPE_WGATE do {                                                                                                    \
-        const int tap_ = g.wt_base + wa_i * g.wt_sa + wb_i * g.wt_sb;                                                      \
-        const int ws_ = DAM_PIPE_WOFF(((tap_ * g.nchunks + wc) * g.NBtot + nb0) * 1024);                                   \
+    int base_b[MB];
+    int unit = blockIdx.x;
+    PipeUnit cur = pipe_decode<MB, NB>(g, unit, nby, inv_wo);
+    int sbuf = 0;
+#define DAM_PIPE_W(S_, CPART_, T_)                                                                                         \
+    do {                                                                                                                   \
+        const int ws_ = DAM_PIPE_WOFF(tapw[T_] + (CPART_));                                                                \
         _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                  \
             wa[S_][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16 + nb * 1024, ws_, 0)); \
-        if (!(wc == cg_hi - 1 && wa_i == 2 && wb_i == 2)) {                                                                \
-            if (++wb_i == 3) { wb_i = 0; if (++wa_i == 3) { wa_i = 0; ++wc; } }                                            \
-        }                                                                                                                  \
     } while (0)
 #define DAM_PIPE_X(S_, T_)                                                                                                 \
-    DAM_PIPE_XGATE do {                                                                                                    \
-        constexpr int a_ = (T_) / 3, b_ = (T_) % 3;                                                                        \
-        const int roff_ = g.off_h + a_ * g.step_h - g.r0;                                                                  \
-        const int coff_ = g.off_w + b_ * g.step_w - g.c0;                                                                  \
-        const int slotoff_ = g.s == 1 ? coff_ : (coff_ & 1) * g.PWs + (coff_ >> 1);                                        \
-        const int lo_ = boff + (roff_ * g.PWT + slotoff_) * 64;                                                            \
+    do {                                                                                                                   \
+        const int lo_ = boff + tapx[T_];                                                                                   \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                  \
             xv[S_][mb] = *reinterpret_cast<const float4*>(smem + base_b[mb] + lo_);                                        \
     } while (0)
@@ -252,105 +293,183 @@ __global__ __launch_bounds__(256 + 64 * NL) void conv_pipe_kernel(const ConvGeo 
             }                                                                                                              \
     } while (0)
 #endif
-    DAM_PIPE_W(0);                                  // weights of the first two items: nothing to wait for
-    DAM_PIPE_W(1);
+    {
+        const int cfirst = cur.nb0 * 1024;
+        DAM_PIPE_W(0, cfirst, 0);                   // weights of the first two items: nothing to wait for
+        DAM_PIPE_W(1, cfirst, 1);
+    }
     DAM_PSTAMP(0, 2);
-    if (NL > 1) DAM_PIPE_BARRIER();                 // (0)
+    DAM_PIPE_BARRIER();                             // (0)
     DAM_PSTAMP(0, 3);
-    DAM_PIPE_BARRIER();                             // (1)
+    DAM_PIPE_BARRIER();                             // (1) the first chunk is staged
     DAM_PSTAMP(0, 5);
-    for (int cg = cg_lo; cg < cg_hi; ++cg) {
-        const int boff = ((cg - cg_lo) & 1) * chunk_bytes;
-        DAM_PIPE_X(0, 0);
-        DAM_PIPE_X(1, 1);
-        DAM_PIPE_W(2); DAM_PIPE_X(2, 2); DAM_PIPE_MFMA(0);
-        DAM_PIPE_W(0); DAM_PIPE_X(0, 3); DAM_PIPE_MFMA(1);
-        DAM_PIPE_W(1); DAM_PIPE_X(1, 4); DAM_PIPE_MFMA(2);
-        DAM_PIPE_W(2); DAM_PIPE_X(2, 5); DAM_PIPE_MFMA(0);
-        DAM_PIPE_W(0); DAM_PIPE_X(0, 6); DAM_PIPE_MFMA(1);
-        DAM_PIPE_W(1); DAM_PIPE_X(1, 7); DAM_PIPE_MFMA(2);
-        DAM_PIPE_W(2); DAM_PIPE_X(2, 8); DAM_PIPE_MFMA(0);
-        DAM_PIPE_W(0);                   DAM_PIPE_MFMA(1);      // weights of the next chunk's first two items
-        DAM_PIPE_W(1);                   DAM_PIPE_MFMA(2);
-        DAM_PSTAMP(0, 6);
-        DAM_PIPE_BARRIER();                         // (2 + i)
-        DAM_PSTAMP(0, 7);
+    for (;;) {
+        const bool has_next = unit + G < nunits;
+        const PipeUnit nxt = has_next ? pipe_decode<MB, NB>(g, unit + G, nby, inv_wo) : cur;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            int p = cur.p0 + wave * MW + mb * 16 + j;
+            p = p < HoWo ? p : HoWo - 1;
+            const int oh = fast_div(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
+            base_b[mb] = (((oh - cur.oh_first) * g.s) * g.PWT + ow) * 64 + kq * 16;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int cg = 0; cg < g.nchunks; ++cg) {
+            const int boff = (sbuf & 1) * PIPE_BUF1;
+            ++sbuf;
+            const int ccur = (cg * g.NBtot + cur.nb0) * 1024;
+            // the chunk behind this one in the stream (the last chunk of the last unit re-requests its own first blocks)
+            const int cnext = cg + 1 < g.nchunks ? ccur + g.NBtot * 1024 : nxt.nb0 * 1024;
+            // the order below IS the software pipeline: without the scheduling barriers the compiler sinks every request to
+            // just in front of its first use (fewer live registers) and the MFMAs wait for L2 on every item
+#define DAM_PIPE_ITEM(SW_, CP_, TW_, SX_, TX_, SM_)                                                                        \
+    do {                                                                                                                   \
+        DAM_PIPE_W(SW_, CP_, TW_);                                                                                         \
+        if ((TX_) >= 0) DAM_PIPE_X(SX_, (TX_) < 0 ? 0 : (TX_));                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        DAM_PIPE_MFMA(SM_);                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+            DAM_PIPE_X(0, 0);
+            DAM_PIPE_X(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            DAM_PIPE_ITEM(2, ccur, 2, 2, 2, 0);
+            DAM_PIPE_ITEM(0, ccur, 3, 0, 3, 1);
+            DAM_PIPE_ITEM(1, ccur, 4, 1, 4, 2);
+            DAM_PIPE_ITEM(2, ccur, 5, 2, 5, 0);
+            DAM_PIPE_ITEM(0, ccur, 6, 0, 6, 1);
+            DAM_PIPE_ITEM(1, ccur, 7, 1, 7, 2);
+            DAM_PIPE_ITEM(2, ccur, 8, 2, 8, 0);
+            DAM_PIPE_ITEM(0, cnext, 0, 0, -1, 1);
+            DAM_PIPE_ITEM(1, cnext, 1, 0, -1, 2);
+#undef DAM_PIPE_ITEM
+            DAM_PSTAMP(0, 6);
+            DAM_PIPE_BARRIER();                     // (2 + i)
+            DAM_PSTAMP(0, 7);
+        }
+
+        // ---- write the tile out (as conv_igemm_kernel): lane holds channels 4*kq..+3 of pixel j of every (mb, nb) block ----
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int p = cur.p0 + wave * MW + mb * 16 + j;
+            if (p >= HoWo) continue;
+            const int oh = fast_div(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
+            const size_t opix = ((size_t)cur.img * g.OHt + (oh * g.os + g.oo_h)) * g.OWt + (ow * g.os + g.oo_w);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int ch = (cur.nb0 + nb) * 16 + kq * 4;
+                if (ch >= g.N) continue;
+                v4f v = acc[mb][nb];
+                const size_t o = opix * g.N + ch;
+                if (bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if (res) {
+                    const float4 rv = *reinterpret_cast<const float4*>(res + o);
+                    if (res_mask) {
+                        const float4 mv = *reinterpret_cast<const float4*>(res_mask + o);
+                        v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;
+                        v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;
+                    } else {
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
+            }
+        }
+        DAM_PSTAMP(0, 8);
+        if (!has_next) break;
+        unit += G;
+        cur = nxt;
     }
 #undef DAM_PIPE_W
 #undef DAM_PIPE_X
 #undef DAM_PIPE_MFMA
-
-    // ---- epilogue (as conv_igemm_kernel): lane holds channels 4*kq..+3 of pixel j of every (mb, nb) block ----
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int p = p0 + wave * MW + mb * 16 + j;
-        if (p >= HoWo) continue;
-        const int oh = fast_div(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
-        const size_t opix = ((size_t)img * g.OHt + (oh * g.os + g.oo_h)) * g.OWt + (ow * g.os + g.oo_w);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int ch = (nb0 + nb) * 16 + kq * 4;
-            if (ch >= g.N) continue;
-            v4f v = acc[mb][nb];
-            const size_t o = opix * g.N + ch;
-            if (g.ksplit > 1) {
-                *reinterpret_cast<float4*>(splitk_ws + (size_t)ks * ((size_t)g.B * g.OHt * g.OWt * g.N) + o) =
-                    make_float4(v.x, v.y, v.z, v.w);
-                continue;
-            }
-            if (bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            }
-            if (res) {
-                const float4 rv = *reinterpret_cast<const float4*>(res + o);
-                if (res_mask) {
-                    const float4 mv = *reinterpret_cast<const float4*>(res_mask + o);
-                    v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;
-                    v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;
-                } else {
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                }
-            }
-            *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
-        }
-    }
-    DAM_PSTAMP(0, 8);
 }
 
-template <int MB, int NB, int NL>
+// resident workgroups per launch: occupancy x CUs, asked once per instance and LDS size
+template <int MB, int NB>
+int pipe_slots(size_t lds) {
+    static int cus = 0;
+    static size_t cached_lds = ~(size_t)0;
+    static int cached = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+    }
+    if (cached_lds != lds) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_pipe_kernel<MB, NB>), PIPE_THREADS,
+                                                         lds) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        cached = per_cu * cus;
+        cached_lds = lds;
+    }
+    return cached;
+}
+
+template <int MB, int NB>
 int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
-                float* Y, const float* res, const float* res_mask, float* splitk_ws, hipStream_t st) {
-    constexpr int TM = 64 * MB;
-    dim3 grid((unsigned)cdiv((int64_t)g.Ho * g.Wo, TM), (unsigned)(cdiv(g.N / 16, NB) * g.ksplit), (unsigned)g.B);
-    hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, NL>), grid, dim3(256 + 64 * NL), lds, st, g, X, reinterpret_cast<const float4*>(Wp),
-                       bias, sc, sh, Y, res, res_mask, splitk_ws);
+                float* Y, const float* res, const float* res_mask, float* workspace, hipStream_t st) {
+    const int nunits = g.tiles_m * (g.N / 16 / NB) * g.B;
+    int wgs = pipe_slots<MB, NB>(lds);
+    if (const char* e = getenv("DAM_PIPE_WGS")) wgs = atoi(e);          // diagnostic
+    if (wgs > nunits) wgs = nunits;
+    hipLaunchKernelGGL((conv_pipe_kernel<MB, NB>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
+                       reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
 
 }  // namespace
 
-// Returns DAM_ERR_UNSUPPORTED when the layer / tile does not fit this variant (the caller launches conv_igemm_kernel).
-// g: fully set up by dam_conv2d_tapgrid_f32 (tile MB x NB chosen, PR, ksplit / gps) EXCEPT the channel-group size, which is 1 here.
-int conv_pipe_try(ConvGeo g, int MB, int NB, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
-                  float* Y, const float* res, const float* res_mask, float* splitk_ws, hipStream_t st) {
+// Returns DAM_ERR_UNSUPPORTED when the layer does not fit this variant (the caller goes on to conv_igemm_kernel).
+// g: set up by dam_conv2d_tapgrid_f32 up to the tile-independent part (patch columns PWin / PWs / PWT, tap grid);
+// row_span = h_hi - h_lo of the tap grid.  The tile is chosen here: no split-K -- small tiles give this kernel its
+// workgroups, their patches are staged beside the MFMAs and cost the matrix pipe nothing.
+int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
+                  float* Y, const float* res, const float* res_mask, float* workspace, hipStream_t st) {
     if (g.nA != 3 || g.nB != 3 || g.in_nchw || g.nchunks < 2) return DAM_ERR_UNSUPPORTED;
-    const int total = g.PR * g.PWin * 4;
-    if (total > 128 * PIPE_U * PIPE_H) return DAM_ERR_UNSUPPORTED;
-    // two loader waves measured faster than one on every thick layer even where one would reach (the first chunk's staging is
-    // exposed, and two waves halve it); DAM_PIPE_NL=1 is the diagnostic switch for the comparison
-    int NL = 2;
-    if (const char* e = getenv("DAM_PIPE_NL")) NL = atoi(e) == 1 && total <= 64 * PIPE_U * PIPE_H ? 1 : 2;
-    const size_t lds = (size_t)2 * g.PR * g.PWT * 64;
-    if (lds > 64 * 1024) return DAM_ERR_UNSUPPORTED;
-    // split-K bookkeeping in chunks: gps was computed in groups of the caller's CG
-    g.gps = g.ksplit > 1 ? g.gps * g.CG : g.nchunks;
-    g.CG = 1;
-#define DAM_PIPE_CASE(M_, N_)                                                                                        \
-    if (MB == M_ && NB == N_)                                                                                        \
-        return NL == 2 ? launch_pipe<M_, N_, 2>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, splitk_ws, st)        \
-                       : launch_pipe<M_, N_, 1>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, splitk_ws, st)
+    if ((size_t)g.H * g.W * g.C * 4 >= ((size_t)1 << 30)) return DAM_ERR_UNSUPPORTED;      // offsets of the range-checked loads
+    const int64_t npix = (int64_t)g.Ho * g.Wo;
+    const int nblk = g.N / 16;
+    auto patch_rows = [&](int mb) {
+        int rows_out = (int)((64 * mb + g.Wo - 2) / g.Wo + 1);
+        if (rows_out > g.Ho) rows_out = g.Ho;
+        return (rows_out - 1) * g.s + row_span + 1;
+    };
+    auto fits = [&](int mb, int nb) {
+        const int pr = patch_rows(mb);
+        return nblk % nb == 0 && pr * g.PWin * 4 <= PIPE_LT * PIPE_U && (size_t)pr * g.PWT * 64 <= PIPE_BUF1;
+    };
+    // Tile: the largest of the <= 4-block tiles (<= 128 VGPRs: two workgroups per CU, three for the smallest) that still yields
+    // >= 384 work units, else the one with the most units.  Measured on the ResNet's thick layers (tools/pipe_ab.sh):
+    // layer3 1x4, layer4 2x2, layer5 / layer6 1x1 -- larger tiles lose more to idle CUs than they save in weight traffic.
+    static const int cand[5][2] = {{1, 4}, {2, 2}, {1, 2}, {2, 1}, {1, 1}};
+    int MB = 0, NB = 0;
+    int64_t most = -1;
+    for (int i = 0; i < 5; ++i) {
+        const int mb = cand[i][0], nb = cand[i][1];
+        if (!fits(mb, nb)) continue;
+        const int64_t units = cdiv(npix, 64 * mb) * (nblk / nb) * g.B;
+        if (units >= 384) { MB = mb; NB = nb; break; }
+        if (units > most) { most = units; MB = mb; NB = nb; }
+    }
+    if (const char* e = getenv("DAM_TILE")) {          // diagnostic: "MBxNB"
+        MB = e[0] - '0'; NB = e[2] - '0';
+        if (MB < 1 || NB < 1 || !fits(MB, NB)) return DAM_ERR_UNSUPPORTED;
+    }
+    if (!MB) return DAM_ERR_UNSUPPORTED;
+    g.PR = patch_rows(MB);
+    g.tiles_m = (int)cdiv(npix, 64 * MB);
+    g.CG = 1; g.ksplit = 1; g.gps = g.nchunks;
+    // chunk buffer 0 (padded to PIPE_BUF1), chunk buffer 1, scale / shift tables, the dump zone
+    const size_t lds = PIPE_BUF1 + (size_t)g.PR * g.PWT * 64 + (sc ? (size_t)2 * g.C * 4 : 0) + PIPE_LT * 16;
+#define DAM_PIPE_CASE(M_, N_) \
+    if (MB == M_ && NB == N_) return launch_pipe<M_, N_>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, st)
     DAM_PIPE_CASE(4, 4); DAM_PIPE_CASE(4, 2); DAM_PIPE_CASE(4, 1);
     DAM_PIPE_CASE(2, 4); DAM_PIPE_CASE(2, 2); DAM_PIPE_CASE(2, 1);
     DAM_PIPE_CASE(1, 4); DAM_PIPE_CASE(1, 2); DAM_PIPE_CASE(1, 1);
