@@ -26,7 +26,7 @@ torch.autograd.backward(boundary activation, its gradient, inputs=early paramete
 """
 import torch
 
-from . import distributed, features
+from . import distributed, features, ops
 
 
 class TrainStep:
@@ -74,6 +74,7 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss = self.model.forward_mse(self.x, self.gt)[0]
         loss.backward()
+        ops.side_stream_join(self.device)           # the weight gradients ran beside the chain
         self.loss.copy_(loss.detach())
         self.opt.gather_grads()
 
@@ -84,6 +85,7 @@ class TrainStep:
         tap = []
         loss = self.model.forward_mse(self.x, self.gt, tap=tap)[0]
         grads, dmid = distributed.backward_late(loss, self.opt.bucket_params(1), tap[0])
+        ops.side_stream_join(self.device)           # bucket 1 is complete (and the capture of this stage can end)
         self.loss.copy_(loss.detach())
         self.opt.gather_grads(1, grads=grads)
         self._stage = (tap[0], dmid)
@@ -93,6 +95,7 @@ class TrainStep:
         mid, dmid = self._stage
         self._stage = None
         distributed.backward_early(mid, dmid, self.opt.bucket_params(0))
+        ops.side_stream_join(self.device)
         self.opt.gather_grads(0)
 
     def _update(self):

@@ -75,8 +75,12 @@ class ConvSpec:
 
     def wgrad(self, x, dy, in_affine=None, out=None):
         aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
-        return ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil, in_nchw=self.in_nchw,
-                                out=out, **aff)
+        call = lambda: ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil,
+                                        in_nchw=self.in_nchw, out=out, **aff)
+        if out is None:
+            return call()
+        # written in place into the optimizer's gradient bucket: a leaf of the backward pass, off the chain's stream
+        return ops.side_stream_run(call, (x, dy) + (tuple(in_affine) if in_affine is not None else ()), x.device)
 
     def dgrad(self, dy, w, hw, **kw):
         return ops.conv2d_dgrad(dy, self.packed(w, transpose=True), self.cin, hw[0], hw[1], self.k, self.k,
@@ -99,7 +103,8 @@ class _Nhwc16Spec(ConvSpec):
 
     def wgrad(self, x, dy, in_affine=None, out=None):
         # only the real input planes are written ([cout, cin, 3, 3] = conv1.weight's shape): the zero-padded ones drop out
-        return ops.conv2d_wgrad(x, dy, self.cout, 3, 3, 1, 1, 1, out=out, c_real=self.parent.cin)
+        call = lambda: ops.conv2d_wgrad(x, dy, self.cout, 3, 3, 1, 1, 1, out=out, c_real=self.parent.cin)
+        return call() if out is None else ops.side_stream_run(call, (x, dy), x.device)
 
 
 class WeightPacker:

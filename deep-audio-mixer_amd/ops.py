@@ -3,6 +3,8 @@ torch's caching allocator, launch on the current torch stream.  No arithmetic ha
 there is no CPU fallback."""
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -182,10 +184,60 @@ def _grow(table, key, device, floats):
 
 
 def _workspace(device, floats):
-    """One grow-only scratch buffer per device (split-K slabs, weight-gradient slabs, reduction scratch of the heads /
-    mask-sum); all users are ordered on the current stream.  A buffer that has to grow is never freed: hipGraphs
-    captured earlier keep replaying into the old one (the launches recorded there were sized for it)."""
-    return _grow(_workspaces, (device.type, device.index), device, floats)
+    """One grow-only scratch buffer per device and stream role (split-K slabs, weight-gradient slabs, reduction scratch of
+    the heads / mask-sum); all users of one buffer are ordered on one stream -- launches made inside side_stream_run()
+    get their own.  A buffer that has to grow is never freed: hipGraphs captured earlier keep replaying into the old one
+    (the launches recorded there were sized for it)."""
+    key = (device.type, device.index, 'side') if _side_active else (device.type, device.index)
+    return _grow(_workspaces, key, device, floats)
+
+
+# -- side stream for the leaves of the backward pass ------------------------------------------------------------------------
+# A weight gradient is a leaf: nothing in the backward chain (BatchNorm backward -> data gradient -> next layer) waits for it,
+# so it can run on a second stream beside the chain (under hipGraph capture: a parallel branch of the graph).  MEASURED, C3
+# ResNet18 step: 5.57 ms on one stream, 5.96 ms with the weight gradients on the side stream -- the kernels do overlap
+# (profiles/r02_side_stream_trace_summary.txt) but the big ones are one-workgroup-per-CU persistent kernels with 60-150 KB
+# of LDS: two of them cannot share a CU, so each runs 1.3-1.7 x longer (conv_strip 66 -> 85-92 us, wgrad_rows 54 -> 79-96 us)
+# and the sum grows.  Hence OFF by default; DAM_SIDE_STREAM=1 turns it on for the A/B.  Only gradients written in place into a
+# caller-owned buffer (Adam's flat gradient bucket) take it: the consumer joins with side_stream_join() before it reads them.
+SIDE_STREAM = bool(os.environ.get('DAM_SIDE_STREAM'))
+_side_active = False
+_side_streams = {}
+_side_dirty = set()
+
+
+def side_stream_run(fn, reads, device):
+    """Runs fn() (kernel launches only) on the device's side stream, ordered after everything issued so far on the current
+    stream.  `reads`: the tensors those launches read -- their memory is not handed out again before the side stream is done."""
+    global _side_active
+    if not SIDE_STREAM or device.type != 'cuda' or _side_active:
+        return fn()
+    key = (device.type, device.index)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    _side_active = True
+    try:
+        with torch.cuda.stream(side):
+            out = fn()
+    finally:
+        _side_active = False
+    for t in reads:
+        if t is not None:
+            t.record_stream(side)
+    _side_dirty.add(key)
+    return out
+
+
+def side_stream_join(device=None):
+    """The current stream waits for everything side_stream_run() has issued (call before reading its results, and before
+    the end of a hipGraph capture that contains such launches)."""
+    for key in list(_side_dirty):
+        if device is not None and key != (device.type, device.index):
+            continue
+        torch.cuda.current_stream(torch.device(*key)).wait_stream(_side_streams[key])
+        _side_dirty.discard(key)
 
 
 def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, relu_in=False,

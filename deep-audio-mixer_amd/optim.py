@@ -135,6 +135,8 @@ class Adam(torch.optim.Optimizer):
     def gather_grads(self, bucket=None, grads=None):
         """One launch: every p.grad (or the given list of gradient tensors, bucket order) -> its slice of the flat
         buffer (missing grads count as zero).  bucket=None: all parameters."""
+        if self._flat.is_cuda:
+            ops.side_stream_join(self._flat.device)       # weight gradients written in place beside the backward chain
         lo, hi = (0, len(self._params)) if bucket is None else self._bucket_params[bucket]
         views, srcs = [], []
         for i in range(lo, hi):
@@ -155,6 +157,8 @@ class Adam(torch.optim.Optimizer):
     def all_reduce_grads(self, bucket=None, async_op=False):
         """Sum one bucket (default: the whole flat buffer) over the data-parallel group (RCCL all-reduce over xGMI);
         the 1/world average is folded into the Adam launch.  Returns the work handle when async_op."""
+        if self._flat.is_cuda:
+            ops.side_stream_join(self._flat.device)
         if self.world_size > 1:
             t = self._grad if bucket is None else self.bucket_view(bucket)
             if torch.distributed.get_backend(self.process_group) == 'gloo':
@@ -172,6 +176,8 @@ class Adam(torch.optim.Optimizer):
 
     def launch_update(self):
         """The Adam launch alone (gradients already in the flat buffer, already reduced)."""
+        if self._flat.is_cuda:
+            ops.side_stream_join(self._flat.device)
         h = self._hyper_tuple()
         ops.adam_l2_step(self._flat, self._grad, self._exp_avg, self._exp_avg_sq, self._step, self._derived, h[0], h[1],
                          h[2], h[3], h[4], h[5], hyper=self._hyper)
