@@ -16,6 +16,7 @@
 //     registers; waves are combined through LDS once at the end, the workgroup writes ONE partial slab;
 //   * a second kernel sums the slabs in a fixed order (deterministic, no float atomics) and writes
 //     torch's [O][I][KH][KW] layout.
+#include <cstdlib>
 #include "dam_common.h"
 #include "dam_conv_stage.h"
 
@@ -491,9 +492,19 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     const int tiles_n = nblk / TNB;
     g.tiles_k = nblk / TKB;
     const int nx = tiles_n * g.tiles_k;
-    int want = 256 / nx;                              // one workgroup per CU
-    if (want < 1) want = 1;
-    int spi = (int)cdiv(want, B);
+    const size_t rowb = (size_t)g.P4 * 64;
+    size_t lds = RW_GUARD + (size_t)TKB * NRX * rowb + (size_t)TNB * NRD * rowb + RW_TAIL;
+    if (lds < (size_t)NBLK * 1024) lds = (size_t)NBLK * 1024;
+    if (lds > 160 * 1024) return DAM_ERR_UNSUPPORTED;
+    // Strips: as many workgroups as the chip holds at once and no more (a strip that has to wait for a CU doubles the
+    // launch: 96 channels on 8 images gave 288 workgroups on 256 CUs, 63 us).  One workgroup per CU when whole strips per
+    // image fill >= 80 % of the CUs that way; otherwise size for two co-resident workgroups per CU (the register file
+    // holds two of these 8-wave workgroups, the narrow stages' rings leave the LDS for both): 432 workgroups, 50 us.
+    // Measured both ways (DAM_WGR_PERCU=1|2): where one per CU already fills the chip, two cost 15 % (more slabs, shared pipe).
+    auto strips = [&](int per_cu) { const int w = 256 * per_cu / (nx * B); return w > 0 ? w : 1; };
+    int spi = strips(1);
+    if (nx * B * spi < 205 && lds * 2 <= 160 * 1024) spi = strips(2);
+    if (const char* e = getenv("DAM_WGR_PERCU")) spi = strips(atoi(e) == 2 && lds * 2 <= 160 * 1024 ? 2 : 1);      // diagnostic
     if (spi > (int)cdiv(H, RPS)) spi = (int)cdiv(H, RPS);
     for (;; --spi) {
         g.rps = (int)cdiv(cdiv(H, spi), RPS) * RPS;
@@ -502,10 +513,6 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     }
     const int nsplit = B * g.spi;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
-    const size_t rowb = (size_t)g.P4 * 64;
-    size_t lds = RW_GUARD + (size_t)TKB * NRX * rowb + (size_t)TNB * NRD * rowb + RW_TAIL;
-    if (lds < (size_t)NBLK * 1024) lds = (size_t)NBLK * 1024;
-    if (lds > 160 * 1024) return DAM_ERR_UNSUPPORTED;
     static bool raised = false;
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV>),
