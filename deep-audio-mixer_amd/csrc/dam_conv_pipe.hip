@@ -11,13 +11,13 @@
 //   * a wave issues one instruction per ~4 clocks, so the ~40 scalar instructions and two branches of per-item bookkeeping
 //     (which packed-weight block is next?) cost the pipe ~7 clocks per MFMA.
 // Here:
-//   * a workgroup = 4 compute waves + 2 LOADER waves, and it is PERSISTENT: it walks work units (tile x output-block group x
-//     split-K slice) blockIdx.x, blockIdx.x + gridDim.x, ...  The stream of (unit, 16-channel chunk) stages flows through two
-//     alternating LDS buffers without a break at unit boundaries: while the compute waves run the last chunk of a unit and write
-//     its tile out, the loaders already stage the first chunks of the next one.  One raw barrier per chunk;
-//   * loader waves take whole 64-item segments of a patch row, so everything that changes from unit to unit is scalar (row
-//     base, row inside the tensor?); the per-lane part (column -> LDS slot, global column offset, column inside the tensor?) is
-//     computed once per launch.  A chunk costs a loader thread <= 16 loads + 16 LDS writes and ~3 vector instructions apiece;
+//   * a workgroup = 4 compute waves + 4 LOADER waves (one per SIMD), and it is PERSISTENT: it walks work units (tile x
+//     output-block group) blockIdx.x, blockIdx.x + gridDim.x, ...  The stream of (unit, 16-channel chunk) stages flows through
+//     two alternating LDS buffers without a break at unit boundaries: while the compute waves run the last chunk of a unit and
+//     write its tile out, the loaders already stage the first chunks of the next one.  One raw barrier per chunk;
+//   * a loader thread's items (LDS offset, byte offset in the image) are computed once per launch; everything that changes from
+//     unit to unit is scalar, and the padding comes from the range check of the buffer loads.  A chunk costs a loader thread
+//     <= 5 x (add, load, LDS write);
 //   * the item grid is static: item (chunk, tap T) requests the packed weights of item T+2 (of the next chunk, or of the next
 //     unit's first chunk, behind the chunk boundary) at `tap constant + chunk scalar` -- two scalar adds, no branch -- and the
 //     weight pipeline (L2 -> registers, two items ahead, three rotating operand sets) runs across chunk and unit boundaries.
@@ -36,7 +36,8 @@ constexpr int PIPE_LT = 256;                    // loader threads: 4 waves, one 
                                                 // leaves its SIMD's other waves few issue slots: two loader waves on two SIMDs held
                                                 // back the two compute waves they shared with, and the barrier made all four wait)
 constexpr int PIPE_THREADS = 256 + PIPE_LT;
-constexpr int PIPE_U = 4;                       // float4 items per loader thread and chunk (a chunk of the patch <= 1024 items)
+constexpr int PIPE_U = 5;                       // float4 items per loader thread and chunk (a chunk of the patch <= 1280 items:
+                                                // 64 pixels of 54-pixel rows -- the 64-channel stage at the reference's 216 frames)
 constexpr int PIPE_BUF1 = 32768;                // LDS byte offset of the second chunk buffer: a compile-time constant, so the
                                                 // loaders' LDS writes carry it as an immediate
 
