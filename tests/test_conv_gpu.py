@@ -247,3 +247,34 @@ def _check_in_kernel_finalize(ops, g, xd, wp, gamma, beta, buf, y, parts, want, 
         close(mean, td.mean(0), 1e-6)
         close(invstd, 1 / (td.var(0, unbiased=False) + 1e-5).sqrt(), 1e-5)
         close(shift, bt.double() - td.mean(0) * gm.double() / (td.var(0, unbiased=False) + 1e-5).sqrt(), 2e-5)
+
+
+@pytest.mark.parametrize('B,C,H,W,s', [(2, 64, 20, 33, 1), (2, 96, 11, 17, 1), (1, 128, 13, 9, 1), (2, 256, 7, 5, 1),
+                                       (2, 64, 12, 12, 2), (1, 64, 9, 54, 1)])
+def test_loader_wave_tile_kernel(ops, B, C, H, W, s, monkeypatch):
+    """conv_pipe_kernel (thick 3x3 stages): every tile of its rule, few persistent workgroups (each walks many units, so the
+    chunk stream crosses unit and image boundaries), the fused input affine, the residual epilogue -- and the tile kernel on
+    the same inputs (DAM_NO_PIPE) as a second witness."""
+    g = torch.Generator().manual_seed(C + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    want = F.conv2d(x.double(), w.double(), None, s, 1)
+    a = F.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    want_aff = F.conv2d(a, w.double(), None, s, 1)
+    wp, wpt = ops.pack_weights(w.cuda()), ops.pack_weights(w.cuda(), transpose=True)
+    xd = nhwc(x).cuda()
+    dy = torch.randn(want.shape, generator=g)
+    want_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, 1)
+    r, m = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    envs = [{}, {'DAM_PIPE_WGS': '3'}, {'DAM_TILE': '1x4'}, {'DAM_TILE': '2x2', 'DAM_PIPE_WGS': '2'}, {'DAM_TILE': '1x1'},
+            {'DAM_TILE': '2x1', 'DAM_PIPE_WGS': '5'}, {'DAM_NO_PIPE': '1'}]
+    for env in envs:
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            close(nchw(ops.conv2d_fwd(xd, wp, C, 3, 3, s, 1, 1)), want)
+            close(nchw(ops.conv2d_fwd(xd, wp, C, 3, 3, s, 1, 1, in_scale=sc.cuda(), in_shift=sh.cuda(), relu_in=True)), want_aff)
+            if s == 1:
+                dx = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, C, H, W, 3, 3, 1, 1, 1, res=nhwc(r).cuda(), res_mask=nhwc(m).cuda())
+                close(nchw(dx), want_dx + r.double() * (m > 0))
