@@ -31,7 +31,11 @@ SIGNATURES = {
                                [c_i] * 17 + [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     'dam_conv2d_wgrad_workspace_floats': (c_i64, [c_i, c_i, c_i, c_i]),
     'dam_conv2d_wgrad_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p] + [c_i] * 9 +
-                             [c_p, c_i, c_p, c_i64, c_p]),
+                             [c_p, c_i, c_p, c_i64, c_p, c_p]),
+    'dam_wgrad_queue_bytes': (c_i64, []),
+    'dam_wgrad_queue_init': (c_i, [c_p]),
+    'dam_wgrad_queue_pending': (c_i, [c_p]),
+    'dam_wgrad_queue_flush': (c_i, [c_p, c_p]),
     'dam_bn_workspace_floats': (c_i64, [c_i]),
     'dam_bn_stats_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_finalize_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),

@@ -163,64 +163,125 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
     for (int e = tid; e < NBLK * 64; e += 256) out[e] = reinterpret_cast<const float4*>(red)[e];
 }
 
-// dW[n][k][kh][kw] = sum over splits of the slabs.  Block = 8 elements x 32 split lanes: a thread adds a strided subset
-// of the splits (4 independent chains, all loads in flight), the 32 subtotals are combined by a fixed tree (deterministic).
-template <int SL>       // split lanes: 32 for many slabs (row kernel: one per workgroup), 8 for few big ones
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradGeo g, int TNB, int TKB, int TA, int TB, int n_real,
-                                                           int k_real, const float* __restrict__ partial,
-                                                           float* __restrict__ dw, int nx) {
-    constexpr int EL = 256 / SL;         // threads along the element axis, one float4 (= the 4 out-channels r of one lane) each
-    __shared__ float4 sub[SL][EL];
-    const int nblk_tile = TNB * TKB * TA * TB;
-    const int64_t per_split4 = (int64_t)nx * nblk_tile * 64;       // float4 per slab
-    const float4* p4 = reinterpret_cast<const float4*>(partial);
+// dW[n][k][kh][kw] = sum over splits of the slabs, for a BATCH of weight gradients in one launch: a reduction is 5-10 us of
+// mostly launch latency, a ResNet18 step has 20 of them and nothing but the optimizer waits for any (dam_wgrad_queue_*).
+// Block = EL elements x SL split lanes (32 x 8 for few big slabs, 8 x 32 for many): a thread adds a strided subset of the
+// splits (4 independent chains, all loads in flight), the SL subtotals are combined by a fixed tree (deterministic).
+struct ReduceJob {
+    const float* partial;
+    float* dw;
+    int nsplit, nx, TNB, TKB, TA, TB, n_real, k_real, KH, KW, tap_groups, tiles_k;
+    int sl;                  // split lanes: 32 or 8
+    int blocks;              // workgroups of the launch that work on this job
+};
+constexpr int REDUCE_MAX_JOBS = 24;
+struct ReduceBatch {
+    ReduceJob job[REDUCE_MAX_JOBS];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch batch) {
+    __shared__ float4 sub[256];
+    int ji = 0, b0 = blockIdx.x;
+    while (ji + 1 < batch.njobs && b0 >= batch.job[ji].blocks) { b0 -= batch.job[ji].blocks; ++ji; }
+    const ReduceJob& j = batch.job[ji];
+    const int SL = j.sl, EL = 256 / SL;
+    const int nblk_tile = j.TNB * j.TKB * j.TA * j.TB;
+    const int64_t per_split4 = (int64_t)j.nx * nblk_tile * 64;       // float4 per slab
+    const float4* p4 = reinterpret_cast<const float4*>(j.partial);
     const int el = threadIdx.x % EL, ys = threadIdx.x / EL;
-    for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < per_split4; e0 += (int64_t)gridDim.x * EL) {
+    for (int64_t e0 = (int64_t)b0 * EL; e0 < per_split4; e0 += (int64_t)j.blocks * EL) {
         const int64_t e = e0 + el;
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
         if (e < per_split4) {
             int y = ys;
-            for (; y + 3 * SL < g.nsplit; y += 4 * SL) {
+            for (; y + 3 * SL < j.nsplit; y += 4 * SL) {
                 const float4 a = p4[y * per_split4 + e], b = p4[(y + SL) * per_split4 + e];
                 const float4 c = p4[(y + 2 * SL) * per_split4 + e], d = p4[(y + 3 * SL) * per_split4 + e];
                 s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
                 s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w; s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
             }
-            for (; y < g.nsplit; y += SL) { const float4 a = p4[y * per_split4 + e]; s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
+            for (; y < j.nsplit; y += SL) { const float4 a = p4[y * per_split4 + e]; s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
         }
-        sub[ys][el] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
-                                  (s0.w + s1.w) + (s2.w + s3.w));
+        sub[ys * EL + el] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                                        (s0.w + s1.w) + (s2.w + s3.w));
         __syncthreads();
-#pragma unroll
         for (int stride = SL / 2; stride >= 1; stride >>= 1) {
             if (ys < stride) {
-                float4 a = sub[ys][el];
-                const float4 b = sub[ys + stride][el];
+                float4 a = sub[ys * EL + el];
+                const float4 b = sub[(ys + stride) * EL + el];
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-                sub[ys][el] = a;
+                sub[ys * EL + el] = a;
             }
             __syncthreads();
         }
         if (ys == 0 && e < per_split4) {
-            const float4 s = sub[0][el];
+            const float4 s = sub[el];
             const float sv[4] = {s.x, s.y, s.z, s.w};
             const int lane = e & 63;
             int64_t q = e >> 6;
             const int blk = q % nblk_tile;
             int xt = q / nblk_tile;
-            const int tb = blk % TB, ta = (blk / TB) % TA, kb = (blk / (TB * TA)) % TKB, nb = blk / (TB * TA * TKB);
-            const int tg = xt % g.tap_groups; xt /= g.tap_groups;
-            const int tk = xt % g.tiles_k, tn = xt / g.tiles_k;
-            const int k = (tk * TKB + kb) * 16 + (lane & 15);
-            const int kh = tg * TA + ta;
+            const int tb = blk % j.TB, ta = (blk / j.TB) % j.TA, kb = (blk / (j.TB * j.TA)) % j.TKB, nb = blk / (j.TB * j.TA * j.TKB);
+            const int tg = xt % j.tap_groups; xt /= j.tap_groups;
+            const int tk = xt % j.tiles_k, tn = xt / j.tiles_k;
+            const int k = (tk * j.TKB + kb) * 16 + (lane & 15);
+            const int kh = tg * j.TA + ta;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = (tn * TNB + nb) * 16 + (lane >> 4) * 4 + r;
-                if (n < n_real && k < k_real && kh < g.KH) dw[(((size_t)n * k_real + k) * g.KH + kh) * g.KW + tb] = sv[r];
+                const int n = (tn * j.TNB + nb) * 16 + (lane >> 4) * 4 + r;
+                if (n < j.n_real && k < j.k_real && kh < j.KH) j.dw[(((size_t)n * j.k_real + k) * j.KH + kh) * j.KW + tb] = sv[r];
             }
         }
         __syncthreads();
     }
+}
+
+// Host side of a caller-owned queue of deferred reductions (include/dam_hip.h: dam_wgrad_queue_*).
+struct WgradQueue {
+    unsigned magic;
+    ReduceBatch batch;
+};
+constexpr unsigned WGRAD_QUEUE_MAGIC = 0x57475251u;     // "WGRQ"
+
+int reduce_flush(ReduceBatch& b, hipStream_t st) {
+    if (b.njobs <= 0) return DAM_OK;
+    int blocks = 0;
+    for (int i = 0; i < b.njobs; ++i) blocks += b.job[i].blocks;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
+    b.njobs = 0;
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+// The slab reduction of one weight gradient: launched now (queue == nullptr) or appended to the caller's queue (its slabs
+// must then stay untouched until dam_wgrad_queue_flush).
+int reduce_submit(void* queue, const float* partial, float* dw, int nsplit, int nx, int TNB, int TKB, int TA, int TB, int n_real,
+                  int k_real, int KH, int KW, int tap_groups, int tiles_k, hipStream_t st) {
+    ReduceJob j;
+    j.partial = partial; j.dw = dw; j.nsplit = nsplit; j.nx = nx; j.TNB = TNB; j.TKB = TKB; j.TA = TA; j.TB = TB;
+    j.n_real = n_real; j.k_real = k_real; j.KH = KH; j.KW = KW; j.tap_groups = tap_groups; j.tiles_k = tiles_k;
+    const int64_t per_split4 = (int64_t)nx * TNB * TKB * TA * TB * 64;
+    if (nsplit >= 64) {
+        j.sl = 32;
+        j.blocks = (int)(cdiv(per_split4, 8) < 4096 ? cdiv(per_split4, 8) : 4096);
+    } else {
+        j.sl = 8;
+        j.blocks = (int)(cdiv(per_split4, 32) < 2048 ? cdiv(per_split4, 32) : 2048);
+    }
+    if (!queue) {
+        ReduceBatch one;
+        one.job[0] = j; one.njobs = 1;
+        return reduce_flush(one, st);
+    }
+    WgradQueue* q = static_cast<WgradQueue*>(queue);
+    if (q->magic != WGRAD_QUEUE_MAGIC) return DAM_ERR_BAD_ARG;
+    if (q->batch.njobs == REDUCE_MAX_JOBS) {
+        const int rc = reduce_flush(q->batch, st);
+        if (rc != DAM_OK) return rc;
+    }
+    q->batch.job[q->batch.njobs++] = j;
+    return DAM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -478,7 +539,8 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
 
 template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV = 1>
 int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* dY, const float* in_scale, const float* in_shift,
-                      int relu_in, float* partial, int64_t ws_floats, float* dw, int n_real, int k_real, hipStream_t st) {
+                      int relu_in, float* partial, int64_t ws_floats, float* dw, int n_real, int k_real, void* queue,
+                      hipStream_t st) {
     constexpr int NBLK = TNB * TKB * 9;
     RowsGeo g;
     g.B = B; g.H = H; g.W = W; g.C = C;
@@ -523,18 +585,7 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     hipLaunchKernelGGL((wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV>), dim3(nx, nsplit), dim3(RW_THREADS), lds, st, g, X, dY, in_scale,
                        in_shift, relu_in, partial);
     DAM_CHECK_LAUNCH();
-    WgradGeo rg = {};                                 // what the reduce kernel reads
-    rg.tap_groups = 1; rg.tiles_k = g.tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = 3; rg.KW = 3;
-    const int64_t per_split = (int64_t)nx * NBLK * 256;
-    if (nsplit >= 64) {
-        const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, k_real, partial, dw, nx);
-    } else {
-        const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, 3, 3, n_real, k_real, partial, dw, nx);
-    }
-    DAM_CHECK_LAUNCH();
-    return DAM_OK;
+    return reduce_submit(queue, partial, dw, nsplit, nx, TNB, TKB, 3, 3, n_real, k_real, 3, 3, 1, g.tiles_k, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -626,7 +677,8 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
 
 template <int TNB, int TKB, int KH, int KW>
 int launch_wgrad_direct(int B, int H, int W, int C, int Ho, int Wo, int N, int s, int pad, int dil, const float* X,
-                        const float* dY, float* partial, int64_t ws_floats, float* dw, int n_real, int k_real, hipStream_t st) {
+                        const float* dY, float* partial, int64_t ws_floats, float* dw, int n_real, int k_real, void* queue,
+                        hipStream_t st) {
     constexpr int NBLK = TNB * TKB * KH * KW;
     const int nblk = N / 16, nch = C / 16;
     if (nblk % TNB || nch % TKB) return DAM_ERR_UNSUPPORTED;
@@ -640,23 +692,12 @@ int launch_wgrad_direct(int B, int H, int W, int C, int Ho, int Wo, int N, int s
     hipLaunchKernelGGL((wgrad_direct_kernel<TNB, TKB, KH, KW>), dim3(nx, nsplit), dim3(256), 0, st, X, dY, rows, Ho, Wo, H, W, C,
                        N, s, pad, dil, tiles_k, partial);
     DAM_CHECK_LAUNCH();
-    WgradGeo rg = {};
-    rg.tap_groups = 1; rg.tiles_k = tiles_k; rg.tiles_n = tiles_n; rg.nsplit = nsplit; rg.KH = KH; rg.KW = KW;
-    const int64_t per_split = (int64_t)nx * NBLK * 256;
-    if (nsplit >= 64) {
-        const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, KH, KW, n_real, k_real, partial, dw, nx);
-    } else {
-        const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, rg, TNB, TKB, KH, KW, n_real, k_real, partial, dw, nx);
-    }
-    DAM_CHECK_LAUNCH();
-    return DAM_OK;
+    return reduce_submit(queue, partial, dw, nsplit, nx, TNB, TKB, KH, KW, n_real, k_real, KH, KW, 1, tiles_k, st);
 }
 
 template <int TNB, int TKB, int TA, int TB>
 int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, const float* sh, float* partial,
-                 int64_t ws_floats, float* dw, int n_real, int k_real, hipStream_t st) {
+                 int64_t ws_floats, float* dw, int n_real, int k_real, void* queue, hipStream_t st) {
     constexpr int NBLK = TNB * TKB * TA * TB;
     g.tiles_n = (int)cdiv(g.nblk, TNB);
     g.tiles_k = (int)cdiv(g.nchunks, TKB);
@@ -682,20 +723,32 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
     }
     hipLaunchKernelGGL((wgrad_kernel<TNB, TKB, TA, TB>), dim3(nx, nsplit), dim3(256), lds, st, g, X, dY, sc, sh, partial);
     DAM_CHECK_LAUNCH();
-    const int64_t per_split = (int64_t)nx * NBLK * 256;
-    if (g.nsplit >= 64) {
-        const int rb = (int)(cdiv(per_split / 4, 8) < 4096 ? cdiv(per_split / 4, 8) : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(rb), dim3(256), 0, st, g, TNB, TKB, TA, TB, n_real, k_real, partial, dw, nx);
-    } else {
-        const int rb = (int)(cdiv(per_split / 4, 32) < 2048 ? cdiv(per_split / 4, 32) : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(rb), dim3(256), 0, st, g, TNB, TKB, TA, TB, n_real, k_real, partial, dw, nx);
-    }
-    DAM_CHECK_LAUNCH();
-    return DAM_OK;
+    return reduce_submit(queue, partial, dw, g.nsplit, nx, TNB, TKB, TA, TB, n_real, k_real, g.KH, g.KW, g.tap_groups, g.tiles_k, st);
 }
 
 }  // namespace
 }  // namespace dam
+
+extern "C" int64_t dam_wgrad_queue_bytes(void) { return (int64_t)sizeof(dam::WgradQueue); }
+
+extern "C" int dam_wgrad_queue_init(void* queue) {
+    if (!queue) return DAM_ERR_BAD_ARG;
+    dam::WgradQueue* q = static_cast<dam::WgradQueue*>(queue);
+    q->magic = dam::WGRAD_QUEUE_MAGIC;
+    q->batch.njobs = 0;
+    return DAM_OK;
+}
+
+extern "C" int dam_wgrad_queue_pending(const void* queue) {
+    const dam::WgradQueue* q = static_cast<const dam::WgradQueue*>(queue);
+    return q && q->magic == dam::WGRAD_QUEUE_MAGIC ? q->batch.njobs : -1;
+}
+
+extern "C" int dam_wgrad_queue_flush(void* queue, void* stream) {
+    dam::WgradQueue* q = static_cast<dam::WgradQueue*>(queue);
+    if (!q || q->magic != dam::WGRAD_QUEUE_MAGIC) return DAM_ERR_BAD_ARG;
+    return dam::reduce_flush(q->batch, (hipStream_t)stream);
+}
 
 extern "C" int64_t dam_conv2d_wgrad_workspace_floats(int n_out, int c_in, int kh, int kw) {
     if (n_out <= 0 || c_in <= 0 || kh <= 0 || kw <= 0) return 0;
@@ -708,7 +761,7 @@ extern "C" int64_t dam_conv2d_wgrad_workspace_floats(int n_out, int c_in, int kh
 extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* in_scale,
                                     const float* in_shift, int relu_in, const float* dy, int Ho, int Wo, int n_chan,
                                     int n_out, int kh, int kw, int stride, int pad, int dil, float* dw, int c_real,
-                                    float* workspace, int64_t workspace_floats, void* stream) {
+                                    float* workspace, int64_t workspace_floats, void* reduce_queue, void* stream) {
     using namespace dam;
     if (!x || !dy || !dw || !workspace || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return DAM_ERR_BAD_ARG;
     if (c_real < 0 || c_real > C) return DAM_ERR_BAD_ARG;
@@ -720,7 +773,7 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !in_nchw && Ho == H && Wo == W && C == n_chan) {
         // row-streaming kernel for the shapes of the ResNet stages; anything else takes the tile kernel below
         int rc = DAM_ERR_UNSUPPORTED;
-#define DAM_WGR(...) launch_wgrad_rows<__VA_ARGS__>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, k_real, st)
+#define DAM_WGR(...) launch_wgrad_rows<__VA_ARGS__>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, k_real, reduce_queue, st)
         // <TN, TK, steps, planes per loader wave, pieces per plane, row parts>: the shapes of the ResNet stages at 130 frames
         // (3 s clips) and at the reference's native 216 frames
         if (C == 16) { rc = DAM_WGR(1, 1, 33, 1, 9); if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGR(1, 1, 28, 1, 14, 2); }
@@ -733,7 +786,7 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
 #define DAM_WGD(TN_, TK_, KH_, KW_) \
-    launch_wgrad_direct<TN_, TK_, KH_, KW_>(B, H, W, C, Ho, Wo, n_chan, stride, pad, dil, x, dy, workspace, workspace_floats, dw, n_out, k_real, st)
+    launch_wgrad_direct<TN_, TK_, KH_, KW_>(B, H, W, C, Ho, Wo, n_chan, stride, pad, dil, x, dy, workspace, workspace_floats, dw, n_out, k_real, reduce_queue, st)
     if (kh == 1 && kw == 1 && pad == 0 && !in_nchw && !in_scale) {
         int rc = DAM_WGD(2, 2, 1, 1);
         if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGD(2, 1, 1, 1);
@@ -780,7 +833,7 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
         if (lds_bytes(1, 1) > 72 * 1024) set_tile(128);
     }
 #define DAM_WG(TN_, TK_, TA_, TB_) \
-    return launch_wgrad<TN_, TK_, TA_, TB_>(g, x, dy, in_scale, in_shift, workspace, workspace_floats, dw, n_out, k_real, st)
+    return launch_wgrad<TN_, TK_, TA_, TB_>(g, x, dy, in_scale, in_shift, workspace, workspace_floats, dw, n_out, k_real, reduce_queue, st)
     if (kw == 3 && kh == 3) { if (small) DAM_WG(1, 1, 3, 3); else DAM_WG(2, 2, 3, 3); }
     if (kw == 1 && kh == 1) { if (small) DAM_WG(1, 1, 1, 1); else DAM_WG(2, 2, 1, 1); }
     if (kw == 5) { if (small) DAM_WG(1, 1, 1, 5); else DAM_WG(2, 2, 1, 5); }

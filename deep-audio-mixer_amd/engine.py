@@ -74,7 +74,8 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss = self.model.forward_mse(self.x, self.gt)[0]
         loss.backward()
-        ops.side_stream_join(self.device)           # the weight gradients ran beside the chain
+        ops.side_stream_join(self.device)
+        ops.wgrad_flush(self.device)                # every weight gradient's slab reduction, one launch
         self.loss.copy_(loss.detach())
         self.opt.gather_grads()
 
@@ -85,7 +86,8 @@ class TrainStep:
         tap = []
         loss = self.model.forward_mse(self.x, self.gt, tap=tap)[0]
         grads, dmid = distributed.backward_late(loss, self.opt.bucket_params(1), tap[0])
-        ops.side_stream_join(self.device)           # bucket 1 is complete (and the capture of this stage can end)
+        ops.side_stream_join(self.device)
+        ops.wgrad_flush(self.device)                # bucket 1 is complete
         self.loss.copy_(loss.detach())
         self.opt.gather_grads(1, grads=grads)
         self._stage = (tap[0], dmid)
@@ -96,6 +98,7 @@ class TrainStep:
         self._stage = None
         distributed.backward_early(mid, dmid, self.opt.bucket_params(0))
         ops.side_stream_join(self.device)
+        ops.wgrad_flush(self.device)
         self.opt.gather_grads(0)
 
     def _update(self):

@@ -75,11 +75,12 @@ class ConvSpec:
 
     def wgrad(self, x, dy, in_affine=None, out=None):
         aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
+        # out given = written in place into the optimizer's gradient bucket: a leaf of the backward pass, nothing reads it
+        # before the optimizer, so its slab reduction joins the one launch of ops.wgrad_flush()
         call = lambda: ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, self.stride, self.pad, self.dil,
-                                        in_nchw=self.in_nchw, out=out, **aff)
+                                        in_nchw=self.in_nchw, out=out, defer=out is not None, **aff)
         if out is None:
             return call()
-        # written in place into the optimizer's gradient bucket: a leaf of the backward pass, off the chain's stream
         return ops.side_stream_run(call, (x, dy) + (tuple(in_affine) if in_affine is not None else ()), x.device)
 
     def dgrad(self, dy, w, hw, **kw):
@@ -103,7 +104,7 @@ class _Nhwc16Spec(ConvSpec):
 
     def wgrad(self, x, dy, in_affine=None, out=None):
         # only the real input planes are written ([cout, cin, 3, 3] = conv1.weight's shape): the zero-padded ones drop out
-        call = lambda: ops.conv2d_wgrad(x, dy, self.cout, 3, 3, 1, 1, 1, out=out, c_real=self.parent.cin)
+        call = lambda: ops.conv2d_wgrad(x, dy, self.cout, 3, 3, 1, 1, 1, out=out, c_real=self.parent.cin, defer=out is not None)
         return call() if out is None else ops.side_stream_run(call, (x, dy), x.device)
 
 

@@ -240,10 +240,35 @@ def side_stream_join(device=None):
         _side_dirty.discard(key)
 
 
+_wgrad_queues = {}      # device -> [ctypes buffer of the library's queue, calls recorded since the last flush]
+
+
+def _wgrad_queue(device):
+    key = (device.type, device.index)
+    q = _wgrad_queues.get(key)
+    if q is None:
+        L = _lib.lib()
+        buf = ctypes.create_string_buffer(int(L.dam_wgrad_queue_bytes()))
+        _lib.check(L.dam_wgrad_queue_init(ctypes.addressof(buf)), 'dam_wgrad_queue_init')
+        q = _wgrad_queues[key] = [buf, 0]
+    return q
+
+
+def wgrad_flush(device=None):
+    """Runs the slab reductions recorded by conv2d_wgrad(..., defer=True) in one launch on the current stream; the
+    gradients are in their `out` buffers when that launch is done.  No-op when nothing is recorded."""
+    for key, q in _wgrad_queues.items():
+        if q[1] and (device is None or key == (device.type, device.index)):
+            _lib.check(_lib.lib().dam_wgrad_queue_flush(ctypes.addressof(q[0]), _lib.stream()), 'dam_wgrad_queue_flush')
+            q[1] = 0
+
+
 def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, relu_in=False,
-                 in_nchw=False, out=None, c_real=None):
+                 in_nchw=False, out=None, c_real=None, defer=False):
     """dW in torch layout [n_out, c_real or C, kh, kw] from x (NHWC, or NCHW first layer) and dy NHWC [B,Ho,Wo,n16].
-    out: where to write it (e.g. the parameter's slice of a flat gradient buffer)."""
+    out: where to write it (e.g. the parameter's slice of a flat gradient buffer).
+    defer (needs out): only the slab kernel runs now; the reduction into `out` is recorded and happens in wgrad_flush(),
+    one launch for every weight gradient of the backward pass (each deferred call keeps its own slab buffer until then)."""
     _lib.require_cuda(x, dy)
     _f32c(x, 'x'), _f32c(dy, 'dy')
     if in_nchw:
@@ -252,15 +277,24 @@ def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in
         B, H, W, C = x.shape
     _, Ho, Wo, n_chan = dy.shape
     L = _lib.lib()
-    ws = _workspace(x.device, L.dam_conv2d_wgrad_workspace_floats(n_out, C, kh, kw))
+    floats = L.dam_conv2d_wgrad_workspace_floats(n_out, C, kh, kw)
     cr = C if c_real is None else int(c_real)
     if out is None:
+        if defer:
+            raise ValueError('a deferred weight gradient needs the buffer it will be written to')
         out = torch.empty((n_out, cr, kh, kw), dtype=torch.float32, device=x.device)
     elif out.numel() != n_out * cr * kh * kw or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError('bad out tensor for the weight gradient')
+    if defer:
+        q = _wgrad_queue(x.device)
+        ws = _grow(_workspaces, (x.device.type, x.device.index, 'wgrad slabs', q[1]), x.device, floats)
+        q[1] += 1
+        queue = ctypes.addressof(q[0])
+    else:
+        ws, queue = _workspace(x.device, floats), None
     _lib.check(L.dam_conv2d_wgrad_f32(_lib.ptr(x), B, H, W, C, 1 if in_nchw else 0, _lib.ptr(in_scale),
                                       _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(dy), Ho, Wo, n_chan, n_out,
-                                      kh, kw, stride, pad, dil, _lib.ptr(out), cr, _lib.ptr(ws), ws.numel(),
+                                      kh, kw, stride, pad, dil, _lib.ptr(out), cr, _lib.ptr(ws), ws.numel(), queue,
                                       _lib.stream()), 'dam_conv2d_wgrad_f32')
     return out
 

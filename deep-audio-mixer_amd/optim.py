@@ -136,7 +136,8 @@ class Adam(torch.optim.Optimizer):
         """One launch: every p.grad (or the given list of gradient tensors, bucket order) -> its slice of the flat
         buffer (missing grads count as zero).  bucket=None: all parameters."""
         if self._flat.is_cuda:
-            ops.side_stream_join(self._flat.device)       # weight gradients written in place beside the backward chain
+            ops.side_stream_join(self._flat.device)
+            ops.wgrad_flush(self._flat.device)            # slab reductions of the in-place weight gradients
         lo, hi = (0, len(self._params)) if bucket is None else self._bucket_params[bucket]
         views, srcs = [], []
         for i in range(lo, hi):
@@ -159,6 +160,7 @@ class Adam(torch.optim.Optimizer):
         the 1/world average is folded into the Adam launch.  Returns the work handle when async_op."""
         if self._flat.is_cuda:
             ops.side_stream_join(self._flat.device)
+            ops.wgrad_flush(self._flat.device)
         if self.world_size > 1:
             t = self._grad if bucket is None else self.bucket_view(bucket)
             if torch.distributed.get_backend(self.process_group) == 'gloo':
@@ -178,6 +180,7 @@ class Adam(torch.optim.Optimizer):
         """The Adam launch alone (gradients already in the flat buffer, already reduced)."""
         if self._flat.is_cuda:
             ops.side_stream_join(self._flat.device)
+            ops.wgrad_flush(self._flat.device)
         h = self._hyper_tuple()
         ops.adam_l2_step(self._flat, self._grad, self._exp_avg, self._exp_avg_sq, self._step, self._derived, h[0], h[1],
                          h[2], h[3], h[4], h[5], hyper=self._hyper)

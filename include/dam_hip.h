@@ -154,7 +154,21 @@ int64_t dam_conv2d_wgrad_workspace_floats(int n_out, int c_in, int kh, int kw);
 int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* in_scale,
                          const float* in_shift, int relu_in, const float* dy, int Ho, int Wo, int n_chan,
                          int n_out, int kh, int kw, int stride, int pad, int dil, float* dw, int c_real,
-                         float* workspace, int64_t workspace_floats, void* stream);
+                         float* workspace, int64_t workspace_floats, void* reduce_queue, void* stream);
+
+/* Deferred slab reductions.  Nothing in loss.backward() (model_trainer.py:36) reads a weight gradient before
+ * optimizer.step() (model_trainer.py:37), and the reduction that turns a convolution's slabs into dw is a few
+ * microseconds of mostly launch latency -- twenty of them in a ResNet18 step.  With a queue,
+ * dam_conv2d_wgrad_f32 launches only the slab kernel and records the reduction; dam_wgrad_queue_flush runs every
+ * recorded reduction in ONE launch (descriptors travel as kernel arguments: nothing to upload, hipGraph-capturable).
+ *   queue : caller-owned HOST memory of dam_wgrad_queue_bytes() bytes, dam_wgrad_queue_init() once;
+ *           reduce_queue = NULL in dam_conv2d_wgrad_f32 reduces at once (dw valid when the call's work is done)
+ *   Until the flush, every queued call's `workspace` (its slabs) and `dw` must stay allocated and untouched, so
+ *   queued calls need distinct workspaces; dw is written by the flush.  A full queue flushes itself on `stream`. */
+int64_t dam_wgrad_queue_bytes(void);
+int dam_wgrad_queue_init(void* queue);
+int dam_wgrad_queue_pending(const void* queue);     /* recorded, not yet flushed; -1: not an initialised queue */
+int dam_wgrad_queue_flush(void* queue, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * BatchNorm2d on NHWC float32 [n_pixels][C], C % 16 == 0.  Replaces nn.BatchNorm2d + F.relu (+ the

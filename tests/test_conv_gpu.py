@@ -278,3 +278,27 @@ def test_loader_wave_tile_kernel(ops, B, C, H, W, s, monkeypatch):
             if s == 1:
                 dx = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, C, H, W, 3, 3, 1, 1, 1, res=nhwc(r).cuda(), res_mask=nhwc(m).cuda())
                 close(nchw(dx), want_dx + r.double() * (m > 0))
+
+
+def test_deferred_weight_gradient_reductions(ops):
+    """conv2d_wgrad(defer=True) + wgrad_flush(): one batched reduction launch, bitwise the immediate result (same slabs,
+    same summation order), for a mix of the three slab kernels (row-streaming, direct, tile)."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(2, 16, 16, 23, 130, 3, 1, 1), (2, 32, 64, 33, 34, 3, 2, 1), (1, 256, 256, 7, 5, 3, 1, 1), (2, 32, 64, 21, 14, 1, 2, 0)]
+    calls = []
+    for B, Ci, Co, H, W, k, s, p in shapes:
+        x = torch.randn(B, H, W, Ci, generator=g).cuda()
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dy = torch.randn(B, Ho, Wo, Co, generator=g).cuda()
+        calls.append((x, dy, Co, k, k, s, p, 1))
+    now = [ops.conv2d_wgrad(*c) for c in calls]
+    outs = [torch.full_like(t, float('nan')) for t in now]
+    for c, o in zip(calls, outs):
+        ops.conv2d_wgrad(*c, out=o, defer=True)
+    assert all(torch.isnan(o).all() for o in outs)          # nothing is written before the flush
+    ops.wgrad_flush()
+    for a, b in zip(now, outs):
+        assert torch.equal(a, b)
+    ops.wgrad_flush()                                       # idempotent
+    with pytest.raises(ValueError):
+        ops.conv2d_wgrad(*calls[0], defer=True)
