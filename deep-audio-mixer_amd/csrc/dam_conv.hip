@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
             }
+            if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
         }
     }
@@ -217,7 +218,8 @@ __global__ void pack_weights_multi_kernel(const long long* __restrict__ desc) {
 
 // y = sum_ks slab[ks] + bias (+ res [* (mask > 0)]) for the split-K launches of the tile kernel (fixed order: deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t n4, int Q, const float* __restrict__ bias,
-                                     const float* __restrict__ res, const float* __restrict__ res_mask, float* __restrict__ y) {
+                                     const float* __restrict__ res, const float* __restrict__ res_mask, int relu_out,
+                                     float* __restrict__ y) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
         float4 a = reinterpret_cast<const float4*>(ws)[e];
         for (int k = 1; k < ksplit; ++k) {
@@ -237,6 +239,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, i
                 a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
             }
         }
+        if (relu_out) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
         reinterpret_cast<float4*>(y)[e] = a;
     }
 }
@@ -261,7 +264,7 @@ int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
     if (g.ksplit > 1) {
         const int64_t n4 = (int64_t)g.B * g.OHt * g.OWt * g.N / 4;
         const int blocks = (int)(cdiv(n4, 256) < 2048 ? cdiv(n4, 256) : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, g.ksplit, n4, g.N / 4, bias, res, res_mask, Y);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, g.ksplit, n4, g.N / 4, bias, res, res_mask, g.relu_out, Y);
         DAM_CHECK_LAUNCH();
     }
     return DAM_OK;
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(const ConvGeo g, co
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
         }
+        if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
     }
 }
@@ -389,7 +393,7 @@ int launch_conv1x1(const ConvGeo& g, const float* X, const float* Wp, const floa
 // Generic tap-grid convolution (see dam_hip.h).  The host wrapper derives the patch geometry and picks the tile.
 extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
                                       int k_chunks, int n_out, const float* bias, const float* in_scale,
-                                      const float* in_shift, int relu_in, float* y, int OHt, int OWt, int Ho, int Wo,
+                                      const float* in_shift, int relu_in, int relu_out, float* y, int OHt, int OWt, int Ho, int Wo,
                                       int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                                       int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                                       const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
@@ -415,7 +419,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     g.os = out_stride; g.oo_h = out_off_h; g.oo_w = out_off_w; g.s = in_stride; g.nA = nA; g.nB = nB;
     g.off_h = off_h; g.step_h = step_h; g.off_w = off_w; g.step_w = step_w;
     g.wt_base = wt_base; g.wt_sa = wt_sa; g.wt_sb = wt_sb;
-    g.in_nchw = in_nchw; g.relu_in = relu_in; g.nchunks = k_chunks; g.NBtot = n_out / 16;
+    g.in_nchw = in_nchw; g.relu_in = relu_in; g.relu_out = relu_out != 0; g.nchunks = k_chunks; g.NBtot = n_out / 16;
     const int h_lo = off_h + (step_h < 0 ? (nA - 1) * step_h : 0), h_hi = off_h + (step_h > 0 ? (nA - 1) * step_h : 0);
     const int w_lo = off_w + (step_w < 0 ? (nB - 1) * step_w : 0), w_hi = off_w + (step_w > 0 ? (nB - 1) * step_w : 0);
     g.r0 = h_lo; g.c0 = w_lo;

@@ -21,6 +21,7 @@ struct ConvGeo {
     int tiles_m;             // M tiles per image
     int in_nchw;             // 1: input is [B][C][H][W] with C <= 16 planes (first layer)
     int relu_in;             // with in_scale: apply relu(x*scale+shift) while staging
+    int relu_out;            // ReLU on the result after bias / residual (eval-mode BatchNorm folded into weights + bias)
     int ksplit;              // split-K over channel groups (tile kernel): raw partial sums go to a workspace slab
     int gps;                 // channel groups per split
 };

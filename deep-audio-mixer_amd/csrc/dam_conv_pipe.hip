@@ -377,6 +377,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
                 }
+                if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
             }
         }

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     const float* ximg = X + (size_t)img * g.H * g.W * g.C;
     // fused input affine (the producer's BatchNorm + ReLU applied while the rows are written to LDS): a lane always holds
     // channel quad (lane & 3) of a cell, so its scale / shift values are two registers per chunk for the whole kernel
-    const bool has_aff = in_scale != nullptr, relu_in = g.relu_in != 0;
+    const bool has_aff = in_scale != nullptr, relu_in = g.relu_in != 0, relu_out = g.relu_out != 0;
     v4f scq[NCH], shq[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                                 v += rv;
                             }
                         }
+                        if (relu_out) v = __builtin_elementwise_max(v, (v4f){0.f, 0.f, 0.f, 0.f});
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), yrsrc, voff + nb * 64, 0, 0);
 #ifndef DAM_STAMPS
                         if (stats) {

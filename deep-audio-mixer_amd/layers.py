@@ -155,6 +155,54 @@ def _hw(x, in_nchw):
     return (x.shape[2], x.shape[3]) if in_nchw else (x.shape[1], x.shape[2])
 
 
+class FoldedConvBn:
+    """Inference form of conv -> BatchNorm2d(eval): the running statistics are constants, so the BatchNorm's scale goes
+    into the weights and its shift (plus the scaled convolution bias) into the bias of ONE convolution launch whose epilogue
+    also adds the shortcut and applies the ReLU (`ops.conv2d_fwd(res=, relu_out=)`) -- no BatchNorm kernel, no weight
+    re-packing per forward.  Built lazily, rebuilt when a tensor it was folded from has changed (tensor version counters)."""
+
+    def __init__(self, spec, conv, bn):
+        self.spec, self.conv, self.bn = spec, conv, bn
+        self._key = self.wp = self.bias = None
+
+    def foldable(self):
+        return self.bn.running_mean is not None and self.bn.running_var is not None
+
+    def _tensors(self):
+        bn, conv = self.bn, self.conv
+        return [t for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None]
+
+    def get(self):
+        key = tuple((t.data_ptr(), t._version) for t in self._tensors())
+        if key != self._key:
+            bn, conv = self.bn, self.conv
+            with torch.no_grad():
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                shift = bn.bias - bn.running_mean * scale
+                if conv.bias is not None:
+                    shift = shift + conv.bias * scale
+                n16 = (self.spec.cout + 15) // 16 * 16
+                bias = torch.zeros(n16, dtype=torch.float32, device=scale.device)
+                bias[:self.spec.cout] = shift
+                self.wp = ops.pack_weights(conv.weight * scale.view(-1, 1, 1, 1))
+                self.bias = bias
+            self._key = key
+        return self.wp, self.bias
+
+    def fwd(self, x, res=None, relu=True):
+        wp, bias = self.get()
+        sp = self.spec
+        if sp.nhwc16 is not None:            # the stem: NCHW planes re-laid once, then the 16-channel kernels
+            sp, x = sp.nhwc16, ops.nchw_to_nhwc16(x)
+        return ops.conv2d_fwd(x, wp, sp.cout, sp.k, sp.k, sp.stride, sp.pad, sp.dil, bias=bias, in_nchw=sp.in_nchw,
+                              res=res, relu_out=relu)
+
+
+def inference_mode(module):
+    """True when a conv-BatchNorm block may take its folded one-launch form: eval mode and no autograd graph wanted."""
+    return not module.training and not torch.is_grad_enabled()
+
+
 class ConvBnReluFn(torch.autograd.Function):
     """a = relu(bn(conv(x) [+ bias]))  -- ResNet stem (models/model_resnet.py:97) and
     ConvBlock2d (models/model_scalar_1s.py:179-190 without the dropout)."""
@@ -319,7 +367,20 @@ class BasicBlock(nn.Module):
         self.spec2 = ConvSpec(out_channels, out_channels, 3, 1, 1)
         self.spec_sc = ConvSpec(in_channels, out_channels, 1, stride, 0) if len(self.shortcut) else None
 
+    def _folded(self):
+        f = getattr(self, '_fold', None)
+        if f is None:
+            f = self._fold = (FoldedConvBn(self.spec1, self.conv1, self.bn1), FoldedConvBn(self.spec2, self.conv2, self.bn2),
+                              FoldedConvBn(self.spec_sc, self.shortcut[0], self.shortcut[1]) if self.spec_sc is not None else None)
+        return f
+
     def forward(self, x):
+        if inference_mode(self):
+            f1, f2, fs = self._folded()
+            if f1.foldable() and f2.foldable() and (fs is None or fs.foldable()):
+                # relu(bn1(conv1 x)); shortcut; relu(bn2(conv2 .) + shortcut): three launches (two without a shortcut conv)
+                a1 = f1.fwd(x)
+                return f2.fwd(a1, res=x if fs is None else fs.fwd(x, relu=False))
         if self.spec_sc is not None:
             sc, sbn = self.shortcut[0], self.shortcut[1]
             return BasicBlockFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
@@ -343,6 +404,12 @@ class ConvBlock2d(nn.Module):
         self.spec = ConvSpec(in_channels, out_channels, kernel_size, stride, 0, dilation, in_nchw=in_nchw)
 
     def forward(self, x):
+        if inference_mode(self):
+            f = getattr(self, '_fold', None)
+            if f is None:
+                f = self._fold = FoldedConvBn(self.spec, self.conv, self.batch_norm)
+            if f.foldable():
+                return f.fwd(x)                  # dropout is the identity in eval mode
         out = ConvBnReluFn.apply(x, self.conv.weight, self.conv.bias, self.batch_norm.weight, self.batch_norm.bias,
                                  self.spec, self.batch_norm, self.training)
         if self.training and self.dropout:

@@ -8,7 +8,7 @@ at :73, i.e. a 1025x216 input).
 import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401  (kept for notebook parity: the reference module exposes F)
 
-from ..layers import BasicBlock, ConvBnReluFn, ConvSpec, MixingNet
+from ..layers import BasicBlock, ConvBnReluFn, ConvSpec, FoldedConvBn, MixingNet, inference_mode
 from ..ops import conv_out_size
 
 __all__ = ['BasicBlock', 'ResNet', 'ResNet18']
@@ -54,8 +54,14 @@ class ResNet(MixingNet):
     DDP_BOUNDARY = 4      # layer5, layer6 and the heads hold 85 % of the parameters and come first in backward
 
     def trunk(self, x, tap=None):
-        out = ConvBnReluFn.apply(x, self.conv1.weight, None, self.bn1.weight, self.bn1.bias, self._stem, self.bn1,
-                                 self.training)
+        stem = getattr(self, '_stem_fold', None)
+        if stem is None:
+            stem = self._stem_fold = FoldedConvBn(self._stem, self.conv1, self.bn1)
+        if inference_mode(self) and stem.foldable():
+            out = stem.fwd(x)
+        else:
+            out = ConvBnReluFn.apply(x, self.conv1.weight, None, self.bn1.weight, self.bn1.bias, self._stem, self.bn1,
+                                     self.training)
         for i in range(1, 7):
             out = getattr(self, 'layer%d' % i)(out)
             if tap is not None and i == self.DDP_BOUNDARY:

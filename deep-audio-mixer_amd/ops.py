@@ -73,14 +73,15 @@ def _bn_fin_struct(bn, out4, device):
 
 def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shift, relu_in, y, OHt, OWt, Ho, Wo,
              out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
-             res=None, res_mask=None, bn_partial=None, bn_fin=None):
+             res=None, res_mask=None, bn_partial=None, bn_fin=None, relu_out=False):
     parts = ctypes.c_int(0)
     # split-K scratch: the host code only splits when no tile shape gives 400 workgroups, i.e. for outputs below
     # 400 * 64 px * 64 ch = 1.64 M floats, and then at most 8 ways (dam_conv.hip) -- never more than 13.1 M floats
     ws = _workspace(y.device, min(8 * y.numel(), 8 * 400 * 64 * 64))
     st = _lib.lib().dam_conv2d_tapgrid_f32(
         _lib.ptr(x), B, H, W, C, 1 if in_nchw else 0, _lib.ptr(wp), k_chunks, n_out, _lib.ptr(bias),
-        _lib.ptr(in_scale), _lib.ptr(in_shift), 1 if relu_in else 0, _lib.ptr(y), OHt, OWt, Ho, Wo, out_stride,
+        _lib.ptr(in_scale), _lib.ptr(in_shift), 1 if relu_in else 0, 1 if relu_out else 0, _lib.ptr(y), OHt, OWt, Ho, Wo,
+        out_stride,
         oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb, _lib.ptr(res),
         _lib.ptr(res_mask), _lib.ptr(bn_partial), ctypes.byref(parts) if bn_partial is not None else None,
         ctypes.byref(bn_fin) if bn_fin is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
@@ -89,11 +90,13 @@ def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shi
 
 
 def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale=None, in_shift=None,
-               relu_in=False, in_nchw=False, bn_partial=None, bn=None):
+               relu_in=False, in_nchw=False, bn_partial=None, bn=None, res=None, relu_out=False):
     """x: NHWC [B,H,W,C] (C % 16 == 0), or NCHW [B,C,H,W] with C <= 16 if in_nchw.  Returns NHWC
-    [B,Ho,Wo,n_out] with n_out rounded up to a multiple of 16 (extra channels are zero)."""
+    [B,Ho,Wo,n_out] with n_out rounded up to a multiple of 16 (extra channels are zero).
+    res (same shape as the result) is added, relu_out applies max(., 0) last: with an eval-mode BatchNorm folded into
+    the weights and `bias`, one launch is relu(bn(conv(x)) [+ shortcut])."""
     _lib.require_cuda(x, wp)
-    _f32c(x, 'x'), _f32c(bias, 'bias'), _f32c(in_scale, 'in_scale'), _f32c(in_shift, 'in_shift')
+    _f32c(x, 'x'), _f32c(bias, 'bias'), _f32c(in_scale, 'in_scale'), _f32c(in_shift, 'in_shift'), _f32c(res, 'res')
     if in_nchw:
         B, C, H, W = x.shape
         k_chunks = 1
@@ -111,7 +114,8 @@ def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale
         out4 = torch.empty((4, n16), dtype=torch.float32, device=x.device)
         fin = _bn_fin_struct(bn, out4, x.device)
     parts = _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n16, bias, in_scale, in_shift, relu_in, y, Ho, Wo, Ho, Wo,
-                     1, 0, 0, stride, kh, kw, -pad, dil, -pad, dil, 0, kw, 1, bn_partial=bn_partial, bn_fin=fin)
+                     1, 0, 0, stride, kh, kw, -pad, dil, -pad, dil, 0, kw, 1, res=res, bn_partial=bn_partial, bn_fin=fin,
+                     relu_out=relu_out)
     if bn is not None and bn_partial is not None:
         if parts > 0 and fin is None:      # two-launch form: merge the records with the finalize kernel
             out4 = bn_finalize(bn_partial, parts, *bn)

@@ -114,11 +114,13 @@ int dam_conv_pack_weights_f32(const float* w_oihw, int O, int I, int KH, int KW,
  * {w_oihw pointer, packed pointer, O, I, KH, KW, transpose, packed float count}; max_total = largest count. */
 int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int64_t max_total, void* stream);
 
-/* y[b, oh*out_stride+out_off_h, ow*out_stride+out_off_w, :] (+= res [* (res_mask > 0)]) =
+/* y[b, oh*out_stride+out_off_h, ow*out_stride+out_off_w, :] = g( res [* (res_mask > 0)] +
  *     bias + sum_{a<nA, b<nB, k} Wp[wt_base + a*wt_sa + b*wt_sb][k][:] *
  *            f(x[b, oh*in_stride + off_h + a*step_h, ow*in_stride + off_w + b*step_w, k])
  * for oh < Ho, ow < Wo, with x = 0 outside [0,H)x[0,W) and f(v) = v, or v*in_scale[k]+in_shift[k]
- * (then ReLU if relu_in) -- the producer's BatchNorm apply fused into the load.
+ * (then ReLU if relu_in) -- the producer's BatchNorm apply fused into the load -- and g(v) = v, or max(v, 0) if relu_out:
+ * with an eval-mode BatchNorm folded into the weights (scale) and `bias` (shift), one launch is the reference's
+ * relu(bn(conv(x)) [+ shortcut]) (models/model_resnet.py:23-28,97).
  *   x : NHWC [B][H][W][C] (C % 16 == 0, k_chunks == C/16), or with in_nchw=1 the reference's
  *       [B][C][H][W] planes with C <= 16 (first layer, k_chunks == 1)
  *   y : NHWC [B][OHt][OWt][n_out], n_out % 16 == 0;  res/res_mask (optional): same shape as y
@@ -134,7 +136,7 @@ int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int6
  * 8 * B*OHt*OWt*n_out floats are used, fewer if less is given); partial slabs are summed in a fixed order. */
 int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
                            int k_chunks, int n_out, const float* bias, const float* in_scale,
-                           const float* in_shift, int relu_in, float* y, int OHt, int OWt, int Ho, int Wo,
+                           const float* in_shift, int relu_in, int relu_out, float* y, int OHt, int OWt, int Ho, int Wo,
                            int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                            int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                            const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,

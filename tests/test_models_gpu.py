@@ -230,3 +230,36 @@ def test_dropout_kernel_statistics(dam_lib):
     m.eval()
     a, b = m(xin)[0], m(xin)[0]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('name,shape', [('resnet18', (2, 4, 257, 64)), ('scalar1s', (2, 4, 257, 87))])
+def test_folded_inference_path(dam, name, shape):
+    """eval + no_grad takes the folded form (BatchNorm scale in the weights, shift + shortcut + ReLU in the convolution
+    epilogue); with autograd enabled the same eval forward runs the BatchNorm kernels.  Both must agree, and the folded
+    images must follow an in-place parameter update."""
+    ctor, _ = dam[name]
+    torch.manual_seed(5)
+    model = no_dropout(ctor(n_stems=shape[1], input_shape=shape[2:])).cuda()
+    x, gt = model_input(*shape, seed=9)
+    xc = torch.from_numpy(x).cuda()
+    model.train()
+    for _ in range(2):                                   # non-trivial running statistics
+        model(xc)
+    model.eval()
+
+    def both():
+        with torch.no_grad():
+            folded = torch.cat(model(xc)[1], 1)
+        plain = torch.cat(model(xc)[1], 1).detach()      # autograd on: the unfolded eval path
+        return folded, plain
+    folded, plain = both()
+    assert rel_err(folded.cpu().numpy(), plain.cpu().numpy()) <= 2e-5
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.add_(0.01)
+    folded2, plain2 = both()
+    assert rel_err(folded2.cpu().numpy(), plain2.cpu().numpy()) <= 2e-5
+    assert rel_err(folded2.cpu().numpy(), folded.cpu().numpy()) > 1e-4      # the update was seen
