@@ -419,6 +419,7 @@ int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
     const int nunits = g.tiles_m * (g.N / 16 / NB) * g.B;
     int wgs = pipe_slots<MB, NB>(lds);
     if (const char* e = getenv("DAM_PIPE_WGS")) wgs = atoi(e);          // diagnostic
+    if (wgs < 1) wgs = 1;
     if (wgs > nunits) wgs = nunits;
     hipLaunchKernelGGL((conv_pipe_kernel<MB, NB>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
                        reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace);
