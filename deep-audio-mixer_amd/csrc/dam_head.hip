@@ -126,16 +126,18 @@ __global__ void head_bwd_fc_kernel(const float* __restrict__ dg, const float* __
     }
 }
 
-// partial[blk][s][c] = sum over the block's (b,p) range of e[b][s][p] * trunk[b][p][c]; last column: sum e
+// partial[blk][s][c] = sum over the block's (b,p) range of e[b][s][p] * trunk[b][p][c];  partial_b[blk][s] = sum of e
+// (the conv-bias gradient: the same e values, already in registers)
 __global__ void head_bwd_cw_partial_kernel(const float* __restrict__ e, const float* __restrict__ trunk, int B, int P,
-                                           int C, int S, int Q, int R, int64_t ppb, float* __restrict__ partial) {
+                                           int C, int S, int Q, int R, int64_t ppb, float* __restrict__ partial,
+                                           float* __restrict__ partial_b) {
     extern __shared__ float sm[];    // [R][S][C]
     const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
     const int64_t BP = (int64_t)B * P;
     const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < BP) ? lo + ppb : BP;
-    float acc[MAX_STEMS][4];
+    float acc[MAX_STEMS][4], esum[MAX_STEMS];
 #pragma unroll
-    for (int s = 0; s < MAX_STEMS; ++s) { acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0.f; }
+    for (int s = 0; s < MAX_STEMS; ++s) { acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0.f; esum[s] = 0.f; }
     for (int64_t bp = lo + pr; bp < hi; bp += R) {
         const int b = (int)(bp / P), p = (int)(bp - (int64_t)b * P);
         const float4 v = *reinterpret_cast<const float4*>(trunk + bp * C + cq * 4);
@@ -143,6 +145,7 @@ __global__ void head_bwd_cw_partial_kernel(const float* __restrict__ e, const fl
         for (int s = 0; s < MAX_STEMS; ++s) {
             if (s < S) {
                 const float ev = e[((size_t)b * S + s) * P + p];
+                esum[s] += ev;
                 acc[s][0] = fmaf(ev, v.x, acc[s][0]); acc[s][1] = fmaf(ev, v.y, acc[s][1]);
                 acc[s][2] = fmaf(ev, v.z, acc[s][2]); acc[s][3] = fmaf(ev, v.w, acc[s][3]);
             }
@@ -163,28 +166,42 @@ __global__ void head_bwd_cw_partial_kernel(const float* __restrict__ e, const fl
                 partial[((size_t)blockIdx.x * S + s) * C + cq * 4 + i] = a;
             }
     }
-}
-__global__ void head_bwd_cw_finalize_kernel(const float* __restrict__ partial, int parts, int C, int S,
-                                            float* __restrict__ dcw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < S * C) {
-        double a = 0;
-        for (int p = 0; p < parts; ++p) a += partial[(size_t)p * S * C + i];
-        dcw[i] = (float)a;
+    __syncthreads();                                   // second use of sm: [R][S] sums of e (rows pr, column quad 0 only)
+    if (cq == 0)
+        for (int s = 0; s < S; ++s) sm[pr * S + s] = esum[s];
+    __syncthreads();
+    if (threadIdx.x < S) {
+        float a = 0.f;
+        for (int r = 0; r < R; ++r) a += sm[r * S + threadIdx.x];
+        partial_b[(size_t)blockIdx.x * S + threadIdx.x] = a;
     }
 }
-// dcb[s] = sum_{b,p} e[b][s][p];  grid S
-__global__ __launch_bounds__(256) void head_bwd_cb_kernel(const float* __restrict__ e, int B, int P, int S,
-                                                          float* __restrict__ dcb) {
-    __shared__ float red[4];
-    const int s = blockIdx.x;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* er = e + ((size_t)b * S + s) * P;
-        for (int p = threadIdx.x; p < P; p += 256) a += er[p];
+// dcw[i] = sum over the blocks' records (i < S*C), dcb[s] likewise (i = S*C + s).  Block = 8 outputs x 32 record lanes: a lane
+// adds every 32nd record in double, the 32 subtotals are combined by a fixed tree (deterministic).  (One thread per
+// output walking all ~1000 records took 134-258 us on the scalar models.)
+__global__ __launch_bounds__(256) void head_bwd_cw_finalize_kernel(const float* __restrict__ partial,
+                                                                   const float* __restrict__ partial_b, int parts, int C, int S,
+                                                                   float* __restrict__ dcw, float* __restrict__ dcb) {
+    __shared__ double sub[32][8];
+    const int el = threadIdx.x & 7, ys = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + el, n = S * C;
+    double a = 0;
+    if (i < n) {
+        for (int p = ys; p < parts; p += 32) a += (double)partial[(size_t)p * n + i];
+    } else if (i < n + S) {
+        for (int p = ys; p < parts; p += 32) a += (double)partial_b[(size_t)p * S + (i - n)];
     }
-    a = block_sum(a, red);
-    if (threadIdx.x == 0) dcb[s] = a;
+    sub[ys][el] = a;
+    __syncthreads();
+#pragma unroll
+    for (int stride = 16; stride >= 1; stride >>= 1) {
+        if (ys < stride) sub[ys][el] += sub[ys + stride][el];
+        __syncthreads();
+    }
+    if (ys == 0) {
+        if (i < n) dcw[i] = (float)sub[0][el];
+        else if (i < n + S) dcb[i - n] = (float)sub[0][el];
+    }
 }
 
 // masked[b][i] = sum_s g[b][s] * x[b][s][i]
@@ -281,7 +298,7 @@ extern "C" int dam_heads_fwd_f32(const float* trunk, int B, int P, int C, int S,
 }
 
 extern "C" int64_t dam_heads_bwd_workspace_floats(int B, int P, int C, int S) {
-    return (int64_t)B * S * P + (int64_t)1024 * S * C;
+    return (int64_t)B * S * P + (int64_t)1024 * S * C + (int64_t)1024 * S;     // e, weight-grad records, bias-grad records
 }
 
 extern "C" int dam_heads_bwd_f32(const float* dgains, const float* h, const float* trunk, int B, int P, int C, int S,
@@ -293,6 +310,7 @@ extern "C" int dam_heads_bwd_f32(const float* dgains, const float* h, const floa
     hipStream_t st = (hipStream_t)stream;
     float* e = workspace;
     float* partial = workspace + (size_t)B * S * P;
+    float* partial_b = partial + (size_t)1024 * S * C;
     const int gx = (int)(cdiv(P, 4) < 1024 ? cdiv(P, 4) : 1024);
     hipLaunchKernelGGL(head_bwd_pixel_kernel, dim3(gx, B), dim3(256), (size_t)S * C * sizeof(float), st, dgains, h, P, C, S,
                        conv_w, fc_w, e, dtrunk);
@@ -307,12 +325,10 @@ extern "C" int dam_heads_bwd_f32(const float* dgains, const float* h, const floa
     const int64_t ppb = cdiv(BP, parts);
     parts = cdiv(BP, ppb);
     hipLaunchKernelGGL(head_bwd_cw_partial_kernel, dim3((unsigned)parts), dim3(Q * R), (size_t)R * S * C * sizeof(float), st, e,
-                       trunk, B, P, C, S, Q, R, ppb, partial);
+                       trunk, B, P, C, S, Q, R, ppb, partial, partial_b);
     DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_bwd_cw_finalize_kernel, dim3((unsigned)cdiv((int64_t)S * C, 256)), dim3(256), 0, st, partial, (int)parts,
-                       C, S, dconv_w);
-    DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_bwd_cb_kernel, dim3(S), dim3(256), 0, st, e, B, P, S, dconv_b);
+    hipLaunchKernelGGL(head_bwd_cw_finalize_kernel, dim3((unsigned)cdiv((int64_t)S * C + S, 8)), dim3(256), 0, st, partial, partial_b,
+                       (int)parts, C, S, dconv_w, dconv_b);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
