@@ -281,7 +281,11 @@ class BasicBlockFn(torch.autograd.Function):
         s_w1, s_g1, s_b1, s_w2, s_g2, s_b2, s_ws, s_gs, s_bs = ctx.slots
         keep = lambda grad, slot: None if slot is not None else grad      # slotted gradients are already in place
         wview = lambda slot, w: None if slot is None else slot.view(w.shape)
-        dc2, dg2, db2 = ops.bn_backward(dout, out, c2, g2, m2, i2, tr, dgamma=s_g2, dbeta=s_b2)
+        if ctx.has_sc:      # bn2 and the shortcut's BatchNorm see the same dout through the same mask: one pass for both
+            (dc2, dg2, db2), (dcs, dgs, dbs) = ops.bn_backward_pair(dout, out, (c2, g2, m2, i2, s_g2, s_b2),
+                                                                    (cs, gsc, ms, is_, s_gs, s_bs), tr)
+        else:
+            dc2, dg2, db2 = ops.bn_backward(dout, out, c2, g2, m2, i2, tr, dgamma=s_g2, dbeta=s_b2)
         dw2 = blk.spec2.wgrad(c1, dc2, in_affine=(sc1, sh1), out=wview(s_w2, w2))
         da1 = blk.spec2.dgrad(dc2, w2, (c1.shape[1], c1.shape[2]))
         dc1, dg1, db1 = ops.bn_backward(da1, None, c1, g1, m1, i1, tr, mask_affine=(sc1, sh1),   # mask = (bn1(c1) > 0)
@@ -289,7 +293,6 @@ class BasicBlockFn(torch.autograd.Function):
         dw1 = blk.spec1.wgrad(x, dc1, out=wview(s_w1, w1))
         first = (keep(dw1, s_w1), keep(dg1, s_g1), keep(db1, s_b1), keep(dw2, s_w2), keep(dg2, s_g2), keep(db2, s_b2))
         if ctx.has_sc:
-            dcs, dgs, dbs = ops.bn_backward(dout, out, cs, gsc, ms, is_, tr, dgamma=s_gs, dbeta=s_bs)
             dws = blk.spec_sc.wgrad(x, dcs, out=wview(s_ws, wsc))
             dx = blk.spec1.dgrad(dc1, w1, hw)
             blk.spec_sc.dgrad(dcs, wsc, hw, accumulate_into=dx)

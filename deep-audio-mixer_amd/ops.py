@@ -372,6 +372,30 @@ def bn_apply(x, scale, shift, relu=True, res=None, res_scale=None, res_shift=Non
     return y
 
 
+def bn_backward_pair(dy, y_mask, a, b, training=True):
+    """bn_backward for two BatchNorms fed by the same dy through the same ReLU mask (a residual block's bn2 and its shortcut
+    BatchNorm): three launches instead of six, dy / y_mask read once per pass.  a, b = (x, gamma, save_mean, save_invstd,
+    dgamma or None, dbeta or None).  Returns ((dx, dgamma, dbeta), (dx, dgamma, dbeta)), bitwise equal to two bn_backward calls."""
+    _lib.require_cuda(dy, y_mask, a[0], b[0])
+    C = a[0].shape[-1]
+    if b[0].shape != a[0].shape or dy.shape != a[0].shape:
+        raise ValueError('the two BatchNorms of a pair see the same shape')
+    outs = []
+    for x, gamma, mean, invstd, dgamma, dbeta in (a, b):
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
+        outs.append((dx, dgamma, dbeta))
+    L = _lib.lib()
+    ws = _workspace(dy.device, L.dam_bn_pair_workspace_floats(C))
+    args = []
+    for (x, gamma, mean, invstd, _, _), (dx, dgamma, dbeta) in zip((a, b), outs):
+        args += [_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta)]
+    _lib.check(L.dam_bn_backward_pair_f32(_lib.ptr(dy), _lib.ptr(y_mask), dy.numel() // C, C, 1 if training else 0, *args,
+                                          _lib.ptr(ws), _lib.stream()), 'dam_bn_backward_pair_f32')
+    return outs[0], outs[1]
+
+
 def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mask_affine=None, dgamma=None, dbeta=None):
     """Returns (dx, dgamma, dbeta) for y = [relu](bn(x) + ...).  The ReLU mask comes from y_mask (the saved output), or --
     for a plain relu(bn(x)) -- from mask_affine=(scale, shift), the forward's fused affine (the saved output is not read),

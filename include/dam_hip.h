@@ -228,6 +228,17 @@ int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, in
                         const float* mask_scale, const float* mask_shift, float* dx, float* dgamma, float* dbeta,
                         float* workspace, uint32_t* counter, void* stream);
 
+/* The same for TWO BatchNorms that share dy and y_mask -- a residual block's bn2 and the BatchNorm of its shortcut
+ * convolution, both fed by the gradient of relu(bn2(..) + bn_sc(..)) (models/model_resnet.py:23-28): dy and the mask are
+ * read once per pass instead of twice, three launches instead of six; bitwise the results of two dam_bn_backward_f32 calls.
+ * workspace: dam_bn_pair_workspace_floats(C) floats. */
+int64_t dam_bn_pair_workspace_floats(int C);
+int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, int64_t n_pixels, int C, int training,
+                             const float* x_a, const float* gamma_a, const float* mean_a, const float* invstd_a,
+                             float* dx_a, float* dgamma_a, float* dbeta_a,
+                             const float* x_b, const float* gamma_b, const float* mean_b, const float* invstd_b,
+                             float* dx_b, float* dgamma_b, float* dbeta_b, float* workspace, void* stream);
+
 /* out[c] = sum_p x[p][c] for c < n_real (gradient of a convolution bias, models/model_scalar_1s.py:167). */
 int dam_channel_sum_f32(const float* x, int64_t n_pixels, int C, int n_real, float* out, float* workspace,
                         void* stream);

@@ -53,3 +53,20 @@ def test_bn_relu_forward_backward_mask_modes(ops, B, H, W, C):
     dx0, _, _ = ops.bn_backward(dy.cuda(), None, xd, gamma.cuda(), sm, si, True)
     close(dx0, xr2.grad, 1e-4)
 
+
+
+def test_backward_pair_is_bitwise_two_single_calls(ops):
+    """dam_bn_backward_pair_f32 (a block's bn2 + its shortcut BatchNorm: shared dy and mask) against two single calls."""
+    g = torch.Generator().manual_seed(4)
+    for shape in [(3, 37, 29, 32), (2, 9, 5, 256), (2, 65, 33, 64)]:
+        C = shape[-1]
+        dy, y = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+        xs = [torch.randn(shape, generator=g).cuda() for _ in range(2)]
+        par = [(torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda(), torch.rand(C, generator=g).cuda() + 0.5)
+               for _ in range(2)]
+        for training in (True, False):
+            single = [ops.bn_backward(dy, y, x, gm, mu, iv, training) for x, (gm, mu, iv) in zip(xs, par)]
+            pair = ops.bn_backward_pair(dy, y, (xs[0], *par[0], None, None), (xs[1], *par[1], None, None), training)
+            for s, p in zip(single, pair):
+                for a, b in zip(s, p):
+                    assert torch.equal(a, b)
