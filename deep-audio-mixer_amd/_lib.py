@@ -41,6 +41,7 @@ SIGNATURES = {
     'dam_bn_finalize_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_eval_affine_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_apply_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'dam_bn_stats_pair_f32': (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
     'dam_bn_pair_workspace_floats': (c_i64, [c_i]),
     'dam_bn_backward_pair_f32': (c_i, [c_p, c_p, c_i64, c_i, c_i] + [c_p] * 16),
     'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -39,9 +39,12 @@ inline BnLaunch bn_plan(int64_t P, int C) {
     return l;
 }
 
+// gridDim.y == 2: a second tensor of the same shape (x2 -> partial2) in the same launch (dam_bn_stats_pair_f32).
 __global__ void bn_stats_partial_kernel(const float* __restrict__ x, int64_t P, int C, int Q, int R, int64_t ppb,
-                                        float* __restrict__ partial /* [parts][C][3] */, const BnFinArgs fin) {
+                                        float* __restrict__ partial /* [parts][C][3] */, const BnFinArgs fin,
+                                        const float* __restrict__ x2, float* __restrict__ partial2) {
     extern __shared__ __attribute__((aligned(16))) float sm[];    // [R][C][3]
+    if (blockIdx.y) { x = x2; partial = partial2; }
     const int cq = threadIdx.x % Q, pr = threadIdx.x / Q;
     const int64_t lo = blockIdx.x * ppb, hi = (lo + ppb < P) ? lo + ppb : P;
     float k[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -120,7 +123,13 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __re
                                          float* __restrict__ running_mean, float* __restrict__ running_var,
                                          long long* __restrict__ num_batches, float momentum, float eps,
                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                         float* __restrict__ scale, float* __restrict__ shift) {
+                                         float* __restrict__ scale, float* __restrict__ shift, const BnFinArgs second,
+                                         const float* __restrict__ partial2) {
+    if (blockIdx.y) {       // second BatchNorm of a pair launch
+        partial = partial2; gamma = second.gamma; beta = second.beta; running_mean = second.running_mean;
+        running_var = second.running_var; num_batches = second.num_batches; momentum = second.momentum; eps = second.eps;
+        save_mean = second.save_mean; save_invstd = second.save_invstd; scale = second.scale; shift = second.shift;
+    }
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c == 0 && lane == 0 && num_batches) *num_batches += 1;
     // Every lane requests ALL its records (<= 16: parts <= 1024) before it touches the first: the records come from other
@@ -600,14 +609,38 @@ extern "C" int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const f
     const BnFinArgs fin{gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
                         save_mean, save_invstd, scale, shift, counter};
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st,
-                       x, n_pixels, C, l.q, l.r, l.ppb, workspace, fin);
+                       x, n_pixels, C, l.q, l.r, l.ppb, workspace, fin, (const float*)nullptr, (float*)nullptr);
     DAM_CHECK_LAUNCH();
     if (!counter) {
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
                            gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
-                           save_mean, save_invstd, scale, shift);
+                           save_mean, save_invstd, scale, shift, BnFinArgs{}, (const float*)nullptr);
         DAM_CHECK_LAUNCH();
     }
+    return DAM_OK;
+}
+
+// Training-mode statistics of TWO tensors of one shape (a block's conv1 output and its shortcut convolution's output: two
+// independent BatchNorms that become ready together) in one partial + one finalize launch.
+extern "C" int dam_bn_stats_pair_f32(const float* x_a, const float* x_b, int64_t n_pixels, int C, const dam_bn_fin* a,
+                                     const dam_bn_fin* b, float* workspace, void* stream) {
+    if (!x_a || !x_b || !a || !b || !workspace || n_pixels <= 0) return DAM_ERR_BAD_ARG;
+    if (!a->gamma || !a->beta || !a->save_mean || !a->save_invstd || !a->scale || !a->shift || !b->gamma || !b->beta ||
+        !b->save_mean || !b->save_invstd || !b->scale || !b->shift)
+        return DAM_ERR_BAD_ARG;
+    if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
+    const BnLaunch l = bn_plan(n_pixels, C);
+    hipStream_t st = (hipStream_t)stream;
+    float* ws_b = workspace + (size_t)BN_MAX_PARTS * C * 3;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(l.parts, 2), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st, x_a,
+                       n_pixels, C, l.q, l.r, l.ppb, workspace, BnFinArgs{}, x_b, ws_b);
+    DAM_CHECK_LAUNCH();
+    const BnFinArgs fb{b->gamma, b->beta, b->running_mean, b->running_var, (long long*)b->num_batches_tracked, b->momentum,
+                       b->eps, b->save_mean, b->save_invstd, b->scale, b->shift, nullptr};
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C, 2), dim3(64), 0, st, workspace, l.parts, C, a->gamma, a->beta,
+                       a->running_mean, a->running_var, (long long*)a->num_batches_tracked, a->momentum, a->eps, a->save_mean,
+                       a->save_invstd, a->scale, a->shift, fb, (const float*)ws_b);
+    DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
 
@@ -619,7 +652,7 @@ extern "C" int dam_bn_finalize_f32(const float* partial, int parts, int C, const
         return DAM_ERR_BAD_ARG;
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, C, gamma, beta,
                        running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, save_mean, save_invstd,
-                       scale, shift);
+                       scale, shift, BnFinArgs{}, (const float*)nullptr);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }

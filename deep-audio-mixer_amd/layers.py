@@ -42,30 +42,27 @@ class ConvSpec:
         return ops.conv2d_fwd(x, self.packed(w), self.cout, self.k, self.k, self.stride, self.pad, self.dil,
                               bias=bias, in_nchw=self.in_nchw)
 
-    def fwd_bn(self, x, w, bn, training, bias=None, in_affine=None):
-        """Convolution followed by the statistics of its BatchNorm: (c, save_mean, save_invstd, scale, shift).  In
-        training mode the conv launch emits the per-workgroup partial statistics itself when it can (strip kernel);
-        otherwise a separate statistics pass runs over c.  in_affine=(scale, shift): the input is relu(x*scale + shift),
-        applied while the kernel loads x (the producer's BatchNorm + ReLU never materialised)."""
+    def fwd_conv(self, x, w, bn, training, bias=None, in_affine=None):
+        """The convolution in front of a BatchNorm: (c, stats) with stats = (save_mean, save_invstd, scale, shift) when the
+        conv launch produced the training-mode statistics itself (strip kernel epilogue), else None.  in_affine=(scale,
+        shift): the input is relu(x*scale + shift), applied while the kernel loads x (the producer's BatchNorm + ReLU
+        never materialised)."""
         wp = self.packed(w)
         aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
         if training and not self.in_nchw:
             n16 = (self.cout + 15) // 16 * 16
             buf = ops.bn_partial_buffer(x.device, n16)
-            mom = bn.momentum if bn.momentum is not None else 0.1
-            track = bn.track_running_stats
-            # the launch's last workgroup finalizes the statistics itself (no separate finalize launch)
             c, parts, out4 = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
-                                            bn_partial=buf, bn=(bn.weight, bn.bias, bn.running_mean if track else None,
-                                                                bn.running_var if track else None,
-                                                                bn.num_batches_tracked if track else None, mom, bn.eps),
-                                            **aff)
-            if parts > 0:
-                return c, out4[0], out4[1], out4[2], out4[3]
-        else:
-            c = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
-                               in_nchw=self.in_nchw, **aff)
-        return (c,) + tuple(_bn_fwd_stats(c, bn, training))
+                                            bn_partial=buf, bn=_bn_args(bn, training), **aff)
+            return c, ((out4[0], out4[1], out4[2], out4[3]) if parts > 0 else None)
+        return ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
+                              in_nchw=self.in_nchw, **aff), None
+
+    def fwd_bn(self, x, w, bn, training, bias=None, in_affine=None):
+        """Convolution followed by the statistics of its BatchNorm: (c, save_mean, save_invstd, scale, shift); a separate
+        statistics pass runs over c when the conv launch did not emit them."""
+        c, stats = self.fwd_conv(x, w, bn, training, bias=bias, in_affine=in_affine)
+        return (c,) + tuple(stats if stats is not None else _bn_fwd_stats(c, bn, training))
 
     def fwd_bn_apply(self, x, w, bn, training, in_affine=None, res=None, res_affine=None):
         """fwd_bn followed by out = relu(bn(c) + res [* res_scale + res_shift]): (c, save_mean, save_invstd, scale, shift, out)."""
@@ -141,13 +138,18 @@ class WeightPacker:
         ops.pack_weights_multi(self.desc, self.n, self.max_total)
 
 
+def _bn_args(bn, training):
+    """(gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps) of a batch-statistics pass."""
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    track = training and bn.track_running_stats
+    return (bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
+            bn.num_batches_tracked if track else None, mom, bn.eps)
+
+
 def _bn_fwd_stats(c, bn, training):
     """(save_mean, save_invstd, scale, shift) for conv output c under nn.BatchNorm2d semantics."""
     if training or bn.running_mean is None:
-        mom = bn.momentum if bn.momentum is not None else 0.1
-        track = training and bn.track_running_stats
-        return ops.bn_stats(c, bn.weight, bn.bias, bn.running_mean if track else None,
-                            bn.running_var if track else None, bn.num_batches_tracked if track else None, mom, bn.eps)
+        return ops.bn_stats(c, *_bn_args(bn, training))
     return ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
 
@@ -254,15 +256,22 @@ class BasicBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wsc, gsc, bsc, blk, training):
-        c1, m1, i1, sc1, sh1 = blk.spec1.fwd_bn(x, w1.detach(), blk.bn1, training)
         # a1 = relu(bn1(c1)) is never written: conv2 (and later its weight gradient and bn1's backward) read c1 and apply the
         # fused affine themselves
         if wsc is not None:
-            cs, ms, is_, scs, shs = blk.spec_sc.fwd_bn(x, wsc.detach(), blk.shortcut[1], training)
+            bn_sc = blk.shortcut[1]
+            c1, st1 = blk.spec1.fwd_conv(x, w1.detach(), blk.bn1, training)
+            cs, sts = blk.spec_sc.fwd_conv(x, wsc.detach(), bn_sc, training)
+            if st1 is None and sts is None and training and c1.shape == cs.shape:
+                # two independent BatchNorms over tensors of one shape, ready together: one statistics pass for both
+                st1, sts = ops.bn_stats_pair(c1, _bn_args(blk.bn1, True), cs, _bn_args(bn_sc, True))
+            m1, i1, sc1, sh1 = st1 if st1 is not None else _bn_fwd_stats(c1, blk.bn1, training)
+            ms, is_, scs, shs = sts if sts is not None else _bn_fwd_stats(cs, bn_sc, training)
             c2, m2, i2, sc2, sh2, out = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1),
                                                                res=cs, res_affine=(scs, shs))
             ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_)
         else:
+            c1, m1, i1, sc1, sh1 = blk.spec1.fwd_bn(x, w1.detach(), blk.bn1, training)
             c2, m2, i2, sc2, sh2, out = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1), res=x)
             ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1)
         ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None

@@ -341,6 +341,22 @@ def bn_partial_buffer(device, C):
     return _grow(_bn_partials, (device.type, device.index, C), device, _lib.lib().dam_bn_workspace_floats(C))
 
 
+def bn_stats_pair(xa, bn_a, xb, bn_b):
+    """bn_stats for two tensors of one shape in one partial + one finalize launch.  bn_a, bn_b = (gamma, beta, running_mean,
+    running_var, num_batches_tracked, momentum, eps).  Returns two (save_mean, save_invstd, scale, shift) tuples."""
+    _lib.require_cuda(xa, xb)
+    if xa.shape != xb.shape:
+        raise ValueError('the two tensors of a pair have the same shape')
+    C = xa.shape[-1]
+    L = _lib.lib()
+    outs = [torch.empty((4, C), dtype=torch.float32, device=xa.device) for _ in range(2)]
+    fa, fb = _bn_fin_struct(bn_a, outs[0], xa.device), _bn_fin_struct(bn_b, outs[1], xa.device)
+    ws = _workspace(xa.device, 2 * L.dam_bn_workspace_floats(C))
+    _lib.check(L.dam_bn_stats_pair_f32(_lib.ptr(xa), _lib.ptr(xb), xa.numel() // C, C, ctypes.byref(fa), ctypes.byref(fb),
+                                       _lib.ptr(ws), _lib.stream()), 'dam_bn_stats_pair_f32')
+    return tuple(outs[0]), tuple(outs[1])
+
+
 def bn_finalize(partial, parts, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps):
     """Merges `parts` partial records (from conv2d_fwd(..., bn_partial=...)) -> (save_mean, save_invstd, scale, shift)."""
     C = gamma.numel()

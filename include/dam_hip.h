@@ -201,6 +201,13 @@ int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const float* gamma
                      float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
                      float* shift, float* workspace, uint32_t* counter, void* stream);
 
+/* dam_bn_stats_f32 for TWO tensors of one shape in one partial + one finalize launch (a residual block's conv1 output and its
+ * shortcut convolution's output, models/model_resnet.py:17-21,24-26: two independent BatchNorms that become ready together).
+ * a, b: the parameters / outputs of each (struct dam_bn_fin below; `counter` is ignored); workspace:
+ * 2 * dam_bn_workspace_floats(C) floats. */
+int dam_bn_stats_pair_f32(const float* x_a, const float* x_b, int64_t n_pixels, int C, const struct dam_bn_fin* a,
+                          const struct dam_bn_fin* b, float* workspace, void* stream);
+
 /* Second half of dam_bn_stats_f32 on its own: merges `parts` partial records [parts][C][3] = (n, mean, M2) (as written
  * by dam_conv2d_tapgrid_f32's bn_partial output) and produces the same outputs / running-stat update. */
 int dam_bn_finalize_f32(const float* partial, int parts, int C, const float* gamma, const float* beta,

@@ -70,3 +70,22 @@ def test_backward_pair_is_bitwise_two_single_calls(ops):
             for s, p in zip(single, pair):
                 for a, b in zip(s, p):
                     assert torch.equal(a, b)
+
+
+def test_stats_pair_is_bitwise_two_single_calls(ops):
+    g = torch.Generator().manual_seed(6)
+    for shape in [(3, 37, 29, 32), (2, 9, 5, 256)]:
+        C = shape[-1]
+        xs = [torch.randn(shape, generator=g).cuda() * (i + 1) + i for i in range(2)]
+
+        def params():
+            return [(torch.rand(C, generator=torch.Generator().manual_seed(i)).cuda() + 0.5, torch.randn(C, generator=torch.Generator().manual_seed(10 + i)).cuda(),
+                     torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.zeros((), dtype=torch.int64).cuda(), 0.1, 1e-5) for i in range(2)]
+        pa, pb = params(), params()
+        single = [ops.bn_stats(x, *p) for x, p in zip(xs, pa)]
+        pair = ops.bn_stats_pair(xs[0], pb[0], xs[1], pb[1])
+        for s, p in zip(single, pair):
+            for a, b in zip(s, p):
+                assert torch.equal(a, b)
+        for p, q in zip(pa, pb):                 # running statistics and the batch counter moved the same way
+            assert torch.equal(p[2], q[2]) and torch.equal(p[3], q[3]) and int(p[4]) == int(q[4]) == 1
