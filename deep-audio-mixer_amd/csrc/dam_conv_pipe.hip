@@ -36,8 +36,9 @@ constexpr int PIPE_LT = 256;                    // loader threads: 4 waves, one 
                                                 // leaves its SIMD's other waves few issue slots: two loader waves on two SIMDs held
                                                 // back the two compute waves they shared with, and the barrier made all four wait)
 constexpr int PIPE_THREADS = 256 + PIPE_LT;
-constexpr int PIPE_U = 5;                       // float4 items per loader thread and chunk (a chunk of the patch <= 1280 items:
-                                                // 64 pixels of 54-pixel rows -- the 64-channel stage at the reference's 216 frames)
+// float4 items per loader thread and chunk = template parameter PU: 5 (a chunk of the patch <= 1280 items: every stride-1 stage,
+// also 64 pixels of 54-pixel rows at the reference's 216 frames) or 8 (<= 2048 items: the strided 3x3 convolutions at the head of
+// a down-sampling block, whose patch covers twice the rows and columns)
 constexpr int PIPE_BUF1 = 32768;                // LDS byte offset of the second chunk buffer: a compile-time constant, so the
                                                 // loaders' LDS writes carry it as an immediate
 
@@ -83,7 +84,7 @@ __device__ __forceinline__ PipeUnit pipe_decode(const ConvGeo& g, int unit, int 
 
 // The second launch bound is the register budget (waves per SIMD): without it the compiler hoists every loop-invariant address
 // of the loader's 16 segments into registers (198 VGPRs, one workgroup per CU).
-template <int MB, int NB>
+template <int MB, int NB, int PIPE_U>
 __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g, const int nunits, const float* __restrict__ X,
                                                                  const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                                  const float* __restrict__ in_scale,
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
 }
 
 // resident workgroups per launch: occupancy x CUs, asked once per instance and LDS size
-template <int MB, int NB>
+template <int MB, int NB, int PU>
 int pipe_slots(size_t lds) {
     static int cus = 0;
     static size_t cached_lds = ~(size_t)0;
@@ -404,7 +405,7 @@ int pipe_slots(size_t lds) {
     }
     if (cached_lds != lds) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_pipe_kernel<MB, NB>), PIPE_THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_pipe_kernel<MB, NB, PU>), PIPE_THREADS,
                                                          lds) != hipSuccess || per_cu < 1)
             per_cu = 1;
         cached = per_cu * cus;
@@ -413,15 +414,15 @@ int pipe_slots(size_t lds) {
     return cached;
 }
 
-template <int MB, int NB>
+template <int MB, int NB, int PU>
 int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
                 float* Y, const float* res, const float* res_mask, float* workspace, hipStream_t st) {
     const int nunits = g.tiles_m * (g.N / 16 / NB) * g.B;
-    int wgs = pipe_slots<MB, NB>(lds);
+    int wgs = pipe_slots<MB, NB, PU>(lds);
     if (const char* e = getenv("DAM_PIPE_WGS")) wgs = atoi(e);          // diagnostic
     if (wgs < 1) wgs = 1;
     if (wgs > nunits) wgs = nunits;
-    hipLaunchKernelGGL((conv_pipe_kernel<MB, NB>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
+    hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
                        reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -446,7 +447,7 @@ int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, cons
     };
     auto fits = [&](int mb, int nb) {
         const int pr = patch_rows(mb);
-        return nblk % nb == 0 && pr * g.PWin * 4 <= PIPE_LT * PIPE_U && (size_t)pr * g.PWT * 64 <= PIPE_BUF1;
+        return nblk % nb == 0 && pr * g.PWin * 4 <= PIPE_LT * 8 && (size_t)pr * g.PWT * 64 <= PIPE_BUF1;
     };
     // Tile: the largest of the <= 4-block tiles (<= 128 VGPRs: two workgroups per CU, three for the smallest) that still yields
     // >= 384 work units, else the one with the most units.  Measured on the ResNet's thick layers (tools/pipe_ab.sh):
@@ -471,11 +472,12 @@ int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, cons
     g.CG = 1; g.ksplit = 1; g.gps = g.nchunks;
     // chunk buffer 0 (padded to PIPE_BUF1), chunk buffer 1, scale / shift tables, the dump zone
     const size_t lds = PIPE_BUF1 + (size_t)g.PR * g.PWT * 64 + (sc ? (size_t)2 * g.C * 4 : 0) + PIPE_LT * 16;
-#define DAM_PIPE_CASE(M_, N_) \
-    if (MB == M_ && NB == N_) return launch_pipe<M_, N_>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, st)
-    DAM_PIPE_CASE(4, 4); DAM_PIPE_CASE(4, 2); DAM_PIPE_CASE(4, 1);
-    DAM_PIPE_CASE(2, 4); DAM_PIPE_CASE(2, 2); DAM_PIPE_CASE(2, 1);
-    DAM_PIPE_CASE(1, 4); DAM_PIPE_CASE(1, 2); DAM_PIPE_CASE(1, 1);
+    const bool big = g.PR * g.PWin * 4 > PIPE_LT * 5;      // items per loader thread: 5 or 8
+#define DAM_PIPE_CASE(M_, N_)                                                                                              \
+    if (MB == M_ && NB == N_)                                                                                              \
+        return big ? launch_pipe<M_, N_, 8>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, st)                  \
+                   : launch_pipe<M_, N_, 5>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, st)
+    DAM_PIPE_CASE(1, 4); DAM_PIPE_CASE(2, 2); DAM_PIPE_CASE(1, 2); DAM_PIPE_CASE(2, 1); DAM_PIPE_CASE(1, 1);
 #undef DAM_PIPE_CASE
     return DAM_ERR_UNSUPPORTED;
 }

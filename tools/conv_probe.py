@@ -35,6 +35,12 @@ elif which in ('layer4', 'layer5', 'layer6'):
     x = torch.randn((B, hw[0], hw[1], c), device=dev)
     wp = ops.pack_weights(torch.randn((c, c, 3, 3), device=dev) * 0.05)
     fn = lambda: ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1)
+elif which in ('layer3s2', 'layer4s2', 'layer5s2', 'layer6s2'):       # the strided 3x3 convolution at the head of a stage
+    hw, ci, co = {'layer3s2': ((513, 65), 32, 64), 'layer4s2': ((257, 33), 64, 96), 'layer5s2': ((129, 17), 96, 128),
+                  'layer6s2': ((65, 9), 128, 256)}[which]
+    x = torch.randn((B, hw[0], hw[1], ci), device=dev)
+    wp = ops.pack_weights(torch.randn((co, ci, 3, 3), device=dev) * 0.05)
+    fn = lambda: ops.conv2d_fwd(x, wp, co, 3, 3, 2, 1, 1)
 elif which in ('layer3_wgrad', 'layer4_wgrad', 'layer5_wgrad', 'layer6_wgrad'):
     hw, c = {'layer3_wgrad': ((257, 33), 64), 'layer4_wgrad': ((129, 17), 96), 'layer5_wgrad': ((65, 9), 128),
              'layer6_wgrad': ((33, 5), 256)}[which]
