@@ -28,7 +28,10 @@ SIGNATURES = {
     'dam_conv_pack_weights_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'dam_conv_pack_weights_multi_f32': (c_i, [c_p, c_i, c_i64, c_p]),
     'dam_conv2d_tapgrid_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p] +
-                               [c_i] * 17 + [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+                               [c_i] * 17 + [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    'dam_conv_batch_bytes': (c_i64, []),
+    'dam_conv_batch_init': (c_i, [c_p]),
+    'dam_conv_batch_flush': (c_i, [c_p, c_p]),
     'dam_conv2d_wgrad_workspace_floats': (c_i64, [c_i, c_i, c_i, c_i]),
     'dam_conv2d_wgrad_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p] + [c_i] * 9 +
                              [c_p, c_i, c_p, c_i64, c_p, c_p]),

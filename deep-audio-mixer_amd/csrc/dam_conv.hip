@@ -33,8 +33,16 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Up to four launches that differ only in their geometry (the parity classes of a strided data gradient: same tensors, same
+// weights, same tile) run as ONE launch: blockIdx.z = class * B + image; a workgroup outside its class's grid leaves.
+constexpr int GEO_PACK_MAX = 4;
+struct ConvGeoPack {
+    ConvGeo g[GEO_PACK_MAX];
+    int n, B;
+};
+
 template <int MB, int NB>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const float* __restrict__ X,
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeoPack pk, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          const float* __restrict__ in_scale,
                                                          const float* __restrict__ in_shift, float* __restrict__ Y,
@@ -44,9 +52,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeo g, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
     constexpr int MW = 16 * MB, TM = 4 * MW;
-    const int ks = blockIdx.y % g.ksplit;                       // split-K slice of this workgroup
-    const int img = blockIdx.z, nb0 = (blockIdx.y / g.ksplit) * NB;
+    const int cls = pk.n > 1 ? (int)blockIdx.z / pk.B : 0;
+    const ConvGeo& g = pk.g[cls];
     const int HoWo = g.Ho * g.Wo;
+    if (pk.n > 1 && ((int)blockIdx.x * TM >= HoWo || (int)blockIdx.y >= ((g.N / 16 + NB - 1) / NB) * g.ksplit)) return;
+    const int ks = blockIdx.y % g.ksplit;                       // split-K slice of this workgroup
+    const int img = (int)blockIdx.z - cls * pk.B, nb0 = (blockIdx.y / g.ksplit) * NB;
     const int p0 = blockIdx.x * TM;
     const float inv_wo = 1.0f / (float)g.Wo;
     const int oh_first = fast_div(p0, g.Wo, inv_wo);
@@ -245,8 +256,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, i
 }
 
 template <int MB, int NB>
-int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc,
-                const float* sh, float* Y, const float* res, const float* res_mask, float* splitk_ws, hipStream_t st) {
+int launch_conv_pack(const ConvGeoPack& pk, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc,
+                     const float* sh, float* Y, const float* res, const float* res_mask, float* splitk_ws, hipStream_t st) {
     constexpr int TM = 64 * MB;
     if (lds > 64 * 1024) {
         static bool raised = false;   // per instantiation
@@ -257,10 +268,26 @@ int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
             raised = true;
         }
     }
-    dim3 grid((unsigned)cdiv((int64_t)g.Ho * g.Wo, TM), (unsigned)(cdiv(g.N / 16, NB) * g.ksplit), (unsigned)g.B);
-    hipLaunchKernelGGL((conv_igemm_kernel<MB, NB>), grid, dim3(256), lds, st, g, X, reinterpret_cast<const float4*>(Wp),
+    int64_t gx = 0, gy = 0;
+    for (int i = 0; i < pk.n; ++i) {
+        const ConvGeo& g = pk.g[i];
+        const int64_t tx = cdiv((int64_t)g.Ho * g.Wo, TM), ty = cdiv(g.N / 16, NB) * g.ksplit;
+        gx = tx > gx ? tx : gx; gy = ty > gy ? ty : gy;
+    }
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)(pk.B * pk.n));
+    hipLaunchKernelGGL((conv_igemm_kernel<MB, NB>), grid, dim3(256), lds, st, pk, X, reinterpret_cast<const float4*>(Wp),
                        bias, sc, sh, Y, res, res_mask, splitk_ws);
     DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+template <int MB, int NB>
+int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc,
+                const float* sh, float* Y, const float* res, const float* res_mask, float* splitk_ws, hipStream_t st) {
+    ConvGeoPack pk;
+    pk.g[0] = g; pk.n = 1; pk.B = g.B;
+    const int rc = launch_conv_pack<MB, NB>(pk, lds, X, Wp, bias, sc, sh, Y, res, res_mask, splitk_ws, st);
+    if (rc != DAM_OK) return rc;
     if (g.ksplit > 1) {
         const int64_t n4 = (int64_t)g.B * g.OHt * g.OWt * g.N / 4;
         const int blocks = (int)(cdiv(n4, 256) < 2048 ? cdiv(n4, 256) : 2048);
@@ -268,6 +295,60 @@ int launch_conv(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
         DAM_CHECK_LAUNCH();
     }
     return DAM_OK;
+}
+
+// Caller-owned batch of tile-kernel launches (include/dam_hip.h: dam_conv_batch_*): dam_conv2d_tapgrid_f32 records a launch that
+// would take conv_igemm_kernel without split-K instead of making it; the flush packs consecutive records that differ only in
+// geometry into one launch.
+struct ConvLaunchRec {
+    ConvGeo g;
+    int MB, NB;
+    size_t lds;
+    const float *X, *Wp, *bias, *sc, *sh, *res, *res_mask;
+    float *Y, *ws;
+};
+constexpr int CONV_BATCH_MAX = 8;
+constexpr unsigned CONV_BATCH_MAGIC = 0x43424154u;      // "CBAT"
+struct ConvBatch {
+    unsigned magic;
+    int n;
+    ConvLaunchRec rec[CONV_BATCH_MAX];
+};
+
+int conv_pack_dispatch(const ConvGeoPack& pk, const ConvLaunchRec& r, hipStream_t st) {
+#define DAM_CONV_PCASE(M_, N_) \
+    if (r.MB == M_ && r.NB == N_) return launch_conv_pack<M_, N_>(pk, r.lds, r.X, r.Wp, r.bias, r.sc, r.sh, r.Y, r.res, r.res_mask, r.ws, st)
+    DAM_CONV_PCASE(4, 4); DAM_CONV_PCASE(4, 2); DAM_CONV_PCASE(4, 1);
+    DAM_CONV_PCASE(2, 4); DAM_CONV_PCASE(2, 2); DAM_CONV_PCASE(2, 1);
+    DAM_CONV_PCASE(1, 4); DAM_CONV_PCASE(1, 2); DAM_CONV_PCASE(1, 1);
+#undef DAM_CONV_PCASE
+    return DAM_ERR_UNSUPPORTED;
+}
+
+int conv_batch_flush(ConvBatch& b, hipStream_t st) {
+    int i = 0, rc = DAM_OK;
+    while (i < b.n && rc == DAM_OK) {
+        const ConvLaunchRec& r = b.rec[i];
+        ConvGeoPack pk;
+        pk.B = r.g.B; pk.n = 0;
+        size_t lds = 0;
+        int k = i;
+        while (k < b.n && pk.n < GEO_PACK_MAX) {
+            const ConvLaunchRec& q = b.rec[k];
+            if (q.MB != r.MB || q.NB != r.NB || q.X != r.X || q.Wp != r.Wp || q.bias != r.bias || q.sc != r.sc || q.sh != r.sh ||
+                q.Y != r.Y || q.res != r.res || q.res_mask != r.res_mask || q.g.B != r.g.B)
+                break;
+            pk.g[pk.n++] = q.g;
+            lds = q.lds > lds ? q.lds : lds;
+            ++k;
+        }
+        ConvLaunchRec merged = r;
+        merged.lds = lds;
+        rc = conv_pack_dispatch(pk, merged, st);
+        i = k;
+    }
+    b.n = 0;
+    return rc;
 }
 
 }  // namespace
@@ -391,13 +472,30 @@ int launch_conv1x1(const ConvGeo& g, const float* X, const float* Wp, const floa
 }  // namespace dam
 
 // Generic tap-grid convolution (see dam_hip.h).  The host wrapper derives the patch geometry and picks the tile.
+extern "C" int64_t dam_conv_batch_bytes(void) { return (int64_t)sizeof(dam::ConvBatch); }
+
+extern "C" int dam_conv_batch_init(void* batch) {
+    if (!batch) return DAM_ERR_BAD_ARG;
+    dam::ConvBatch* b = static_cast<dam::ConvBatch*>(batch);
+    b->magic = dam::CONV_BATCH_MAGIC;
+    b->n = 0;
+    return DAM_OK;
+}
+
+extern "C" int dam_conv_batch_flush(void* batch, void* stream) {
+    dam::ConvBatch* b = static_cast<dam::ConvBatch*>(batch);
+    if (!b || b->magic != dam::CONV_BATCH_MAGIC) return DAM_ERR_BAD_ARG;
+    return dam::conv_batch_flush(*b, (hipStream_t)stream);
+}
+
 extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
                                       int k_chunks, int n_out, const float* bias, const float* in_scale,
                                       const float* in_shift, int relu_in, int relu_out, float* y, int OHt, int OWt, int Ho, int Wo,
                                       int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                                       int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                                       const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
-                                      const dam_bn_fin* bn_fin, float* workspace, int64_t workspace_floats, void* stream) {
+                                      const dam_bn_fin* bn_fin, float* workspace, int64_t workspace_floats, void* batch,
+                                      void* stream) {
     using namespace dam;
     if (bn_parts_host) *bn_parts_host = 0;
     BnFinArgs fin{};
@@ -528,6 +626,18 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
         }
     }
     const size_t lds = (size_t)CG * g.PR * g.PWT * 64;
+    if (batch && g.ksplit == 1) {       // recorded, launched (packed with its siblings) by dam_conv_batch_flush
+        ConvBatch* cb = static_cast<ConvBatch*>(batch);
+        if (cb->magic != CONV_BATCH_MAGIC) return DAM_ERR_BAD_ARG;
+        if (cb->n == CONV_BATCH_MAX) {
+            const int rc = conv_batch_flush(*cb, st);
+            if (rc != DAM_OK) return rc;
+        }
+        ConvLaunchRec& r = cb->rec[cb->n++];
+        r.g = g; r.MB = MB; r.NB = NB; r.lds = lds; r.X = x; r.Wp = w_packed; r.bias = bias; r.sc = in_scale; r.sh = in_shift;
+        r.res = res; r.res_mask = res_mask; r.Y = y; r.ws = workspace;
+        return DAM_OK;
+    }
 #define DAM_CONV_CASE(M_, N_) \
     if (MB == M_ && NB == N_) return launch_conv<M_, N_>(g, lds, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st)
     DAM_CONV_CASE(4, 4); DAM_CONV_CASE(4, 2); DAM_CONV_CASE(4, 1);

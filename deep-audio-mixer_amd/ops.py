@@ -73,7 +73,7 @@ def _bn_fin_struct(bn, out4, device):
 
 def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shift, relu_in, y, OHt, OWt, Ho, Wo,
              out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
-             res=None, res_mask=None, bn_partial=None, bn_fin=None, relu_out=False):
+             res=None, res_mask=None, bn_partial=None, bn_fin=None, relu_out=False, batch=None):
     parts = ctypes.c_int(0)
     # split-K scratch: the host code only splits when no tile shape gives 400 workgroups, i.e. for outputs below
     # 400 * 64 px * 64 ch = 1.64 M floats, and then at most 8 ways (dam_conv.hip) -- never more than 13.1 M floats
@@ -84,7 +84,8 @@ def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shi
         out_stride,
         oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb, _lib.ptr(res),
         _lib.ptr(res_mask), _lib.ptr(bn_partial), ctypes.byref(parts) if bn_partial is not None else None,
-        ctypes.byref(bn_fin) if bn_fin is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctypes.byref(bn_fin) if bn_fin is not None else None, _lib.ptr(ws), ws.numel(),
+        ctypes.addressof(batch) if batch is not None else None, _lib.stream())
     _lib.check(st, 'dam_conv2d_tapgrid_f32')
     return parts.value
 
@@ -157,20 +158,38 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
         if res is not None:
             raise ValueError('a fused residual needs every output parity class to receive taps')
         dx.zero_()          # classes without taps get no gradient (e.g. the 1x1 stride-2 shortcut)
-    covered = True
-    for ph in range(stride):
-        for pw in range(stride):
-            ah, aw = _dgrad_axis(ph, pad, dil, kh, stride), _dgrad_axis(pw, pad, dil, kw, stride)
-            nh, nw = (H - ph + stride - 1) // stride, (W - pw + stride - 1) // stride
-            if nh <= 0 or nw <= 0:
-                continue
-            if ah is None or aw is None:
-                covered = False
-                continue
-            _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, nh, nw,
-                     stride, ph, pw, 1, ah[0], aw[0], ah[3], ah[4], aw[3], aw[4], ah[1] * kw + aw[1],
-                     ah[2] * kw, aw[2], res, res_mask)
+    # the classes write disjoint pixels of dx from the same dy and weights: those that take the tile kernel are recorded
+    # and run as ONE launch (class in blockIdx.z) at the flush
+    batch = _conv_batch(dy.device)
+    try:
+        for ph in range(stride):
+            for pw in range(stride):
+                ah, aw = _dgrad_axis(ph, pad, dil, kh, stride), _dgrad_axis(pw, pad, dil, kw, stride)
+                nh, nw = (H - ph + stride - 1) // stride, (W - pw + stride - 1) // stride
+                if nh <= 0 or nw <= 0 or ah is None or aw is None:
+                    continue
+                _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, nh, nw,
+                         stride, ph, pw, 1, ah[0], aw[0], ah[3], ah[4], aw[3], aw[4], ah[1] * kw + aw[1],
+                         ah[2] * kw, aw[2], res, res_mask, batch=batch)
+        _lib.check(_lib.lib().dam_conv_batch_flush(ctypes.addressof(batch), _lib.stream()), 'dam_conv_batch_flush')
+    except Exception:
+        _lib.lib().dam_conv_batch_init(ctypes.addressof(batch))      # drop what a failed call left recorded
+        raise
     return dx
+
+
+_conv_batches = {}
+
+
+def _conv_batch(device):
+    """The device's launch batch for sibling tile-kernel launches (include/dam_hip.h: dam_conv_batch_*)."""
+    key = (device.type, device.index)
+    b = _conv_batches.get(key)
+    if b is None:
+        L = _lib.lib()
+        b = _conv_batches[key] = ctypes.create_string_buffer(int(L.dam_conv_batch_bytes()))
+        _lib.check(L.dam_conv_batch_init(ctypes.addressof(b)), 'dam_conv_batch_init')
+    return b
 
 
 _workspaces = {}

@@ -140,7 +140,18 @@ int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nc
                            int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                            int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                            const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
-                           const struct dam_bn_fin* bn_fin, float* workspace, int64_t workspace_floats, void* stream);
+                           const struct dam_bn_fin* bn_fin, float* workspace, int64_t workspace_floats, void* batch,
+                           void* stream);
+
+/* Sibling launches in one.  The parity classes of a strided data gradient are up to four small launches over the same
+ * tensors, weights and tile that differ only in their tap grid.  With a batch (caller-owned HOST memory of
+ * dam_conv_batch_bytes() bytes, dam_conv_batch_init() once) dam_conv2d_tapgrid_f32 records a launch that would take the tile
+ * kernel instead of making it (launches that take another kernel run at once, as without a batch);
+ * dam_conv_batch_flush packs consecutive records that differ only in geometry into ONE launch (class in blockIdx.z).
+ * Every tensor of a recorded call must stay valid until the flush; batch = NULL launches at once. */
+int64_t dam_conv_batch_bytes(void);
+int dam_conv_batch_init(void* batch);
+int dam_conv_batch_flush(void* batch, void* stream);
 
 /* Weight gradient of the same convolutions (autograd of nn.Conv2d reached from loss.backward(),
  * model_trainer.py:36):  dw[n][k][kh][kw] = sum_{b,oh,ow} dy[b,oh,ow,n] * f(x[b, oh*stride+kh*dil-pad, ow*stride+kw*dil-pad, k])
