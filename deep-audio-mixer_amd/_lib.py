@@ -43,11 +43,11 @@ SIGNATURES = {
     'dam_bn_stats_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_finalize_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_eval_affine_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
-    'dam_bn_apply_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    'dam_bn_apply_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     'dam_bn_stats_pair_f32': (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
     'dam_bn_pair_workspace_floats': (c_i64, [c_i]),
-    'dam_bn_backward_pair_f32': (c_i, [c_p, c_p, c_i64, c_i, c_i] + [c_p] * 16),
-    'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'dam_bn_backward_pair_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i] + [c_p] * 16),
+    'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'dam_channel_sum_f32': (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
     'dam_dropout_tick': (c_i, [c_p, c_i64, c_p, c_p]),
     'dam_dropout_apply_f32': (c_i, [c_p, c_i64, c_f, ctypes.c_uint64, c_p, c_p, c_p]),

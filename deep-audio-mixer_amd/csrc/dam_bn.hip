@@ -198,7 +198,7 @@ __global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, co
 __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t nquads, int Q, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const float* __restrict__ res,
                                 const float* __restrict__ rscale, const float* __restrict__ rshift, int relu,
-                                float* __restrict__ y) {
+                                float* __restrict__ y, unsigned char* __restrict__ sign_bits) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nquads; e += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(e % Q);
         const float4 v = reinterpret_cast<const float4*>(x)[e];
@@ -214,6 +214,8 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t nquads, int
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[e] = o;
+        // one byte per channel quad: bit i = (y[4e + i] > 0) -- the ReLU mask the backward passes want, 1/16 of the bytes of y
+        if (sign_bits) sign_bits[e] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
     }
 }
 
@@ -267,6 +269,11 @@ __device__ __forceinline__ void bn_bwd_finalize_block(const float* partial, int 
 }
 
 // partial[blk][c] = (sum dz, sum dz*xhat)
+__device__ __forceinline__ float4 sign_quad(unsigned b) {       // sign byte -> (1 or 0) x 4
+    return make_float4((float)(b & 1u), (float)((b >> 1) & 1u), (float)((b >> 2) & 1u), (float)((b >> 3) & 1u));
+}
+
+// MASK: 3 = from the sign bytes written by bn_apply (one byte per channel quad: y_mask then points at bytes);
 // MASK: 0 none, 1 from y_mask (saved output), 2 recomputed as fma(x, mscale, mshift) > 0 -- the forward's own expression, so
 // the bits agree and the saved activation is not read at all
 template <int MASK>
@@ -293,6 +300,7 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, const float*
             gv[u] = ok ? *reinterpret_cast<const float4*>(dy + q * C + cq * 4) : z;
             xv[u] = ok ? *reinterpret_cast<const float4*>(x + q * C + cq * 4) : z;
             mv[u] = (ok && MASK == 1) ? *reinterpret_cast<const float4*>(y_mask + q * C + cq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+            if (MASK == 3) mv[u] = sign_quad(ok ? reinterpret_cast<const unsigned char*>(y_mask)[q * Q + cq] : 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -393,6 +401,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             float4 m;
             if (MASK == 1) {
                 m = reinterpret_cast<const float4*>(y_mask)[e];
+            } else if (MASK == 3) {
+                m = sign_quad(reinterpret_cast<const unsigned char*>(y_mask)[e]);
             } else {
                 const float4 sc = reinterpret_cast<const float4*>(mscale)[cq], sh = reinterpret_cast<const float4*>(mshift)[cq];
                 m = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
@@ -411,6 +421,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 // ---- two BatchNorms that share dy and the ReLU mask (a residual block's bn2 and its shortcut BatchNorm, both fed by the
 // block's output gradient): one partial / finalize / apply launch for both -- dy and the mask are read once per pass
 // instead of twice, three launches instead of six.  Same sums in the same order as the single form: bitwise the same result.
+template <bool BITS>        // y_mask points at the sign bytes of bn_apply instead of the float output
 __global__ void bn_bwd_partial_pair_kernel(const float* __restrict__ dy, const float* __restrict__ y_mask,
                                            const float* __restrict__ xa, const float* __restrict__ xb, int64_t P, int C, int Q,
                                            int R, int64_t ppb, const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
@@ -433,7 +444,8 @@ __global__ void bn_bwd_partial_pair_kernel(const float* __restrict__ dy, const f
             gv[u] = ok ? *reinterpret_cast<const float4*>(dy + q * C + cq * 4) : z;
             va[u] = ok ? *reinterpret_cast<const float4*>(xa + q * C + cq * 4) : z;
             vb[u] = ok ? *reinterpret_cast<const float4*>(xb + q * C + cq * 4) : z;
-            mv[u] = ok ? *reinterpret_cast<const float4*>(y_mask + q * C + cq * 4) : z;
+            if (BITS) mv[u] = sign_quad(ok ? reinterpret_cast<const unsigned char*>(y_mask)[q * Q + cq] : 0);
+            else mv[u] = ok ? *reinterpret_cast<const float4*>(y_mask + q * C + cq * 4) : z;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -518,13 +530,14 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_pair_kernel(const float* _
     coef[3 * C + c] = (float)gb; coef[4 * C + c] = (float)b2; coef[5 * C + c] = (float)b3;
 }
 
+template <bool BITS>
 __global__ void bn_bwd_apply_pair_kernel(const float* __restrict__ dy, const float* __restrict__ y_mask,
                                          const float* __restrict__ xa, const float* __restrict__ xb, int64_t nquads, int Q, int C,
                                          const float* __restrict__ coef, float* __restrict__ dxa, float* __restrict__ dxb) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nquads; e += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(e % Q);
         float4 g = reinterpret_cast<const float4*>(dy)[e];
-        const float4 m = reinterpret_cast<const float4*>(y_mask)[e];
+        const float4 m = BITS ? sign_quad(reinterpret_cast<const unsigned char*>(y_mask)[e]) : reinterpret_cast<const float4*>(y_mask)[e];
         const float4 v = reinterpret_cast<const float4*>(xa)[e], w = reinterpret_cast<const float4*>(xb)[e];
         g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
         const float4 a1 = reinterpret_cast<const float4*>(coef)[cq], a2 = reinterpret_cast<const float4*>(coef + C)[cq],
@@ -670,34 +683,36 @@ extern "C" int dam_bn_eval_affine_f32(int C, const float* gamma, const float* be
 
 extern "C" int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const float* scale, const float* shift,
                                 const float* res, const float* res_scale, const float* res_shift, int relu, float* y,
-                                void* stream) {
+                                uint8_t* sign_bits, void* stream) {
     if (!x || !scale || !shift || !y || n_pixels <= 0) return DAM_ERR_BAD_ARG;
     if (C % 16) return DAM_ERR_UNSUPPORTED;
     if (res_scale && (!res || !res_shift)) return DAM_ERR_BAD_ARG;
     const int64_t nq = n_pixels * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(elt_blocks(nq)), dim3(256), 0, (hipStream_t)stream, x, nq, C / 4, scale, shift,
-                       res, res_scale, res_shift, relu, y);
+                       res, res_scale, res_shift, relu, y, sign_bits);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
 
 extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
                                    const float* gamma, const float* save_mean, const float* save_invstd, int training,
-                                   const float* mask_scale, const float* mask_shift, float* dx, float* dgamma, float* dbeta,
-                                   float* workspace, uint32_t* counter, void* stream) {
+                                   const float* mask_scale, const float* mask_shift, const uint8_t* mask_bits, float* dx,
+                                   float* dgamma, float* dbeta, float* workspace, uint32_t* counter, void* stream) {
     if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || n_pixels <= 0)
         return DAM_ERR_BAD_ARG;
-    if ((mask_scale != nullptr) != (mask_shift != nullptr) || (y_mask && mask_scale)) return DAM_ERR_BAD_ARG;
+    if ((mask_scale != nullptr) != (mask_shift != nullptr) || (y_mask && mask_scale) || (mask_bits && (y_mask || mask_scale)))
+        return DAM_ERR_BAD_ARG;
+    if (mask_bits) y_mask = reinterpret_cast<const float*>(mask_bits);       // MASK == 3 reads it as bytes
     if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
     const BnLaunch l = bn_plan(n_pixels, C);
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + (size_t)BN_MAX_PARTS * C * 2;    // workspace holds [parts][C][2] then [3][C]
-    const int mask = y_mask ? 1 : (mask_scale ? 2 : 0);
+    const int mask = mask_bits ? 3 : (y_mask ? 1 : (mask_scale ? 2 : 0));
     const BnBwdFin fin{(double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef, counter};
 #define DAM_BN_PARTIAL(M_)                                                                                                   \
     hipLaunchKernelGGL(bn_bwd_partial_kernel<M_>, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 2 * sizeof(float), st, dy, \
                        y_mask, x, n_pixels, C, l.q, l.r, l.ppb, save_mean, save_invstd, mask_scale, mask_shift, workspace, fin)
-    if (mask == 1) DAM_BN_PARTIAL(1); else if (mask == 2) DAM_BN_PARTIAL(2); else DAM_BN_PARTIAL(0);
+    if (mask == 1) DAM_BN_PARTIAL(1); else if (mask == 2) DAM_BN_PARTIAL(2); else if (mask == 3) DAM_BN_PARTIAL(3); else DAM_BN_PARTIAL(0);
 #undef DAM_BN_PARTIAL
     DAM_CHECK_LAUNCH();
     if (!counter) {
@@ -709,7 +724,7 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
 #define DAM_BN_APPLY(M_)                                                                                                     \
     hipLaunchKernelGGL(bn_bwd_apply_kernel<M_>, dim3(elt_blocks(nq)), dim3(256), 0, st, dy, y_mask, x, nq, C / 4, C, coef,   \
                        mask_scale, mask_shift, dx)
-    if (mask == 1) DAM_BN_APPLY(1); else if (mask == 2) DAM_BN_APPLY(2); else DAM_BN_APPLY(0);
+    if (mask == 1) DAM_BN_APPLY(1); else if (mask == 2) DAM_BN_APPLY(2); else if (mask == 3) DAM_BN_APPLY(3); else DAM_BN_APPLY(0);
 #undef DAM_BN_APPLY
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -717,11 +732,15 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
 
 extern "C" int64_t dam_bn_pair_workspace_floats(int C) { return (int64_t)BN_MAX_PARTS * C * 3 + 6 * (int64_t)C; }
 
-extern "C" int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, int64_t n_pixels, int C, int training,
+extern "C" int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, const uint8_t* mask_bits, int64_t n_pixels, int C,
+                                        int training,
                                         const float* x_a, const float* gamma_a, const float* mean_a, const float* invstd_a,
                                         float* dx_a, float* dgamma_a, float* dbeta_a,
                                         const float* x_b, const float* gamma_b, const float* mean_b, const float* invstd_b,
                                         float* dx_b, float* dgamma_b, float* dbeta_b, float* workspace, void* stream) {
+    if ((y_mask != nullptr) == (mask_bits != nullptr)) return DAM_ERR_BAD_ARG;      // exactly one form of the mask
+    const bool bits = mask_bits != nullptr;
+    if (bits) y_mask = reinterpret_cast<const float*>(mask_bits);
     if (!dy || !y_mask || !x_a || !gamma_a || !mean_a || !invstd_a || !dx_a || !dgamma_a || !dbeta_a || !x_b || !gamma_b ||
         !mean_b || !invstd_b || !dx_b || !dgamma_b || !dbeta_b || !workspace || n_pixels <= 0)
         return DAM_ERR_BAD_ARG;
@@ -730,15 +749,23 @@ extern "C" int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, in
     if ((size_t)l.r * C * 3 * sizeof(float) > 64 * 1024) return DAM_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + (size_t)BN_MAX_PARTS * C * 3;
-    hipLaunchKernelGGL(bn_bwd_partial_pair_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st, dy,
-                       y_mask, x_a, x_b, n_pixels, C, l.q, l.r, l.ppb, mean_a, invstd_a, mean_b, invstd_b, workspace);
+    if (bits)
+        hipLaunchKernelGGL(bn_bwd_partial_pair_kernel<true>, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st,
+                           dy, y_mask, x_a, x_b, n_pixels, C, l.q, l.r, l.ppb, mean_a, invstd_a, mean_b, invstd_b, workspace);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_pair_kernel<false>, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st,
+                           dy, y_mask, x_a, x_b, n_pixels, C, l.q, l.r, l.ppb, mean_a, invstd_a, mean_b, invstd_b, workspace);
     DAM_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_pair_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C, (double)n_pixels, gamma_a,
                        mean_a, invstd_a, gamma_b, mean_b, invstd_b, training, dgamma_a, dbeta_a, dgamma_b, dbeta_b, coef);
     DAM_CHECK_LAUNCH();
     const int64_t nq = n_pixels * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_pair_kernel, dim3(elt_blocks(nq)), dim3(256), 0, st, dy, y_mask, x_a, x_b, nq, C / 4, C, coef,
-                       dx_a, dx_b);
+    if (bits)
+        hipLaunchKernelGGL(bn_bwd_apply_pair_kernel<true>, dim3(elt_blocks(nq)), dim3(256), 0, st, dy, y_mask, x_a, x_b, nq, C / 4, C,
+                           coef, dx_a, dx_b);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_pair_kernel<false>, dim3(elt_blocks(nq)), dim3(256), 0, st, dy, y_mask, x_a, x_b, nq, C / 4, C,
+                           coef, dx_a, dx_b);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }

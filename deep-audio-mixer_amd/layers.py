@@ -64,11 +64,12 @@ class ConvSpec:
         c, stats = self.fwd_conv(x, w, bn, training, bias=bias, in_affine=in_affine)
         return (c,) + tuple(stats if stats is not None else _bn_fwd_stats(c, bn, training))
 
-    def fwd_bn_apply(self, x, w, bn, training, in_affine=None, res=None, res_affine=None):
-        """fwd_bn followed by out = relu(bn(c) + res [* res_scale + res_shift]): (c, save_mean, save_invstd, scale, shift, out)."""
+    def fwd_bn_apply(self, x, w, bn, training, in_affine=None, res=None, res_affine=None, sign_bits=False):
+        """fwd_bn followed by out = relu(bn(c) + res [* res_scale + res_shift]): (c, save_mean, save_invstd, scale, shift, out);
+        with sign_bits the last item is (out, bits): see ops.bn_apply."""
         rs, rh = res_affine if res_affine is not None else (None, None)
         c, m, i, sc, sh = self.fwd_bn(x, w, bn, training, in_affine=in_affine)
-        return c, m, i, sc, sh, ops.bn_apply(c, sc, sh, relu=True, res=res, res_scale=rs, res_shift=rh)
+        return c, m, i, sc, sh, ops.bn_apply(c, sc, sh, relu=True, res=res, res_scale=rs, res_shift=rh, sign_bits=sign_bits)
 
     def wgrad(self, x, dy, in_affine=None, out=None):
         aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
@@ -267,13 +268,16 @@ class BasicBlockFn(torch.autograd.Function):
                 st1, sts = ops.bn_stats_pair(c1, _bn_args(blk.bn1, True), cs, _bn_args(bn_sc, True))
             m1, i1, sc1, sh1 = st1 if st1 is not None else _bn_fwd_stats(c1, blk.bn1, training)
             ms, is_, scs, shs = sts if sts is not None else _bn_fwd_stats(cs, bn_sc, training)
-            c2, m2, i2, sc2, sh2, out = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1),
-                                                               res=cs, res_affine=(scs, shs))
-            ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_)
+            # the backward BatchNorm passes want only the SIGN of the block output (the ReLU mask): bn_apply leaves it as one
+            # byte per channel quad, 1/16 of the bytes those passes would read from `out`
+            c2, m2, i2, sc2, sh2, (out, bits) = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1),
+                                                                       res=cs, res_affine=(scs, shs), sign_bits=True)
+            ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, bits, wsc, gsc, cs, ms, is_)
         else:
             c1, m1, i1, sc1, sh1 = blk.spec1.fwd_bn(x, w1.detach(), blk.bn1, training)
-            c2, m2, i2, sc2, sh2, out = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1), res=x)
-            ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1)
+            c2, m2, i2, sc2, sh2, (out, bits) = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1),
+                                                                       res=x, sign_bits=True)
+            ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, bits)
         ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None
         ctx.slots = tuple(_slot(p) for p in (w1, g1, b1, w2, g2, b2, wsc, gsc, bsc))
         return out
@@ -282,19 +286,19 @@ class BasicBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         blk, tr = ctx.blk, ctx.training
         if ctx.has_sc:
-            x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, wsc, gsc, cs, ms, is_ = ctx.saved_tensors
+            x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, bits, wsc, gsc, cs, ms, is_ = ctx.saved_tensors
         else:
-            x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1 = ctx.saved_tensors
+            x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, bits = ctx.saved_tensors
         dout = dout.contiguous()
         hw = (x.shape[1], x.shape[2])
         s_w1, s_g1, s_b1, s_w2, s_g2, s_b2, s_ws, s_gs, s_bs = ctx.slots
         keep = lambda grad, slot: None if slot is not None else grad      # slotted gradients are already in place
         wview = lambda slot, w: None if slot is None else slot.view(w.shape)
         if ctx.has_sc:      # bn2 and the shortcut's BatchNorm see the same dout through the same mask: one pass for both
-            (dc2, dg2, db2), (dcs, dgs, dbs) = ops.bn_backward_pair(dout, out, (c2, g2, m2, i2, s_g2, s_b2),
-                                                                    (cs, gsc, ms, is_, s_gs, s_bs), tr)
+            (dc2, dg2, db2), (dcs, dgs, dbs) = ops.bn_backward_pair(dout, None, (c2, g2, m2, i2, s_g2, s_b2),
+                                                                    (cs, gsc, ms, is_, s_gs, s_bs), tr, mask_bits=bits)
         else:
-            dc2, dg2, db2 = ops.bn_backward(dout, out, c2, g2, m2, i2, tr, dgamma=s_g2, dbeta=s_b2)
+            dc2, dg2, db2 = ops.bn_backward(dout, None, c2, g2, m2, i2, tr, dgamma=s_g2, dbeta=s_b2, mask_bits=bits)
         dw2 = blk.spec2.wgrad(c1, dc2, in_affine=(sc1, sh1), out=wview(s_w2, w2))
         da1 = blk.spec2.dgrad(dc2, w2, (c1.shape[1], c1.shape[2]))
         dc1, dg1, db1 = ops.bn_backward(da1, None, c1, g1, m1, i1, tr, mask_affine=(sc1, sh1),   # mask = (bn1(c1) > 0)

@@ -397,21 +397,26 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
     return out[0], out[1], out[2], out[3]
 
 
-def bn_apply(x, scale, shift, relu=True, res=None, res_scale=None, res_shift=None):
+def bn_apply(x, scale, shift, relu=True, res=None, res_scale=None, res_shift=None, sign_bits=False):
+    """y = relu?(x*scale + shift [+ res [*res_scale + res_shift]]).  sign_bits=True: returns (y, bits) with one uint8 per
+    channel quad, bit i = (y[..., 4q + i] > 0): what bn_backward(mask_bits=) reads instead of y."""
     _lib.require_cuda(x)
     C = x.shape[-1]
     y = torch.empty_like(x)
+    bits = torch.empty(x.shape[:-1] + (C // 4,), dtype=torch.uint8, device=x.device) if sign_bits else None
     _lib.check(_lib.lib().dam_bn_apply_f32(_lib.ptr(x), x.numel() // C, C, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res),
                                            _lib.ptr(res_scale), _lib.ptr(res_shift), 1 if relu else 0, _lib.ptr(y),
-                                           _lib.stream()), 'dam_bn_apply_f32')
-    return y
+                                           _lib.ptr(bits), _lib.stream()), 'dam_bn_apply_f32')
+    return (y, bits) if sign_bits else y
 
 
-def bn_backward_pair(dy, y_mask, a, b, training=True):
+def bn_backward_pair(dy, y_mask, a, b, training=True, mask_bits=None):
     """bn_backward for two BatchNorms fed by the same dy through the same ReLU mask (a residual block's bn2 and its shortcut
     BatchNorm): three launches instead of six, dy / y_mask read once per pass.  a, b = (x, gamma, save_mean, save_invstd,
     dgamma or None, dbeta or None).  Returns ((dx, dgamma, dbeta), (dx, dgamma, dbeta)), bitwise equal to two bn_backward calls."""
-    _lib.require_cuda(dy, y_mask, a[0], b[0])
+    _lib.require_cuda(dy, a[0], b[0])
+    if (y_mask is None) == (mask_bits is None):
+        raise ValueError('exactly one of y_mask / mask_bits')
     C = a[0].shape[-1]
     if b[0].shape != a[0].shape or dy.shape != a[0].shape:
         raise ValueError('the two BatchNorms of a pair see the same shape')
@@ -426,12 +431,14 @@ def bn_backward_pair(dy, y_mask, a, b, training=True):
     args = []
     for (x, gamma, mean, invstd, _, _), (dx, dgamma, dbeta) in zip((a, b), outs):
         args += [_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta)]
-    _lib.check(L.dam_bn_backward_pair_f32(_lib.ptr(dy), _lib.ptr(y_mask), dy.numel() // C, C, 1 if training else 0, *args,
+    _lib.check(L.dam_bn_backward_pair_f32(_lib.ptr(dy), _lib.ptr(y_mask), _lib.ptr(mask_bits), dy.numel() // C, C,
+                                          1 if training else 0, *args,
                                           _lib.ptr(ws), _lib.stream()), 'dam_bn_backward_pair_f32')
     return outs[0], outs[1]
 
 
-def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mask_affine=None, dgamma=None, dbeta=None):
+def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mask_affine=None, dgamma=None, dbeta=None,
+                mask_bits=None):
     """Returns (dx, dgamma, dbeta) for y = [relu](bn(x) + ...).  The ReLU mask comes from y_mask (the saved output), or --
     for a plain relu(bn(x)) -- from mask_affine=(scale, shift), the forward's fused affine (the saved output is not read),
     or there is none (both None)."""
@@ -448,7 +455,7 @@ def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mas
     _lib.check(_lib.lib().dam_bn_backward_f32(_lib.ptr(dy), _lib.ptr(y_mask), _lib.ptr(x), x.numel() // C, C, _lib.ptr(gamma),
                                               _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
                                               _lib.ptr(mask_affine[0]) if mask_affine else None,
-                                              _lib.ptr(mask_affine[1]) if mask_affine else None, _lib.ptr(dx),
+                                              _lib.ptr(mask_affine[1]) if mask_affine else None, _lib.ptr(mask_bits), _lib.ptr(dx),
                                               _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
                                               _lib.ptr(arrival_counter(x.device)), _lib.stream()),
                'dam_bn_backward_f32')

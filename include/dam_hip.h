@@ -231,27 +231,30 @@ int dam_bn_eval_affine_f32(int C, const float* gamma, const float* beta, const f
                            const float* running_var, float eps, float* save_mean, float* save_invstd,
                            float* scale, float* shift, void* stream);
 
-/* y = relu?( x*scale + shift  [+ res]  or  [+ res*res_scale + res_shift] ). */
+/* y = relu?( x*scale + shift  [+ res]  or  [+ res*res_scale + res_shift] ).
+ * sign_bits (optional, n_pixels * C/4 bytes): one byte per channel quad, bit i = (y[4q + i] > 0) -- the ReLU mask the
+ * backward passes need from the block output, in 1/16 of its bytes (mask_bits of dam_bn_backward*_f32). */
 int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const float* scale, const float* shift,
                      const float* res, const float* res_scale, const float* res_shift, int relu, float* y,
-                     void* stream);
+                     uint8_t* sign_bits, void* stream);
 
 /* Backward of y = [relu](bn(x) [+ ...]): dz = dy * mask, where mask is (y_mask > 0) if y_mask (the saved output) is given,
- * (x*mask_scale + mask_shift > 0) if the forward's fused affine is given instead (plain relu(bn(x)): the saved output is
- * then not read at all), 1 if both are NULL;
+ * the sign bytes dam_bn_apply_f32 wrote if mask_bits is given, (x*mask_scale + mask_shift > 0) if the forward's fused affine
+ * is given instead (plain relu(bn(x)): the saved output is then not read at all), 1 if all are NULL (at most one form);
  * dgamma = sum dz*xhat, dbeta = sum dz, dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
  * (training) or gamma*invstd*dz (training == 0, running statistics). */
 int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
                         const float* gamma, const float* save_mean, const float* save_invstd, int training,
-                        const float* mask_scale, const float* mask_shift, float* dx, float* dgamma, float* dbeta,
-                        float* workspace, uint32_t* counter, void* stream);
+                        const float* mask_scale, const float* mask_shift, const uint8_t* mask_bits, float* dx,
+                        float* dgamma, float* dbeta, float* workspace, uint32_t* counter, void* stream);
 
-/* The same for TWO BatchNorms that share dy and y_mask -- a residual block's bn2 and the BatchNorm of its shortcut
+/* The same for TWO BatchNorms that share dy and the mask (exactly one of y_mask / mask_bits) -- a residual block's bn2 and the BatchNorm of its shortcut
  * convolution, both fed by the gradient of relu(bn2(..) + bn_sc(..)) (models/model_resnet.py:23-28): dy and the mask are
  * read once per pass instead of twice, three launches instead of six; bitwise the results of two dam_bn_backward_f32 calls.
  * workspace: dam_bn_pair_workspace_floats(C) floats. */
 int64_t dam_bn_pair_workspace_floats(int C);
-int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, int64_t n_pixels, int C, int training,
+int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, const uint8_t* mask_bits, int64_t n_pixels, int C,
+                             int training,
                              const float* x_a, const float* gamma_a, const float* mean_a, const float* invstd_a,
                              float* dx_a, float* dgamma_a, float* dbeta_a,
                              const float* x_b, const float* gamma_b, const float* mean_b, const float* invstd_b,

@@ -89,3 +89,29 @@ def test_stats_pair_is_bitwise_two_single_calls(ops):
                 assert torch.equal(a, b)
         for p, q in zip(pa, pb):                 # running statistics and the batch counter moved the same way
             assert torch.equal(p[2], q[2]) and torch.equal(p[3], q[3]) and int(p[4]) == int(q[4]) == 1
+
+
+def test_sign_bytes_equal_the_float_mask(ops):
+    """bn_apply(sign_bits=True) + bn_backward(mask_bits=) / bn_backward_pair(mask_bits=): bitwise the y_mask forms."""
+    g = torch.Generator().manual_seed(8)
+    for shape in [(3, 37, 29, 32), (2, 9, 5, 256)]:
+        C = shape[-1]
+        x, res = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+        sc, sh = torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda()
+        y = ops.bn_apply(x, sc, sh, relu=True, res=res)
+        y2, bits = ops.bn_apply(x, sc, sh, relu=True, res=res, sign_bits=True)
+        assert torch.equal(y, y2) and bits.shape == shape[:-1] + (C // 4,)
+        want = (y.view(*shape[:-1], C // 4, 4) > 0).to(torch.uint8)
+        want = want[..., 0] | (want[..., 1] << 1) | (want[..., 2] << 2) | (want[..., 3] << 3)
+        assert torch.equal(bits, want)
+        dy = torch.randn(shape, generator=g).cuda()
+        xs = [torch.randn(shape, generator=g).cuda() for _ in range(2)]
+        par = [(torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda(), torch.rand(C, generator=g).cuda() + 0.5)
+               for _ in range(2)]
+        a = ops.bn_backward(dy, y, xs[0], *par[0], True)
+        b = ops.bn_backward(dy, None, xs[0], *par[0], True, mask_bits=bits)
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+        pa = ops.bn_backward_pair(dy, y, (xs[0], *par[0], None, None), (xs[1], *par[1], None, None), True)
+        pb = ops.bn_backward_pair(dy, None, (xs[0], *par[0], None, None), (xs[1], *par[1], None, None), True, mask_bits=bits)
+        for s, t in zip(pa, pb):
+            assert all(torch.equal(p, q) for p, q in zip(s, t))
