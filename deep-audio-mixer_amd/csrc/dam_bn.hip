@@ -608,7 +608,7 @@ inline int elt_blocks(int64_t n) {
 
 using namespace dam;
 
-extern "C" int64_t dam_bn_workspace_floats(int C) { return (int64_t)BN_MAX_PARTS * C * 3; }
+extern "C" int64_t dam_bn_workspace_floats(int C) { return (int64_t)BN_RECORDS_MAX * C * 3; }
 
 extern "C" int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -644,7 +644,7 @@ extern "C" int dam_bn_stats_pair_f32(const float* x_a, const float* x_b, int64_t
     if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
     const BnLaunch l = bn_plan(n_pixels, C);
     hipStream_t st = (hipStream_t)stream;
-    float* ws_b = workspace + (size_t)BN_MAX_PARTS * C * 3;
+    float* ws_b = workspace + (size_t)BN_RECORDS_MAX * C * 3;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(l.parts, 2), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st, x_a,
                        n_pixels, C, l.q, l.r, l.ppb, workspace, BnFinArgs{}, x_b, ws_b);
     DAM_CHECK_LAUNCH();

@@ -557,7 +557,10 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     // thick 3x3 layers: the persistent variant whose patches are staged chunk by chunk by loader waves beside the MFMAs
     // (DAM_NO_PIPE: diagnostic switch for the A/B in tools/pipe_ab.sh)
     if (!getenv("DAM_NO_PIPE")) {
-        const int rc = conv_pipe_try(g, h_hi - h_lo, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st);
+        int parts = 0;
+        const int rc = conv_pipe_try(g, h_hi - h_lo, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace,
+                                     fin.counter ? nullptr : bn_partial, &parts, st);
+        if (rc == DAM_OK && bn_partial && bn_parts_host) *bn_parts_host = parts;
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }
     // tile choice.  With a workspace: keep big tiles (weights are streamed per workgroup: FLOPs per weight byte grow with

@@ -26,6 +26,7 @@
 #include "dam_common.h"
 #include "dam_conv_geo.h"
 #include "dam_conv_stage.h"
+#include "dam_bn_fin.h"
 
 namespace dam {
 namespace {
@@ -84,13 +85,15 @@ __device__ __forceinline__ PipeUnit pipe_decode(const ConvGeo& g, int unit, int 
 
 // The second launch bound is the register budget (waves per SIMD): without it the compiler hoists every loop-invariant address
 // of the loader's 16 segments into registers (198 VGPRs, one workgroup per CU).
-template <int MB, int NB, int PIPE_U>
+// STATS: the launch also emits BatchNorm partial statistics (a separate instantiation: the epilogue code costs every launch
+// 1-2 us through register allocation even when it does not run).
+template <int MB, int NB, int PIPE_U, bool STATS>
 __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g, const int nunits, const float* __restrict__ X,
                                                                  const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                                  const float* __restrict__ in_scale,
                                                                  const float* __restrict__ in_shift, float* __restrict__ Y,
                                                                  const float* __restrict__ res, const float* __restrict__ res_mask,
-                                                                 float* __restrict__ stamps) {
+                                                                 float* __restrict__ stamps, float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -352,6 +355,22 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         }
 
         // ---- write the tile out (as conv_igemm_kernel): lane holds channels 4*kq..+3 of pixel j of every (mb, nb) block ----
+        // BatchNorm partial statistics of what this WAVE writes (optional), flushed below as one (n, mean, M2) record per
+        // channel, wave and unit -- no cross-wave step, so no extra barrier with the loaders.  The 16 pixel lanes of a channel
+        // share ONE shift (the value of the row's first lane: real data even behind the image's last pixel, whose lanes compute
+        // that pixel again), so the lanes' sum(v - shift) and sum((v - shift)^2) simply add: DPP row rotations, no LDS.
+        float st_k[NB][4], st_s1[NB][4], st_s2[NB][4];
+        float st_n = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float first = reinterpret_cast<const float*>(&acc[0][nb])[r] +
+                                    (bias ? bias[(cur.nb0 + nb) * 16 + kq * 4 + r] : 0.f);
+                st_k[nb][r] = STATS ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, first), 0x150, 0xF, 0xF, false))
+                                    : 0.f;                                     // row_newbcast:0 -- lane 0 of the row
+                st_s1[nb][r] = 0.f; st_s2[nb][r] = 0.f;
+            }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int p = cur.p0 + wave * MW + mb * 16 + j;
@@ -380,7 +399,45 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                 }
                 if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
+                if (STATS) {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d = e[r] - st_k[nb][r];
+                        st_s1[nb][r] += d;
+                        st_s2[nb][r] = fmaf(d, d, st_s2[nb][r]);
+                    }
+                }
             }
+            if (STATS) st_n += 1.f;
+        }
+        if (STATS) {
+            // row sums by rotation (ror 8, 4, 2, 1: every lane ends up with the total), then lane 0 of the row writes
+#define DAM_ROW_SUM(V_)                                                                                                     \
+    do {                                                                                                                    \
+        V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), 0x128, 0xF, 0xF, false)); \
+        V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), 0x124, 0xF, 0xF, false)); \
+        V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), 0x122, 0xF, 0xF, false)); \
+        V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), 0x121, 0xF, 0xF, false)); \
+    } while (0)
+            const size_t rec = ((size_t)cur.img * g.tiles_m + (cur.p0 / (64 * MB))) * 4 + wave;
+            float n = st_n;
+            DAM_ROW_SUM(n);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s1 = st_s1[nb][r], s2 = st_s2[nb][r];
+                    DAM_ROW_SUM(s1);
+                    DAM_ROW_SUM(s2);
+                    const int ch = (cur.nb0 + nb) * 16 + kq * 4 + r;
+                    if (j == 0 && ch < g.N) {
+                        const float md = n > 0.f ? s1 / n : 0.f;
+                        float* o = stats + (rec * g.N + ch) * 3;
+                        o[0] = n; o[1] = st_k[nb][r] + md; o[2] = n > 0.f ? fmaxf(s2 - s1 * md, 0.f) : 0.f;
+                    }
+                }
+#undef DAM_ROW_SUM
         }
         DAM_PSTAMP(0, 8);
         if (!has_next) break;
@@ -393,7 +450,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
 }
 
 // resident workgroups per launch: occupancy x CUs, asked once per instance and LDS size
-template <int MB, int NB, int PU>
+template <int MB, int NB, int PU, bool STATS>
 int pipe_slots(size_t lds) {
     static int cus = 0;
     static size_t cached_lds = ~(size_t)0;
@@ -405,7 +462,7 @@ int pipe_slots(size_t lds) {
     }
     if (cached_lds != lds) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_pipe_kernel<MB, NB, PU>), PIPE_THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_pipe_kernel<MB, NB, PU, STATS>), PIPE_THREADS,
                                                          lds) != hipSuccess || per_cu < 1)
             per_cu = 1;
         cached = per_cu * cus;
@@ -416,14 +473,25 @@ int pipe_slots(size_t lds) {
 
 template <int MB, int NB, int PU>
 int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
-                float* Y, const float* res, const float* res_mask, float* workspace, hipStream_t st) {
+                float* Y, const float* res, const float* res_mask, float* workspace, float* stats, int* stats_parts,
+                hipStream_t st) {
     const int nunits = g.tiles_m * (g.N / 16 / NB) * g.B;
-    int wgs = pipe_slots<MB, NB, PU>(lds);
+    // statistics records: one per (image tile, wave), each unit fills its own channels of it
+    if (stats) {
+        const int64_t parts = (int64_t)g.B * g.tiles_m * 4;
+        if (parts > BN_RECORDS_MAX) stats = nullptr;            // the caller runs the statistics pass instead
+        else if (stats_parts) *stats_parts = (int)parts;
+    }
+    int wgs = stats ? pipe_slots<MB, NB, PU, true>(lds) : pipe_slots<MB, NB, PU, false>(lds);
     if (const char* e = getenv("DAM_PIPE_WGS")) wgs = atoi(e);          // diagnostic
     if (wgs < 1) wgs = 1;
     if (wgs > nunits) wgs = nunits;
-    hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
-                       reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace);
+    if (stats)
+        hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, true>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
+                           reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats);
+    else
+        hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, false>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
+                           reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
@@ -435,7 +503,8 @@ int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
 // row_span = h_hi - h_lo of the tap grid.  The tile is chosen here: no split-K -- small tiles give this kernel its
 // workgroups, their patches are staged beside the MFMAs and cost the matrix pipe nothing.
 int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
-                  float* Y, const float* res, const float* res_mask, float* workspace, hipStream_t st) {
+                  float* Y, const float* res, const float* res_mask, float* workspace, float* stats, int* stats_parts,
+                  hipStream_t st) {
     if (g.nA != 3 || g.nB != 3 || g.in_nchw || g.nchunks < 2) return DAM_ERR_UNSUPPORTED;
     if ((size_t)g.H * g.W * g.C * 4 >= ((size_t)1 << 30)) return DAM_ERR_UNSUPPORTED;      // offsets of the range-checked loads
     const int64_t npix = (int64_t)g.Ho * g.Wo;
@@ -475,8 +544,8 @@ int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, cons
     const bool big = g.PR * g.PWin * 4 > PIPE_LT * 5;      // items per loader thread: 5 or 8
 #define DAM_PIPE_CASE(M_, N_)                                                                                              \
     if (MB == M_ && NB == N_)                                                                                              \
-        return big ? launch_pipe<M_, N_, 8>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, st)                  \
-                   : launch_pipe<M_, N_, 5>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, st)
+        return big ? launch_pipe<M_, N_, 8>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, st) \
+                   : launch_pipe<M_, N_, 5>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, st)
     DAM_PIPE_CASE(1, 4); DAM_PIPE_CASE(2, 2); DAM_PIPE_CASE(1, 2); DAM_PIPE_CASE(2, 1); DAM_PIPE_CASE(1, 1);
 #undef DAM_PIPE_CASE
     return DAM_ERR_UNSUPPORTED;

@@ -42,14 +42,14 @@ class ConvSpec:
         return ops.conv2d_fwd(x, self.packed(w), self.cout, self.k, self.k, self.stride, self.pad, self.dil,
                               bias=bias, in_nchw=self.in_nchw)
 
-    def fwd_conv(self, x, w, bn, training, bias=None, in_affine=None):
+    def fwd_conv(self, x, w, bn, training, bias=None, in_affine=None, fuse_stats=True):
         """The convolution in front of a BatchNorm: (c, stats) with stats = (save_mean, save_invstd, scale, shift) when the
         conv launch produced the training-mode statistics itself (strip kernel epilogue), else None.  in_affine=(scale,
         shift): the input is relu(x*scale + shift), applied while the kernel loads x (the producer's BatchNorm + ReLU
         never materialised)."""
         wp = self.packed(w)
         aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
-        if training and not self.in_nchw:
+        if training and not self.in_nchw and fuse_stats:
             n16 = (self.cout + 15) // 16 * 16
             buf = ops.bn_partial_buffer(x.device, n16)
             c, parts, out4 = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
@@ -261,8 +261,10 @@ class BasicBlockFn(torch.autograd.Function):
         # fused affine themselves
         if wsc is not None:
             bn_sc = blk.shortcut[1]
-            c1, st1 = blk.spec1.fwd_conv(x, w1.detach(), blk.bn1, training)
-            cs, sts = blk.spec_sc.fwd_conv(x, wsc.detach(), bn_sc, training)
+            # (no statistics from these two launches: the pair pass below is one launch sequence for both tensors, a
+            # fused epilogue on conv1 alone would leave the shortcut's statistics a pass of their own)
+            c1, st1 = blk.spec1.fwd_conv(x, w1.detach(), blk.bn1, training, fuse_stats=False)
+            cs, sts = blk.spec_sc.fwd_conv(x, wsc.detach(), bn_sc, training, fuse_stats=False)
             if st1 is None and sts is None and training and c1.shape == cs.shape:
                 # two independent BatchNorms over tensors of one shape, ready together: one statistics pass for both
                 st1, sts = ops.bn_stats_pair(c1, _bn_args(blk.bn1, True), cs, _bn_args(bn_sc, True))

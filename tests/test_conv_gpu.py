@@ -302,3 +302,23 @@ def test_deferred_weight_gradient_reductions(ops):
     ops.wgrad_flush()                                       # idempotent
     with pytest.raises(ValueError):
         ops.conv2d_wgrad(*calls[0], defer=True)
+
+
+@pytest.mark.parametrize('B,C,H,W,s,Co', [(2, 96, 21, 17, 1, 96), (3, 128, 13, 9, 1, 128), (2, 256, 9, 5, 1, 256),
+                                          (2, 64, 24, 20, 2, 96), (2, 64, 20, 33, 1, 64)])
+def test_loader_wave_kernel_statistics_epilogue(ops, B, C, H, W, s, Co):
+    """conv_pipe_kernel's per-wave BatchNorm records (with the fused input affine in front, as conv2 of a block runs it),
+    merged by dam_bn_finalize_f32, against the two-pass statistics of the float64 convolution; mean far from zero."""
+    g = torch.Generator().manual_seed(C + W + s)
+    x = torch.randn(B, C, H, W, generator=g) * 3 + 7
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    want = F.conv2d(x.double(), w.double(), None, s, 1)
+    buf = ops.bn_partial_buffer(torch.device('cuda'), Co)
+    y, parts = ops.conv2d_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), Co, 3, 3, s, 1, 1, bn_partial=buf)
+    close(nchw(y), want)
+    assert parts > 0, 'this shape is expected to take the loader-wave kernel with its statistics epilogue'
+    gamma, beta = torch.rand(Co, device='cuda') + 0.5, torch.randn(Co, device='cuda')
+    mean, invstd, scale, shift = ops.bn_finalize(buf, parts, gamma, beta, None, None, None, 0.1, 1e-5)
+    wm, wv = want.mean((0, 2, 3)), want.var((0, 2, 3), unbiased=False)
+    assert (mean.double().cpu() - wm).abs().max() <= 1e-5 * wm.abs().max()
+    assert ((invstd.double().cpu() - 1 / (wv + 1e-5).sqrt()).abs() * (wv + 1e-5).sqrt()).max() <= 2e-5
