@@ -185,4 +185,5 @@ class TrainStep:
             w0.wait()
             g[2].replay()
         self._steps_run += 1
+        ops.params_changed()        # parameters / running statistics moved (a graph replay runs none of the Python above)
         return self.loss

@@ -162,7 +162,8 @@ class FoldedConvBn:
     """Inference form of conv -> BatchNorm2d(eval): the running statistics are constants, so the BatchNorm's scale goes
     into the weights and its shift (plus the scaled convolution bias) into the bias of ONE convolution launch whose epilogue
     also adds the shortcut and applies the ReLU (`ops.conv2d_fwd(res=, relu_out=)`) -- no BatchNorm kernel, no weight
-    re-packing per forward.  Built lazily, rebuilt when a tensor it was folded from has changed (tensor version counters)."""
+    re-packing per forward.  Built lazily, rebuilt when a tensor it was folded from has changed: torch's version counters
+    for torch-side writes, ops.PARAM_EPOCH for the in-place updates of this library's own kernels (Adam, running statistics)."""
 
     def __init__(self, spec, conv, bn):
         self.spec, self.conv, self.bn = spec, conv, bn
@@ -176,7 +177,7 @@ class FoldedConvBn:
         return [t for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None]
 
     def get(self):
-        key = tuple((t.data_ptr(), t._version) for t in self._tensors())
+        key = (ops.PARAM_EPOCH,) + tuple((t.data_ptr(), t._version) for t in self._tensors())
         if key != self._key:
             bn, conv = self.bn, self.conv
             with torch.no_grad():
@@ -531,6 +532,8 @@ class MixingNet(nn.Module):
         return []
 
     def _pack_weights(self):
+        if self.training:
+            ops.params_changed()        # this forward's statistics passes move the BatchNorm running buffers
         if getattr(self, '_packer', None) is None:
             pairs = self.conv_pairs()
             self._packer = WeightPacker(pairs) if pairs else False

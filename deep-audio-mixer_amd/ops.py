@@ -263,6 +263,18 @@ def side_stream_join(device=None):
         _side_dirty.discard(key)
 
 
+# Parameters and BatchNorm running statistics are updated IN PLACE by kernels of this library (the fused Adam launch, the
+# statistics finalize), possibly inside a replayed hipGraph: torch's tensor version counters do not see that.  Whatever
+# caches something derived from them (layers.FoldedConvBn) keys on this counter too; it is bumped by every training forward
+# (the statistics finalize updates the running buffers), every optimizer launch and every graph replay of a step.
+PARAM_EPOCH = 0
+
+
+def params_changed():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
+
 _wgrad_queues = {}      # device -> [ctypes buffer of the library's queue, calls recorded since the last flush]
 
 

@@ -181,6 +181,7 @@ class Adam(torch.optim.Optimizer):
         if self._flat.is_cuda:
             ops.side_stream_join(self._flat.device)
             ops.wgrad_flush(self._flat.device)
+        ops.params_changed()
         h = self._hyper_tuple()
         ops.adam_l2_step(self._flat, self._grad, self._exp_avg, self._exp_avg_sq, self._step, self._derived, h[0], h[1],
                          h[2], h[3], h[4], h[5], hyper=self._hyper)

@@ -263,3 +263,17 @@ def test_folded_inference_path(dam, name, shape):
     folded2, plain2 = both()
     assert rel_err(folded2.cpu().numpy(), plain2.cpu().numpy()) <= 2e-5
     assert rel_err(folded2.cpu().numpy(), folded.cpu().numpy()) > 1e-4      # the update was seen
+    # updates made by this library's own kernels (fused Adam over the flat buffer, running statistics from the statistics
+    # finalize) do not move torch's version counters: the folded images must follow them too
+    from deep_audio_mixer_amd.optim import Adam
+    opt = Adam(model.parameters(), lr=1e-2)
+    model.train()
+    for _ in range(2):
+        opt.zero_grad()
+        loss = model.forward_mse(xc, torch.from_numpy(gt).cuda())[0]
+        loss.backward()
+        opt.step()
+    model.eval()
+    folded3, plain3 = both()
+    assert rel_err(folded3.cpu().numpy(), plain3.cpu().numpy()) <= 2e-5
+    assert rel_err(folded3.cpu().numpy(), folded2.cpu().numpy()) > 1e-4
