@@ -98,7 +98,11 @@ class SongMixer:
             ops.mixdown_peak_normalize(self.pcm, smooth, normalize=self.normalize, out=self.out, workspace=self.ws)
 
     def _model_key(self):
-        return (self.model.training,) + tuple(t.data_ptr() for t in self.model.state_dict(keep_vars=True).values())
+        # the captured forward holds the FOLDED conv + BatchNorm images (layers.FoldedConvBn), computed when it was captured:
+        # any change of the parameters or running statistics -- torch-side (version counters) or by this library's own
+        # in-place kernels (ops.PARAM_EPOCH) -- needs a new capture, not just a replay
+        return (self.model.training, ops.PARAM_EPOCH) + tuple(
+            (t.data_ptr(), t._version) for t in self.model.state_dict(keep_vars=True).values())
 
     def launch(self):
         """Runs the device pipeline on whatever is in self.pcm (graph replay when the model is in eval mode)."""

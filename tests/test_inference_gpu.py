@@ -178,6 +178,16 @@ def test_c5_full_song_matches_oracle(dam):
     m32, _, _ = inference_utils.mix_song_to_master(d, model, tracks, chunk_length=chunk_length, sr=sr, dtype=np.float32)
     assert m32.dtype == np.float32
     np.testing.assert_allclose(m32, want, rtol=2e-4, atol=4e-6)
+    # the captured forward holds folded conv + BatchNorm images: a parameter update must lead to a new capture, not a replay
+    # of the old weights
+    g_old = next(iter(inference_utils._mixers.values())).graph
+    with torch.no_grad():
+        for p in model._heads.parameters():
+            p.mul_(1.05)
+        model.layer6[1].conv2.weight.mul_(1.05)
+    _, raw_u, _ = inference_utils.mix_song_to_master(d, model, tracks, chunk_length=chunk_length, sr=sr, dtype=np.float32)
+    assert next(iter(inference_utils._mixers.values())).graph is not g_old
+    assert not np.allclose(raw_u['s3'], raw_m['s3'], rtol=1e-4)
     inference_utils._mixers.clear()
 
 
