@@ -589,6 +589,295 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Row-streaming variant for 3x3 / stride 2 / pad 1 (the first convolution of a down-sampling block,
+// models/model_resnet.py:18-21 of the reference): the same workgroup shape, rings, slabs and reduce kernel as
+// wgrad_rows_kernel, with the X rows kept as two column-parity planes so that all three column taps stay "dY cell + constant":
+//
+//   * X ring row = [odd plane | even plane], P4 cells of 16 channels each: odd cell e holds input column 2e-1 (cell 0 = the
+//     left padding column), even cell e holds column 2e.  Output column ow reads tap 0 at odd cell ow, tap 1 at even cell ow
+//     and tap 2 at odd cell ow+1; the dY ring row holds output column e in cell e (pitch P4 as well).
+//   * Output row r reads X rows 2r-1, 2r, 2r+1.  A slot of RPS output rows brings in the 2*RPS rows 2r, 2r+1 of its output
+//     rows (row 2*r_begin-1 comes with slot 0), so the X ring holds 2*RPS+1 rows in use + 2*RPS being written.
+//   * one 16-channel chunk of X per workgroup (TKB = 1): the ring of two chunks does not fit beside the dY ring.
+struct RowsS2Geo {
+    int B, H, W, C;          // X
+    int Ho, Wo, N;           // dY
+    int rps, spi;            // output rows per strip (multiple of the slot's rows), strips per image
+    int tiles_k;             // in-channel tiles (= chunks)
+};
+template <> __device__ __forceinline__ int rw_mod<18>(int v) { return v - ((v * 58255) >> 20) * 18; }     // v < 36000
+
+// HV as in wgrad_rows_kernel; GPPX / GPPD: 1 KB pieces per X row plane (both parities) / dY row plane; KP planes per loader wave
+template <int TNB, int STEPS, int KP, int GPPX, int GPPD, int HV>
+__global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2Geo g, const float* __restrict__ X,
+                                                                   const float* __restrict__ dY, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBLK = TNB * 9;
+    constexpr int RPS = 4 / HV, NRX = 4 * RPS + 2, NRD = 2 * RPS;
+    constexpr int P4 = STEPS * 4 * HV;
+    constexpr int XROWB = 2 * P4 * 64, DROWB = P4 * 64;
+    constexpr int XPLANE = NRX * XROWB, DPLANE = NRD * DROWB;
+    constexpr int XBASE = RW_GUARD, DBASE = XBASE + XPLANE;
+    constexpr int lds_bytes = DBASE + TNB * DPLANE + RW_TAIL;
+    constexpr int NXP = 2 * RPS;                      // X planes a slot brings in
+    constexpr int GPP = GPPX > GPPD ? GPPX : GPPD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int tn = blockIdx.x / g.tiles_k, tk = blockIdx.x - tn * g.tiles_k;
+    const int img = blockIdx.y / g.spi, r_begin = (blockIdx.y - img * g.spi) * g.rps;
+    const int r_end = r_begin + g.rps < g.Ho ? r_begin + g.rps : g.Ho;
+    const int n_slots = (r_end - r_begin + RPS - 1) / RPS;
+    const int n_slots2 = (n_slots + 1) & ~1;
+
+#define DAM_RW_ZERO()                                                                                                      \
+    do {                                                                                                                   \
+        for (int e = tid * 16; e < lds_bytes; e += RW_THREADS * 16)                                                        \
+            *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                    \
+    } while (0)
+
+    v4f acc[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    if (wave >= 4) {
+        // ================================ loader waves ================================
+        // plane cwl + 8k of a slot: the first NXP are X rows, the rest dY (row, out-channel block) planes -- which kind a
+        // (wave, k) pair carries never changes, so the per-lane column offsets and write masks are set up once per k
+        const int cwl = wave - 4;
+        int loffb[KP][GPP];
+        unsigned long long cmask[KP][GPP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const bool isx = cwl + RW_LOADERS * k < NXP;
+#pragma unroll
+            for (int gi = 0; gi < GPP; ++gi) {
+                const int L = gi * 64 + lane, e = L >> 2, quad = L & 3;
+                const int col = isx ? (e < P4 ? 2 * e - 1 : 2 * (e - P4)) : e;
+                const int lim = isx ? g.W : g.Wo, cells = isx ? 2 * P4 : P4;
+                const bool ok = e < cells && col >= 0 && col < lim;
+                const int colc = col < 0 ? 0 : (col >= lim ? lim - 1 : col);
+                loffb[k][gi] = (colc * (isx ? g.C : g.N) + quad * 4) * 4;
+                cmask[k][gi] = __ballot(ok);
+            }
+        }
+        const int ximg_bytes = g.H * g.W * g.C * 4, dimg_bytes = g.Ho * g.Wo * g.N * 4;
+        const __amdgpu_buffer_rsrc_t xrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + (size_t)img * g.H * g.W * g.C, 0, ximg_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t drsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY) + (size_t)img * g.Ho * g.Wo * g.N, 0, dimg_bytes, 0x00020000);
+        const int lane16 = lane * 16;
+        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+        const int xrowstride = g.W * g.C * 4, drowstride = g.Wo * g.N * 4;
+        const int x_first = 2 * r_begin - 1, x_last = 2 * r_end - 1;            // X rows this strip reads
+        v4f lv[KP][GPP], lv2[KP][GPP], lvb[GPPX];
+        int dst[KP], dst2[KP], dstb;   // scalar: LDS byte offset of the plane | 1 << 30 (row outside the image: zeros), -1 = none
+        // X rows XR0_ .. XR0_+NXP-1, then dY rows DR0_ .. DR0_+RPS-1 (TNB planes each).  Loads are unconditional (clamped).
+#define DAM_RW2_REQUEST(XR0_, DR0_, LV_, DST_)                                                                             \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
+            const int pl_ = cwl + RW_LOADERS * k;                                                                          \
+            const bool isx_ = pl_ < NXP;                                                                                   \
+            const int q_ = isx_ ? pl_ : pl_ - NXP;                                                                         \
+            const int i_ = isx_ ? q_ : q_ / TNB, c_ = isx_ ? 0 : q_ - i_ * TNB;                                            \
+            const int row_ = (isx_ ? (XR0_) : (DR0_)) + i_;                                                                \
+            const bool need_ = isx_ ? row_ <= x_last : (i_ < RPS && row_ < r_end);                                         \
+            const bool inimg_ = need_ && row_ >= 0 && row_ < (isx_ ? g.H : g.Ho);                                          \
+            const int xi_ = rw_mod<NRX>(isx_ ? row_ - x_first : 0);                                                        \
+            const int di_ = (row_ - r_begin) & (NRD - 1);                                                                  \
+            const int ldsoff_ = isx_ ? XBASE + xi_ * XROWB : DBASE + c_ * DPLANE + di_ * DROWB;                            \
+            const int soff_ = (inimg_ ? row_ : 0) * (isx_ ? xrowstride : drowstride) + (isx_ ? tk * 64 : (tn * TNB + c_) * 64); \
+            if (isx_) {                                                                                                    \
+                _Pragma("unroll") for (int gi = 0; gi < GPPX; ++gi)                                                        \
+                    LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[k][gi], soff_, 0)); \
+            } else {                                                                                                       \
+                _Pragma("unroll") for (int gi = 0; gi < GPPD; ++gi)                                                        \
+                    LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(drsrc, loffb[k][gi], soff_, 0)); \
+            }                                                                                                              \
+            DST_[k] = need_ ? (ldsoff_ | (inimg_ ? 0 : 1 << 30) | (isx_ ? 1 << 29 : 0)) : -1;                              \
+        }                                                                                                                  \
+    } while (0)
+#define DAM_RW2_WRITE(ADDR_, DATA_, MASK_, GI_)                                                                            \
+    asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
+                 : : "v"(ADDR_), "v"(DATA_), "s"(MASK_), "n"((GI_) * 1024) : "memory")
+#define DAM_RW2_COMMIT(LV_, DST_)                                                                                          \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
+            if (DST_[k] >= 0) {                                                                                            \
+                const int va_ = lane16 + (DST_[k] & 0x1fffffff);                                                           \
+                const bool zero_ = (DST_[k] >> 30) & 1;                                                                    \
+                if ((DST_[k] >> 29) & 1) {                                                                                 \
+                    _Pragma("unroll") for (int gi = 0; gi < GPPX; ++gi) {                                                  \
+                        const v4f v_ = zero_ ? zero4 : LV_[k][gi];                                                         \
+                        DAM_RW2_WRITE(va_, v_, cmask[k][gi], gi);                                                          \
+                    }                                                                                                      \
+                } else {                                                                                                   \
+                    _Pragma("unroll") for (int gi = 0; gi < GPPD; ++gi) {                                                  \
+                        const v4f v_ = zero_ ? zero4 : LV_[k][gi];                                                         \
+                        DAM_RW2_WRITE(va_, v_, cmask[k][gi], gi);                                                          \
+                    }                                                                                                      \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
+        // slot 0: X rows 2*r_begin .. +NXP-1 and dY rows r_begin .. +RPS-1 like every slot, plus X row 2*r_begin-1 (loader
+        // wave 0, whose k = 0 plane is an X plane: its offsets and masks apply)
+        DAM_RW2_REQUEST(2 * r_begin, r_begin, lv, dst);
+        {
+            const bool inimg = x_first >= 0;
+            const int soff = (inimg ? x_first : 0) * xrowstride + tk * 64;
+#pragma unroll
+            for (int gi = 0; gi < GPPX; ++gi)
+                lvb[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[0][gi], soff, 0));
+            dstb = cwl == 0 ? (XBASE | (inimg ? 0 : 1 << 30)) : -1;
+        }
+        DAM_RW_ZERO();
+        DAM_RW2_COMMIT(lv, dst);
+        if (dstb >= 0) {
+            const int va = lane16 + (dstb & 0x1fffffff);
+#pragma unroll
+            for (int gi = 0; gi < GPPX; ++gi) {
+                const v4f v = (dstb >> 30) & 1 ? zero4 : lvb[gi];
+                DAM_RW2_WRITE(va, v, cmask[0][gi], gi);
+            }
+        }
+        // steady state as in wgrad_rows_kernel: slot s writes the rows of slot s+1 and requests those of slot s+3
+#define DAM_RW2_SLOT(T_, LV_, DST_) DAM_RW2_REQUEST(2 * (r_begin + RPS * (T_)), r_begin + RPS * (T_), LV_, DST_)
+        DAM_RW2_SLOT(1, lv, dst);
+        DAM_RW2_SLOT(2, lv2, dst2);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int s = 0; s < n_slots2; s += 2) {
+            DAM_RW2_COMMIT(lv, dst);
+            DAM_RW2_SLOT(s + 3, lv, dst);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            DAM_RW2_COMMIT(lv2, dst2);
+            DAM_RW2_SLOT(s + 4, lv2, dst2);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+#undef DAM_RW2_SLOT
+#undef DAM_RW2_REQUEST
+#undef DAM_RW2_WRITE
+#undef DAM_RW2_COMMIT
+    } else {
+        // ================================ compute waves ================================
+        const int cw = wave;
+        const int lane_b = kq * 64 + j * 4;       // lane group kq owns cell 4t + kq of step t, lane j channel j of the cell
+        DAM_RW_ZERO();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS
+        for (int s = 0; s < n_slots2; ++s) {
+            const int rw = cw / HV, half = cw - rw * HV;                      // row of the slot, part of the row
+            const int r = r_begin + RPS * s + rw;
+            if (r < r_end) {
+                int vx[3], vd[TNB];
+                const int part = half * STEPS * 256;                          // byte offset of this wave's first cell
+#pragma unroll
+                for (int a = 0; a < 3; ++a)                                   // X row 2r - 1 + a, relative to 2*r_begin - 1
+                    vx[a] = lane_b + (XBASE + rw_mod<NRX>(2 * (RPS * s + rw) + a) * XROWB + part);
+#pragma unroll
+                for (int nb = 0; nb < TNB; ++nb)
+                    vd[nb] = lane_b + (DBASE + nb * DPLANE + ((RPS * s + rw) & (NRD - 1)) * DROWB + part);
+                float av[2][TNB], bv[2][9];
+                // column taps: odd-plane cell ow, even-plane cell ow, odd-plane cell ow + 1
+#define DAM_RW2_LOAD(T_, BUF_)                                                                                             \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                                 \
+            av[BUF_][nb] = *reinterpret_cast<const float*>(smem + vd[nb] + (T_) * 256);                                    \
+        _Pragma("unroll") for (int a = 0; a < 3; ++a) {                                                                    \
+            bv[BUF_][a * 3 + 0] = *reinterpret_cast<const float*>(smem + vx[a] + (T_) * 256);                              \
+            bv[BUF_][a * 3 + 1] = *reinterpret_cast<const float*>(smem + vx[a] + ((T_) * 256 + P4 * 64));                  \
+            bv[BUF_][a * 3 + 2] = *reinterpret_cast<const float*>(smem + vx[a] + ((T_) * 256 + 64));                       \
+        }                                                                                                                  \
+    } while (0)
+                DAM_RW2_LOAD(0, 0);
+#pragma unroll
+                for (int t = 0; t < STEPS; ++t) {
+                    if (t + 1 < STEPS) DAM_RW2_LOAD(t + 1, (t + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nb = 0; nb < TNB; ++nb)
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap)
+                            acc[nb * 9 + tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][nb], bv[t & 1][tap], acc[nb * 9 + tap], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef DAM_RW2_LOAD
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+#undef DAM_RW_ZERO
+
+    // combine the 4 compute waves through LDS (sequential adds: fixed order), one slab per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) {
+                float4* d4 = reinterpret_cast<float4*>(red + (i * 64 + lane) * 4);
+                if (w == 0) {
+                    *d4 = make_float4(acc[i].x, acc[i].y, acc[i].z, acc[i].w);
+                } else {
+                    float4 o = *d4;
+                    o.x += acc[i].x; o.y += acc[i].y; o.z += acc[i].z; o.w += acc[i].w;
+                    *d4 = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NBLK * 64;
+    for (int e = tid; e < NBLK * 64; e += RW_THREADS) out[e] = reinterpret_cast<const float4*>(red)[e];
+}
+
+template <int TNB, int STEPS, int KP, int GPPX, int GPPD, int HV>
+int launch_wgrad_rows_s2(int B, int H, int W, int C, int Ho, int Wo, int N, const float* X, const float* dY, float* partial,
+                         int64_t ws_floats, float* dw, int n_real, int k_real, void* queue, hipStream_t st) {
+    constexpr int NBLK = TNB * 9;
+    constexpr int RPS = 4 / HV, NRX = 4 * RPS + 2, NRD = 2 * RPS, P4 = STEPS * 4 * HV;
+    static_assert(NRX == 18 || NRX == 10, "ring sizes with a multiply-shift modulo");
+    static_assert((2 * RPS + RPS * TNB + RW_LOADERS - 1) / RW_LOADERS <= KP, "planes per loader wave");
+    static_assert(2 * P4 * 64 <= GPPX * 1024 && P4 * 64 <= GPPD * 1024, "pieces per plane");
+    if (Ho != (H - 1) / 2 + 1 || Wo != (W - 1) / 2 + 1) return DAM_ERR_UNSUPPORTED;
+    if (((Wo + 1 + 4 * HV - 1) / (4 * HV)) * (4 * HV) != P4) return DAM_ERR_UNSUPPORTED;
+    const int nblk = N / 16;
+    if (nblk % TNB || C % 16 || H >= 8000) return DAM_ERR_UNSUPPORTED;
+    if ((int64_t)H * W * C * 4 >= (1ll << 31) || (int64_t)Ho * Wo * N * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;
+    RowsS2Geo g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.N = N;
+    const int tiles_n = nblk / TNB;
+    g.tiles_k = C / 16;
+    const int nx = tiles_n * g.tiles_k;
+    size_t lds = RW_GUARD + (size_t)NRX * 2 * P4 * 64 + (size_t)TNB * NRD * P4 * 64 + RW_TAIL;
+    if (lds < (size_t)NBLK * 1024) lds = (size_t)NBLK * 1024;
+    if (lds > 160 * 1024) return DAM_ERR_UNSUPPORTED;
+    // strips as in launch_wgrad_rows: fill the chip once
+    auto strips = [&](int per_cu) { const int w = 256 * per_cu / (nx * B); return w > 0 ? w : 1; };
+    int spi = strips(1);
+    if (nx * B * spi < 205 && lds * 2 <= 160 * 1024) spi = strips(2);
+    if (spi > (int)cdiv(Ho, RPS)) spi = (int)cdiv(Ho, RPS);
+    for (;; --spi) {
+        g.rps = (int)cdiv(cdiv(Ho, spi), RPS) * RPS;
+        g.spi = (int)cdiv(Ho, g.rps);
+        if ((int64_t)B * g.spi * nx * NBLK * 256 <= ws_floats || spi == 1) break;
+    }
+    const int nsplit = B * g.spi;
+    if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_s2_kernel<TNB, STEPS, KP, GPPX, GPPD, HV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return DAM_ERR_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((wgrad_rows_s2_kernel<TNB, STEPS, KP, GPPX, GPPD, HV>), dim3(nx, nsplit), dim3(RW_THREADS), lds, st, g, X, dY,
+                       partial);
+    DAM_CHECK_LAUNCH();
+    return reduce_submit(queue, partial, dw, nsplit, nx, TNB, 1, 3, 3, n_real, k_real, 3, 3, 1, g.tiles_k, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Direct variant: nothing goes through LDS.  dW[n][k][a][b] = sum over output pixels of dY[p][n] * X[s*p + tap][k]; a
 // wave walks whole output rows, lane = (pixel 4t + kq, channel j), both MFMA operands are buffer loads (dword per lane,
 // 64-byte segments) straight from HBM / L2 -- every X element is wanted by at most KH*KW/s^2 taps and those re-reads are
@@ -795,6 +1084,19 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     }
     // strided 3x3 (the first convolution of a down-sampling block): measured 61/62/58 us against 80/78/67 us for the tile
     // kernel; for stride-1 narrow rows (17 pixels, 96 channels) it is slower (117 vs 60 us: nine L2 reads per element)
+    if (kh == 3 && kw == 3 && !in_nchw && !in_scale && stride == 2 && pad == 1 && dil == 1 && !getenv("DAM_WGR_S2_DIRECT")) {
+        // <TN, steps, planes per loader wave, pieces per X plane, per dY plane, row parts>: the down-sampling convolutions of
+        // the ResNet stages at 130 frames (65-, 33- and 17-pixel output rows) and at the reference's native 216 (54, 27)
+#define DAM_WGR2(...) launch_wgrad_rows_s2<__VA_ARGS__>(B, H, W, C, Ho, Wo, n_chan, x, dy, workspace, workspace_floats, dw, n_out, k_real, reduce_queue, st)
+        int rc = DAM_ERR_UNSUPPORTED;
+        if (Wo > 56) rc = DAM_WGR2(2, 9, 1, 9, 5, 2);
+        else if (Wo > 34) rc = DAM_WGR2(2, 7, 1, 7, 4, 2);
+        else if (Wo > 28) rc = DAM_WGR2(2, 9, 2, 5, 3, 1);
+        else if (Wo > 18) rc = DAM_WGR2(2, 7, 2, 4, 2, 1);
+        else if (Wo > 14) rc = DAM_WGR2(2, 5, 2, 3, 2, 1);
+#undef DAM_WGR2
+        if (rc != DAM_ERR_UNSUPPORTED) return rc;
+    }
     if (kh == 3 && kw == 3 && !in_nchw && !in_scale && Wo >= 16 && stride == 2) {
         int rc = DAM_WGD(2, 1, 3, 3);
         if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGD(1, 1, 3, 3);

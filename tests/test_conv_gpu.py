@@ -149,7 +149,25 @@ def test_wgrad_row_streaming_shapes(ops, B, C, H, W):
     close(got, want, 5e-5)
 
 
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 16, 32, 41, 130), (1, 16, 32, 24, 129), (2, 32, 64, 37, 65), (1, 32, 64, 20, 66),
+                                         (1, 64, 96, 33, 33), (2, 64, 96, 18, 34), (1, 32, 64, 11, 108), (1, 64, 96, 13, 54),
+                                         (8, 16, 32, 131, 130), (1, 64, 96, 3, 33), (1, 16, 32, 1, 130)])
+def test_wgrad_strided_row_streaming_shapes(ops, B, Ci, Co, H, W):
+    """3x3 / stride 2 / pad 1 weight gradient of the down-sampling convolutions (row-streaming kernel with column-parity
+    planes): odd and even heights and widths (bottom padding row / right padding column present or not), ragged strips,
+    strips of a single slot, the widths of the ResNet stages at 130 and 216 frames."""
+    g = torch.Generator().manual_seed(B * 1000 + Ci + H + W)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, Co, Ho, Wo, generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 3, 3), dy.double(), 2, 1)
+    got = ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), Co, 3, 3, 2, 1, 1)
+    assert got.shape == (Co, Ci, 3, 3)
+    close(got, want, 5e-5)
+
+
 @pytest.mark.parametrize('B,Ci,Co,H,W,k,s,p', [(2, 16, 32, 41, 65, 3, 2, 1), (1, 32, 64, 33, 34, 3, 2, 1), (2, 96, 96, 9, 17, 3, 1, 1),
+                                              (1, 16, 32, 9, 216, 3, 2, 1), (1, 16, 16, 21, 40, 3, 2, 1),
                                               (2, 16, 32, 41, 65, 1, 2, 0), (1, 64, 96, 21, 33, 1, 2, 0), (1, 48, 48, 20, 30, 3, 1, 1)])
 def test_wgrad_direct_kernel_shapes(ops, B, Ci, Co, H, W, k, s, p):
     """Weight gradient without LDS staging: strided 3x3, narrow-row 3x3 and 1x1 shortcut shapes (ragged row ends, padding

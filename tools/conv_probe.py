@@ -47,8 +47,8 @@ elif which in ('layer3_wgrad', 'layer4_wgrad', 'layer5_wgrad', 'layer6_wgrad'):
     x = torch.randn((B, hw[0], hw[1], c), device=dev)
     dy = torch.randn((B, hw[0], hw[1], c), device=dev)
     fn = lambda: ops.conv2d_wgrad(x, dy, c, 3, 3, 1, 1, 1)
-elif which in ('layer3s2_wgrad', 'layer4s2_wgrad', 'layer5s2_wgrad', 'layer6s2_wgrad'):
-    hw, ci, co = {'layer3s2_wgrad': ((513, 65), 32, 64), 'layer4s2_wgrad': ((257, 33), 64, 96),
+elif which in ('layer2s2_wgrad', 'layer3s2_wgrad', 'layer4s2_wgrad', 'layer5s2_wgrad', 'layer6s2_wgrad'):
+    hw, ci, co = {'layer2s2_wgrad': ((1025, 130), 16, 32), 'layer3s2_wgrad': ((513, 65), 32, 64), 'layer4s2_wgrad': ((257, 33), 64, 96),
                   'layer5s2_wgrad': ((129, 17), 96, 128), 'layer6s2_wgrad': ((65, 9), 128, 256)}[which]
     x = torch.randn((B, hw[0], hw[1], ci), device=dev)
     dy = torch.randn((B, (hw[0] + 1) // 2, (hw[1] + 1) // 2, co), device=dev)
