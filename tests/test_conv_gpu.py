@@ -151,7 +151,8 @@ def test_wgrad_row_streaming_shapes(ops, B, C, H, W):
 
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 16, 32, 41, 130), (1, 16, 32, 24, 129), (2, 32, 64, 37, 65), (1, 32, 64, 20, 66),
                                          (1, 64, 96, 33, 33), (2, 64, 96, 18, 34), (1, 32, 64, 11, 108), (1, 64, 96, 13, 54),
-                                         (8, 16, 32, 131, 130), (1, 64, 96, 3, 33), (1, 16, 32, 1, 130)])
+                                         (8, 16, 32, 131, 130), (1, 64, 96, 3, 33), (1, 16, 32, 1, 130),
+                                         (2, 96, 128, 65, 17), (1, 96, 128, 22, 18), (2, 128, 256, 33, 9), (1, 128, 256, 12, 10)])
 def test_wgrad_strided_row_streaming_shapes(ops, B, Ci, Co, H, W):
     """3x3 / stride 2 / pad 1 weight gradient of the down-sampling convolutions (row-streaming kernel with column-parity
     planes): odd and even heights and widths (bottom padding row / right padding column present or not), ragged strips,

@@ -61,6 +61,10 @@ elif which == 'bn':
     x = torch.randn((B, H, W, 16), device=dev)
     gam, bet = torch.ones(16, device=dev), torch.zeros(16, device=dev)
     fn = lambda: ops.bn_stats(x, gam, bet, None, None, None, 0.1, 1e-5)
+elif which == 'bn_apply':
+    x = torch.randn((B, H, W, 16), device=dev)
+    gam, bet = torch.ones(16, device=dev), torch.zeros(16, device=dev)
+    fn = lambda: ops.bn_apply(x, gam, bet, relu=True, sign_bits=True)
 elif which == 'stft':
     pcm = 0.1 * torch.randn((72, 132300, 2), device=dev)
     fn = lambda: features.stft_logmag(pcm, hop=1024)
