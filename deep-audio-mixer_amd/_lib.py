@@ -28,7 +28,7 @@ SIGNATURES = {
     'dam_conv_pack_weights_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'dam_conv_pack_weights_multi_f32': (c_i, [c_p, c_i, c_i64, c_p]),
     'dam_conv2d_tapgrid_f32': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p] +
-                               [c_i] * 17 + [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+                               [c_i] * 17 + [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     'dam_conv_batch_bytes': (c_i64, []),
     'dam_conv_batch_init': (c_i, [c_p]),
     'dam_conv_batch_flush': (c_i, [c_p, c_p]),
@@ -47,7 +47,7 @@ SIGNATURES = {
     'dam_bn_stats_pair_f32': (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p]),
     'dam_bn_pair_workspace_floats': (c_i64, [c_i]),
     'dam_bn_backward_pair_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i] + [c_p] * 16),
-    'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'dam_bn_backward_f32': (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     'dam_channel_sum_f32': (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
     'dam_dropout_tick': (c_i, [c_p, c_i64, c_p, c_p]),
     'dam_dropout_apply_f32': (c_i, [c_p, c_i64, c_f, ctypes.c_uint64, c_p, c_p, c_p]),
@@ -76,6 +76,11 @@ class BnFin(ctypes.Structure):
     _fields_ = [('gamma', c_p), ('beta', c_p), ('running_mean', c_p), ('running_var', c_p), ('num_batches_tracked', c_p),
                 ('momentum', c_f), ('eps', c_f), ('save_mean', c_p), ('save_invstd', c_p), ('scale', c_p), ('shift', c_p),
                 ('counter', c_p)]
+
+
+class BnBwdSums(ctypes.Structure):
+    """struct dam_bn_bwd_sums (include/dam_hip.h): BatchNorm-backward sums taken in a data-gradient epilogue."""
+    _fields_ = [('x', c_p), ('mean', c_p), ('invstd', c_p), ('mask_scale', c_p), ('mask_shift', c_p)]
 
 
 _lib = None

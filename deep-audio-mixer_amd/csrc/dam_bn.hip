@@ -697,14 +697,17 @@ extern "C" int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const f
 extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
                                    const float* gamma, const float* save_mean, const float* save_invstd, int training,
                                    const float* mask_scale, const float* mask_shift, const uint8_t* mask_bits, float* dx,
-                                   float* dgamma, float* dbeta, float* workspace, uint32_t* counter, void* stream) {
+                                   float* dgamma, float* dbeta, float* workspace, int partials_given, uint32_t* counter,
+                                   void* stream) {
     if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || n_pixels <= 0)
         return DAM_ERR_BAD_ARG;
     if ((mask_scale != nullptr) != (mask_shift != nullptr) || (y_mask && mask_scale) || (mask_bits && (y_mask || mask_scale)))
         return DAM_ERR_BAD_ARG;
     if (mask_bits) y_mask = reinterpret_cast<const float*>(mask_bits);       // MASK == 3 reads it as bytes
     if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
-    const BnLaunch l = bn_plan(n_pixels, C);
+    BnLaunch l = bn_plan(n_pixels, C);
+    if (partials_given < 0 || partials_given > BN_MAX_PARTS) return DAM_ERR_BAD_ARG;
+    if (partials_given) { l.parts = partials_given; counter = nullptr; }       // records from a data-gradient epilogue
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + (size_t)BN_MAX_PARTS * C * 2;    // workspace holds [parts][C][2] then [3][C]
     const int mask = mask_bits ? 3 : (y_mask ? 1 : (mask_scale ? 2 : 0));
@@ -712,7 +715,8 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
 #define DAM_BN_PARTIAL(M_)                                                                                                   \
     hipLaunchKernelGGL(bn_bwd_partial_kernel<M_>, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 2 * sizeof(float), st, dy, \
                        y_mask, x, n_pixels, C, l.q, l.r, l.ppb, save_mean, save_invstd, mask_scale, mask_shift, workspace, fin)
-    if (mask == 1) DAM_BN_PARTIAL(1); else if (mask == 2) DAM_BN_PARTIAL(2); else if (mask == 3) DAM_BN_PARTIAL(3); else DAM_BN_PARTIAL(0);
+    if (partials_given) { }
+    else if (mask == 1) DAM_BN_PARTIAL(1); else if (mask == 2) DAM_BN_PARTIAL(2); else if (mask == 3) DAM_BN_PARTIAL(3); else DAM_BN_PARTIAL(0);
 #undef DAM_BN_PARTIAL
     DAM_CHECK_LAUNCH();
     if (!counter) {

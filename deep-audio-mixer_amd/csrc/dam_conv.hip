@@ -494,10 +494,16 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
                                       int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                                       int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                                       const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
-                                      const dam_bn_fin* bn_fin, float* workspace, int64_t workspace_floats, void* batch,
-                                      void* stream) {
+                                      const dam_bn_fin* bn_fin, const dam_bn_bwd_sums* bn_bwd, float* workspace,
+                                      int64_t workspace_floats, void* batch, void* stream) {
     using namespace dam;
     if (bn_parts_host) *bn_parts_host = 0;
+    BnBwdEpi bwd{};
+    if (bn_bwd && bn_bwd->x) {
+        if (!bn_partial || !bn_parts_host || res || bn_fin || !bn_bwd->mean || !bn_bwd->invstd || !bn_bwd->mask_scale ||
+            !bn_bwd->mask_shift) return DAM_ERR_BAD_ARG;
+        bwd = BnBwdEpi{bn_bwd->x, bn_bwd->mean, bn_bwd->invstd, bn_bwd->mask_scale, bn_bwd->mask_shift};
+    }
     BnFinArgs fin{};
     if (bn_fin && bn_partial) {
         if (!bn_fin->gamma || !bn_fin->beta || !bn_fin->save_mean || !bn_fin->save_invstd || !bn_fin->scale || !bn_fin->shift ||
@@ -518,6 +524,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     g.off_h = off_h; g.step_h = step_h; g.off_w = off_w; g.step_w = step_w;
     g.wt_base = wt_base; g.wt_sa = wt_sa; g.wt_sb = wt_sb;
     g.in_nchw = in_nchw; g.relu_in = relu_in; g.relu_out = relu_out != 0; g.nchunks = k_chunks; g.NBtot = n_out / 16;
+    g.epi_bwd = 0;
     const int h_lo = off_h + (step_h < 0 ? (nA - 1) * step_h : 0), h_hi = off_h + (step_h > 0 ? (nA - 1) * step_h : 0);
     const int w_lo = off_w + (step_w < 0 ? (nB - 1) * step_w : 0), w_hi = off_w + (step_w > 0 ? (nB - 1) * step_w : 0);
     g.r0 = h_lo; g.c0 = w_lo;
@@ -542,14 +549,15 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     if (!in_nchw) {
         int parts = 0;
         const int rc = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, bn_partial, &parts,
-                                      fin.counter ? &fin : nullptr, in_scale, in_shift, st);
+                                      fin.counter ? &fin : nullptr, in_scale, in_shift, bwd, st);
         if (rc == DAM_OK) {
             if (bn_partial && bn_parts_host) *bn_parts_host = parts;
             return DAM_OK;
         }
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
         if (bn_partial) {       // maybe only the statistics did not fit: retry without them
-            const int rc2 = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, nullptr, nullptr, nullptr, in_scale, in_shift, st);
+            const int rc2 = conv_strip_try(g, h_lo, h_hi, x, w_packed, bias, y, res, res_mask, nullptr, nullptr, nullptr, in_scale, in_shift,
+                                           BnBwdEpi{}, st);
             if (rc2 == DAM_OK) return DAM_OK;
             if (rc2 != DAM_ERR_UNSUPPORTED) return rc2;
         }
@@ -559,7 +567,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     if (!getenv("DAM_NO_PIPE")) {
         int parts = 0;
         const int rc = conv_pipe_try(g, h_hi - h_lo, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace,
-                                     fin.counter ? nullptr : bn_partial, &parts, st);
+                                     (fin.counter || bwd.x) ? nullptr : bn_partial, &parts, st);
         if (rc == DAM_OK && bn_partial && bn_parts_host) *bn_parts_host = parts;
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }

@@ -24,6 +24,16 @@ struct ConvGeo {
     int relu_out;            // ReLU on the result after bias / residual (eval-mode BatchNorm folded into weights + bias)
     int ksplit;              // split-K over channel groups (tile kernel): raw partial sums go to a workspace slab
     int gps;                 // channel groups per split
+    int epi_bwd;             // 1: BatchNorm-backward sums epilogue (BnBwdEpi): `res` is the BatchNorm's input, nothing is added
+};
+
+// BatchNorm-backward sums from a data-gradient epilogue: the launch's output IS the gradient dy that reaches relu(bn(x)), so
+// the two per-channel sums of the BatchNorm's backward pass  sum(dz), sum(dz * xhat)  with  dz = dy * (x*mscale + mshift > 0),
+// xhat = (x - mean) * invstd  are taken from the output registers + one read of x instead of a pass over dy and x.
+// Records [workgroup][channel][2] (the layout of dam_bn_backward_f32's workspace).  All pointers: device, per channel.
+struct BnBwdEpi {
+    const float* x;          // null: off
+    const float* mean; const float* invstd; const float* mscale; const float* mshift;
 };
 
 struct StripGeo {
@@ -40,7 +50,7 @@ struct StripGeo {
 struct BnFinArgs;
 int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
                    const float* res, const float* res_mask, float* stats, int* stats_parts, const BnFinArgs* fin,
-                   const float* in_scale, const float* in_shift, hipStream_t st);
+                   const float* in_scale, const float* in_shift, const BnBwdEpi& bwd, hipStream_t st);
 
 // dam_conv_pipe.hip: the persistent tile kernel with loader waves (thick 3x3 layers); picks its own tile;
 // DAM_ERR_UNSUPPORTED = the caller falls back to conv_igemm_kernel

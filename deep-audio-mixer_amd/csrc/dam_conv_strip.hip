@@ -113,13 +113,15 @@ __device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&
 // NCH: 16-channel input chunks (compile time so that every MFMA operand offset of the 3x3xNCH item grid is a scalar)
 // LW: loader shape -- false: rows of up to 144 (16 ch) / 80 (32 ch) cells, true: up to 224 / 112 cells (the reference's native
 // 216-frame spectrograms and their half-resolution stage)
-template <int MB, int NB, int NCH, bool T33, bool LW>
+// EPI: the BatchNorm-backward sums epilogue (BnBwdEpi) is compiled in -- its per-lane constants cost 16*NB registers, so only
+// the data-gradient shapes that use it are instantiated with it
+template <int MB, int NB, int NCH, bool T33, bool LW, bool EPI>
 __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
                                                          const float* __restrict__ res_mask, float* __restrict__ stats,
                                                          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                         const BnFinArgs fin) {
+                                                         const BnFinArgs fin, const BnBwdEpi bwd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: role tests and loader arithmetic on the scalar ALU
@@ -353,6 +355,19 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     for (int nb = 0; nb < NB; ++nb)
         bias4[nb] = bias ? *reinterpret_cast<const v4f*>(bias + (nb0 + nb) * 16 + kq * 4) : (v4f){0.f, 0.f, 0.f, 0.f};
 
+    // BatchNorm-backward sums epilogue (BnBwdEpi): `res` is the BatchNorm's input x; per lane the two affine maps of its
+    // channel quad: mask = x*mscale + mshift > 0, xhat = x*invstd - mean*invstd.  The sums live in st_s1 / st_s2.
+    constexpr bool epi_bwd = EPI;
+    v4f bw_ms[EPI ? NB : 1], bw_mh[EPI ? NB : 1], bw_k1[EPI ? NB : 1], bw_k2[EPI ? NB : 1];
+#pragma unroll
+    for (int nb = 0; nb < (EPI ? NB : 0); ++nb) {
+        const int ch = (nb0 + nb) * 16 + kq * 4;
+        bw_ms[nb] = *reinterpret_cast<const v4f*>(bwd.mscale + ch);
+        bw_mh[nb] = *reinterpret_cast<const v4f*>(bwd.mshift + ch);
+        bw_k1[nb] = *reinterpret_cast<const v4f*>(bwd.invstd + ch);
+        bw_k2[nb] = -(*reinterpret_cast<const v4f*>(bwd.mean + ch)) * bw_k1[nb];
+    }
+
     // T33: operand row bases of this group's NEXT tile.  They are computed in the group's write-out slot, where the wave
     // otherwise waits for the other group's MFMAs: ~200 scalar instructions that would sit in front of the MFMA stream.
     int base_a[3][MB];
@@ -544,7 +559,16 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                                 rv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
                                 if (res_mask) mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
                             }
-                            if (res_mask) {
+                            if constexpr (epi_bwd) {    // rv = the BatchNorm's input at this pixel: sums only, v goes out as it is
+                                const v4f m = __builtin_elementwise_fma(rv, bw_ms[nb], bw_mh[nb]);
+                                const v4f xh = __builtin_elementwise_fma(rv, bw_k1[nb], bw_k2[nb]);
+                                v4f dz;
+                                dz.x = m.x > 0.f ? v.x : 0.f; dz.y = m.y > 0.f ? v.y : 0.f;
+                                dz.z = m.z > 0.f ? v.z : 0.f; dz.w = m.w > 0.f ? v.w : 0.f;
+                                st_s1[nb][0] += dz.xy; st_s1[nb][1] += dz.zw;
+                                st_s2[nb][0] = __builtin_elementwise_fma(dz.xy, xh.xy, st_s2[nb][0]);
+                                st_s2[nb][1] = __builtin_elementwise_fma(dz.zw, xh.zw, st_s2[nb][1]);
+                            } else if (res_mask) {
                                 v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;
                                 v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;
                             } else {
@@ -554,7 +578,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                         if (relu_out) v = __builtin_elementwise_max(v, (v4f){0.f, 0.f, 0.f, 0.f});
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), yrsrc, voff + nb * 64, 0, 0);
 #ifndef DAM_STAMPS
-                        if (stats) {
+                        if (stats && !epi_bwd) {
                             if (!st_have) { st_nk[nb][0] = -v.xy; st_nk[nb][1] = -v.zw; }
                             const v2f d0 = v.xy + st_nk[nb][0], d1 = v.zw + st_nk[nb][1];
                             st_s1[nb][0] += d0; st_s1[nb][1] += d1;
@@ -584,6 +608,35 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     DAM_STAMP(8);
     return;
 #endif
+    if constexpr (epi_bwd) {
+        // (sum dz, sum dz*xhat) per lane -> the 16 pixel lanes (butterfly), then the 8 compute waves through LDS in wave order
+        __syncthreads();                                   // the ring is no longer needed
+        float* sm = reinterpret_cast<float*>(smem);        // [8 compute waves][NB*16 ch][2]
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = st_s1[nb][r >> 1][r & 1], b = st_s2[nb][r >> 1][r & 1];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+                if (j == 0 && wave < 8) {
+                    float* o = sm + ((wave * NB * 16) + nb * 16 + kq * 4 + r) * 2;
+                    o[0] = a; o[1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < NB * 16) {
+            float a = 0.f, b = 0.f;
+            for (int w = 0; w < 8; ++w) { a += sm[((w * NB * 16) + tid) * 2]; b += sm[((w * NB * 16) + tid) * 2 + 1]; }
+            const int ch = nb0 * 16 + tid;
+            if (ch < g.N) {
+                const size_t part = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+                store_sc1(stats + (part * g.N + ch) * 2, a);
+                store_sc1(stats + (part * g.N + ch) * 2 + 1, b);
+            }
+        }
+        return;
+    }
     if (stats) {
         // (n, mean, M2) per lane -> Chan merge over the 16 pixel lanes, then over the 4 compute waves through LDS
         float* sm = reinterpret_cast<float*>(smem);        // ring no longer needed: [8 compute waves][NB*16 ch][3]
@@ -643,32 +696,34 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 }  // namespace
 
 // Returns DAM_OK if launched, DAM_ERR_UNSUPPORTED if the layer does not fit this variant (caller falls back).
-template <int MB, int NB, int NCH, bool T33, bool LW = false>
+template <int MB, int NB, int NCH, bool T33, bool LW = false, bool EPI = false>
 static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, const float* Wp, const float* bias, float* Y,
                         const float* res, const float* res_mask, float* stats, const float* in_scale, const float* in_shift,
-                        const BnFinArgs& fin, hipStream_t st) {
+                        const BnFinArgs& fin, const BnBwdEpi& bwd, hipStream_t st) {
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH, T33, LW>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH, T33, LW, EPI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return DAM_ERR_LAUNCH;
             raised = true;
         }
     }
     dim3 grid((unsigned)sg.strips, (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
-    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33, LW>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
-                       Y, res, res_mask, stats, in_scale, in_shift, fin);
+    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33, LW, EPI>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
+                       Y, res, res_mask, stats, in_scale, in_shift, fin, bwd);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
 
 int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const float* Wp, const float* bias, float* Y,
                    const float* res, const float* res_mask, float* stats, int* stats_parts, const BnFinArgs* fin_in,
-                   const float* in_scale, const float* in_shift, hipStream_t st) {
+                   const float* in_scale, const float* in_shift, const BnBwdEpi& bwd, hipStream_t st) {
     BnFinArgs fin{};
-    if (fin_in && stats) fin = *fin_in;
+    if (fin_in && stats && !bwd.x) fin = *fin_in;
+    if (bwd.x && (res || !stats)) return DAM_ERR_BAD_ARG;      // the epilogue reads x through the residual path
     ConvGeo g = g_in;                 // the caller's copy stays as it is for the tile kernel
+    g.epi_bwd = bwd.x ? 1 : 0;
     if (g.nB == 3 && g.step_w < 0) {  // same taps walked left to right: column step becomes +1, weight taps are re-indexed
         g.off_w += 2 * g.step_w; g.step_w = -g.step_w;
         g.wt_base += 2 * g.wt_sb; g.wt_sb = -g.wt_sb;
@@ -727,7 +782,15 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     if (fin.counter && lds < (size_t)32 * 1024 + STRIP_THREADS * 3 * sizeof(double)) lds = (size_t)32 * 1024 + STRIP_THREADS * 3 * sizeof(double);
     // 3x3 taps, stride 1, unit column step: compile-time item grid with immediate operand offsets
     const bool t33 = g.nA == 3 && g.nB == 3 && g.s == 1 && g.step_w == 1;
-#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, res, res_mask, stats, in_scale, in_shift, fin, st
+#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, (bwd.x ? bwd.x : res), res_mask, stats, in_scale, in_shift, fin, bwd, st
+    if (bwd.x) {        // sums epilogue: the 3x3 / stride-1 data gradients of the 16- and 32-channel stages only
+        if (!t33) return DAM_ERR_UNSUPPORTED;
+        if (g.nchunks == 1 && MB == 4 && NB == 1)
+            return wide ? launch_strip<4, 1, 1, true, true, true>(DAM_STRIP_ARGS) : launch_strip<4, 1, 1, true, false, true>(DAM_STRIP_ARGS);
+        if (g.nchunks == 2 && MB == 2 && NB == 2)
+            return wide ? launch_strip<2, 2, 2, true, true, true>(DAM_STRIP_ARGS) : launch_strip<2, 2, 2, true, false, true>(DAM_STRIP_ARGS);
+        return DAM_ERR_UNSUPPORTED;
+    }
 #define DAM_STRIP_CASE(M_, N_)                                                                                           \
     if (MB == M_ && NB == N_) {                                                                                             \
         if (t33) return g.nchunks == 1 ? launch_strip<M_, N_, 1, true>(DAM_STRIP_ARGS) : launch_strip<M_, N_, 2, true>(DAM_STRIP_ARGS); \

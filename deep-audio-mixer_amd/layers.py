@@ -303,9 +303,15 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             dc2, dg2, db2 = ops.bn_backward(dout, None, c2, g2, m2, i2, tr, dgamma=s_g2, dbeta=s_b2, mask_bits=bits)
         dw2 = blk.spec2.wgrad(c1, dc2, in_affine=(sc1, sh1), out=wview(s_w2, w2))
-        da1 = blk.spec2.dgrad(dc2, w2, (c1.shape[1], c1.shape[2]))
+        # conv2's data gradient IS the gradient reaching relu(bn1(c1)): where the kernel can, bn1's two backward sums come out
+        # of its epilogue (sums = (records, count)) and bn_backward only finalizes and applies
+        sums = None
+        if ops.DGRAD_BN_SUMS:
+            da1, sums = blk.spec2.dgrad(dc2, w2, (c1.shape[1], c1.shape[2]), bn_bwd=(c1, m1, i1, sc1, sh1))
+        else:
+            da1 = blk.spec2.dgrad(dc2, w2, (c1.shape[1], c1.shape[2]))
         dc1, dg1, db1 = ops.bn_backward(da1, None, c1, g1, m1, i1, tr, mask_affine=(sc1, sh1),   # mask = (bn1(c1) > 0)
-                                        dgamma=s_g1, dbeta=s_b1)
+                                        dgamma=s_g1, dbeta=s_b1, partials=sums)
         dw1 = blk.spec1.wgrad(x, dc1, out=wview(s_w1, w1))
         first = (keep(dw1, s_w1), keep(dg1, s_g1), keep(db1, s_b1), keep(dw2, s_w2), keep(dg2, s_g2), keep(db2, s_b2))
         if ctx.has_sc:

@@ -51,6 +51,11 @@ _counters = {}
 INKERNEL_FINALIZE = False
 
 
+# BatchNorm-backward sums from the data-gradient epilogue (include/dam_hip.h: dam_bn_bwd_sums); DAM_NO_DGRAD_SUMS=1 keeps the
+# separate pass over dy and x (A/B switch)
+DGRAD_BN_SUMS = not os.environ.get('DAM_NO_DGRAD_SUMS')
+
+
 def arrival_counter(device):
     """The zero-initialised device word of the "last workgroup finalizes" hand-off (include/dam_hip.h: dam_bn_fin): one per
     device -- every launch that uses it returns it to zero and all of them are ordered on the current stream.  None while
@@ -73,7 +78,7 @@ def _bn_fin_struct(bn, out4, device):
 
 def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shift, relu_in, y, OHt, OWt, Ho, Wo,
              out_stride, oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb,
-             res=None, res_mask=None, bn_partial=None, bn_fin=None, relu_out=False, batch=None):
+             res=None, res_mask=None, bn_partial=None, bn_fin=None, relu_out=False, batch=None, bn_bwd=None):
     parts = ctypes.c_int(0)
     # split-K scratch: the host code only splits when no tile shape gives 400 workgroups, i.e. for outputs below
     # 400 * 64 px * 64 ch = 1.64 M floats, and then at most 8 ways (dam_conv.hip) -- never more than 13.1 M floats
@@ -84,7 +89,8 @@ def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shi
         out_stride,
         oo_h, oo_w, in_stride, nA, nB, off_h, step_h, off_w, step_w, wt_base, wt_sa, wt_sb, _lib.ptr(res),
         _lib.ptr(res_mask), _lib.ptr(bn_partial), ctypes.byref(parts) if bn_partial is not None else None,
-        ctypes.byref(bn_fin) if bn_fin is not None else None, _lib.ptr(ws), ws.numel(),
+        ctypes.byref(bn_fin) if bn_fin is not None else None, ctypes.byref(bn_bwd) if bn_bwd is not None else None,
+        _lib.ptr(ws), ws.numel(),
         ctypes.addressof(batch) if batch is not None else None, _lib.stream())
     _lib.check(st, 'dam_conv2d_tapgrid_f32')
     return parts.value
@@ -137,10 +143,29 @@ def _dgrad_axis(parity, pad, dil, k, stride):
     return len(valid), k0, kstep, (parity + pad - k0 * dil) // stride, -(kstep * dil) // stride
 
 
-def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, res_mask=None, accumulate_into=None):
+def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, res_mask=None, accumulate_into=None,
+                 bn_bwd=None):
     """dy: NHWC [B,Ho,Wo,Cout]; wpt packed with transpose=True.  Returns dx NHWC [B,H,W,n_in16]
-    (+ res * (res_mask > 0) if given).  With accumulate_into=dx0 the result is added to dx0 in place."""
+    (+ res * (res_mask > 0) if given).  With accumulate_into=dx0 the result is added to dx0 in place.
+    bn_bwd=(x, save_mean, save_invstd, mask_scale, mask_shift): dx is the gradient reaching relu(bn(x)); returns
+    (dx, partials) where partials = (records, count) for bn_backward(partials=) when the launch could also take that
+    BatchNorm's two backward sums from its epilogue, else None (stride 1, no residual)."""
     _lib.require_cuda(dy, wpt)
+    if bn_bwd is not None:
+        if stride != 1 or res is not None or accumulate_into is not None:
+            raise ValueError('bn_bwd: stride-1 data gradients without a fused residual only')
+        xb, mean, invstd, msc, msh = bn_bwd
+        _lib.require_cuda(xb)
+        B, Ho, Wo, Co = dy.shape
+        n16 = (n_in + 15) // 16 * 16
+        if tuple(xb.shape) != (B, H, W, n16):
+            raise ValueError('bn_bwd: x has the shape of the data gradient')
+        dx = torch.empty((B, H, W, n16), dtype=torch.float32, device=dy.device)
+        rec = torch.empty(_lib.lib().dam_bn_workspace_floats(n16), dtype=torch.float32, device=dy.device)
+        epi = _lib.BnBwdSums(_lib.ptr(xb), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(msc), _lib.ptr(msh))
+        parts = _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, H, W, 1, 0, 0, 1,
+                         kh, kw, pad, -dil, pad, -dil, 0, kw, 1, bn_partial=rec, bn_bwd=epi)
+        return dx, ((rec, parts) if parts > 0 else None)
     _f32c(dy, 'dy'), _f32c(res, 'res'), _f32c(res_mask, 'res_mask')
     B, Ho, Wo, Co = dy.shape
     n16 = (n_in + 15) // 16 * 16
@@ -450,7 +475,7 @@ def bn_backward_pair(dy, y_mask, a, b, training=True, mask_bits=None):
 
 
 def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mask_affine=None, dgamma=None, dbeta=None,
-                mask_bits=None):
+                mask_bits=None, partials=None):
     """Returns (dx, dgamma, dbeta) for y = [relu](bn(x) + ...).  The ReLU mask comes from y_mask (the saved output), or --
     for a plain relu(bn(x)) -- from mask_affine=(scale, shift), the forward's fused affine (the saved output is not read),
     or there is none (both None)."""
@@ -463,12 +488,13 @@ def bn_backward(dy, y_mask, x, gamma, save_mean, save_invstd, training=True, mas
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     if dbeta is None:
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = _bn_ws(x.device, C)
+    # partials=(records, count) from conv2d_dgrad(bn_bwd=): the two sums are already there, only finalize + apply run
+    ws, given = (_bn_ws(x.device, C), 0) if partials is None else partials
     _lib.check(_lib.lib().dam_bn_backward_f32(_lib.ptr(dy), _lib.ptr(y_mask), _lib.ptr(x), x.numel() // C, C, _lib.ptr(gamma),
                                               _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
                                               _lib.ptr(mask_affine[0]) if mask_affine else None,
                                               _lib.ptr(mask_affine[1]) if mask_affine else None, _lib.ptr(mask_bits), _lib.ptr(dx),
-                                              _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
+                                              _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), given,
                                               _lib.ptr(arrival_counter(x.device)), _lib.stream()),
                'dam_bn_backward_f32')
     return dx, dgamma, dbeta

@@ -37,6 +37,7 @@ typedef enum dam_status {
 
 typedef enum dam_pcm_dtype { DAM_PCM_F32 = 0, DAM_PCM_F64 = 1 } dam_pcm_dtype;
 struct dam_bn_fin;      /* defined in the BatchNorm section */
+struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 
 /* Library / build identification ("gfx950"). */
 const char* dam_arch(void);
@@ -132,6 +133,9 @@ int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int6
  * in *bn_parts_host (a HOST int); 0 there means "not produced" and the caller runs dam_bn_stats_f32 instead.
  * Feed the records to dam_bn_finalize_f32 -- or pass bn_fin (see dam_bn_fin below): the launch's last workgroup then
  * merges them itself and writes save_mean / save_invstd / scale / shift (+ running statistics), no finalize launch.
+ * bn_bwd (optional, see dam_bn_bwd_sums below; excludes res / bn_fin, needs bn_partial): the launch is a data gradient whose
+ * output dy feeds the backward pass of y = relu(bn(x)); if it can, it also writes that pass's two per-channel sums as records
+ * [*bn_parts_host][n_out][2] into bn_partial (then hand them to dam_bn_backward_f32 as partials_given); 0 records = not produced.
  * workspace (optional): scratch for split-K over the input channels (used for small-spatial, wide layers; at most
  * 8 * B*OHt*OWt*n_out floats are used, fewer if less is given); partial slabs are summed in a fixed order. */
 int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_packed,
@@ -140,8 +144,8 @@ int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nc
                            int out_stride, int out_off_h, int out_off_w, int in_stride, int nA, int nB,
                            int off_h, int step_h, int off_w, int step_w, int wt_base, int wt_sa, int wt_sb,
                            const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
-                           const struct dam_bn_fin* bn_fin, float* workspace, int64_t workspace_floats, void* batch,
-                           void* stream);
+                           const struct dam_bn_fin* bn_fin, const struct dam_bn_bwd_sums* bn_bwd, float* workspace,
+                           int64_t workspace_floats, void* batch, void* stream);
 
 /* Sibling launches in one.  The parity classes of a strided data gradient are up to four small launches over the same
  * tensors, weights and tile that differ only in their tap grid.  With a batch (caller-owned HOST memory of
@@ -203,6 +207,15 @@ typedef struct dam_bn_fin {       /* host struct of device pointers: what dam_bn
     uint32_t* counter;
 } dam_bn_fin;
 
+/* BatchNorm-backward sums from a data-gradient epilogue (dam_conv2d_tapgrid_f32's bn_bwd): the backward pass of
+ * y = relu(bn(x)) (models/model_resnet.py:24 of the reference, reached from loss.backward()) needs sum(dz) and sum(dz * xhat)
+ * per channel, dz = dy * (x*mask_scale + mask_shift > 0), xhat = (x - mean) * invstd.  dy is the convolution data gradient
+ * that was just computed, so the launch that produces it takes the sums from its output registers and one read of x.
+ * Host struct of device pointers (x: the BatchNorm's input, shape of the launch's output; the rest: per channel). */
+typedef struct dam_bn_bwd_sums {
+    const float* x; const float* mean; const float* invstd; const float* mask_scale; const float* mask_shift;
+} dam_bn_bwd_sums;
+
 /* Training-mode statistics of x: save_mean, save_invstd = 1/sqrt(biased var + eps), the fused affine
  * scale = gamma*invstd, shift = beta - mean*scale, and torch's running-stat update
  * (running = (1-momentum)*running + momentum*stat, unbiased variance; ++*num_batches_tracked).
@@ -242,11 +255,13 @@ int dam_bn_apply_f32(const float* x, int64_t n_pixels, int C, const float* scale
  * the sign bytes dam_bn_apply_f32 wrote if mask_bits is given, (x*mask_scale + mask_shift > 0) if the forward's fused affine
  * is given instead (plain relu(bn(x)): the saved output is then not read at all), 1 if all are NULL (at most one form);
  * dgamma = sum dz*xhat, dbeta = sum dz, dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
- * (training) or gamma*invstd*dz (training == 0, running statistics). */
+ * (training) or gamma*invstd*dz (training == 0, running statistics).
+ * partials_given > 0: `workspace` already holds that many records [partials_given][C][2] of (sum dz, sum dz*xhat) -- written by
+ * a data-gradient launch with bn_bwd -- and the pass over dy and x that would produce them is skipped. */
 int dam_bn_backward_f32(const float* dy, const float* y_mask, const float* x, int64_t n_pixels, int C,
                         const float* gamma, const float* save_mean, const float* save_invstd, int training,
                         const float* mask_scale, const float* mask_shift, const uint8_t* mask_bits, float* dx,
-                        float* dgamma, float* dbeta, float* workspace, uint32_t* counter, void* stream);
+                        float* dgamma, float* dbeta, float* workspace, int partials_given, uint32_t* counter, void* stream);
 
 /* The same for TWO BatchNorms that share dy and the mask (exactly one of y_mask / mask_bits) -- a residual block's bn2 and the BatchNorm of its shortcut
  * convolution, both fed by the gradient of relu(bn2(..) + bn_sc(..)) (models/model_resnet.py:23-28): dy and the mask are

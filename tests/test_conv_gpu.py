@@ -341,3 +341,43 @@ def test_loader_wave_kernel_statistics_epilogue(ops, B, C, H, W, s, Co):
     wm, wv = want.mean((0, 2, 3)), want.var((0, 2, 3), unbiased=False)
     assert (mean.double().cpu() - wm).abs().max() <= 1e-5 * wm.abs().max()
     assert ((invstd.double().cpu() - 1 / (wv + 1e-5).sqrt()).abs() * (wv + 1e-5).sqrt()).max() <= 2e-5
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 16, 41, 130), (3, 16, 23, 127), (2, 32, 37, 65), (1, 32, 20, 66), (1, 16, 9, 216),
+                                     (1, 32, 7, 108), (1, 64, 19, 33)])
+def test_dgrad_bn_backward_sums_epilogue(ops, B, C, H, W):
+    """conv2d_dgrad(bn_bwd=...): the data gradient is bitwise the plain one, and the records it leaves are the two sums of
+    the BatchNorm backward pass of relu(bn(x)) -- checked against float64 and through bn_backward(partials=) against the
+    separate pass.  Thick layers (64 channels here) take a kernel without the epilogue: partials is None."""
+    g = torch.Generator().manual_seed(B * 100 + C + H + W)
+    dy = torch.randn(B, H, W, C, generator=g).cuda()
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (0.3 * torch.randn(C, generator=g)).cuda()
+    mean = x.double().mean((0, 1, 2))
+    invstd = 1.0 / torch.sqrt(x.double().var((0, 1, 2), unbiased=False) + 1e-5)
+    mean, invstd = mean.float(), invstd.float()
+    msc = gamma * invstd
+    msh = beta - mean * msc
+    wpt = ops.pack_weights(w.cuda(), transpose=True)
+    plain = ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1)
+    dx, partials = ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1, bn_bwd=(x, mean, invstd, msc, msh))
+    assert torch.equal(dx, plain)
+    if C >= 64:
+        assert partials is None
+        return
+    rec, parts = partials
+    assert 0 < parts <= 1024
+    sums = rec[:parts * C * 2].view(parts, C, 2).double().sum(0).cpu()
+    mask = (x.double() * msc.double() + msh.double()) > 0
+    dz = dx.double() * mask
+    xhat = (x.double() - mean.double()) * invstd.double()
+    want_a, want_b = dz.sum((0, 1, 2)).cpu(), (dz * xhat).sum((0, 1, 2)).cpu()
+    n = B * H * W
+    assert (sums[:, 0] - want_a).abs().max() <= 2e-5 * dz.abs().max().item() * n ** 0.5 + 1e-3
+    assert (sums[:, 1] - want_b).abs().max() <= 2e-5 * (dz * xhat).abs().max().item() * n ** 0.5 + 1e-3
+    for tr in (True, False):
+        a = ops.bn_backward(dx, None, x, gamma, mean, invstd, tr, mask_affine=(msc, msh))
+        b = ops.bn_backward(dx, None, x, gamma, mean, invstd, tr, mask_affine=(msc, msh), partials=partials)
+        for u, v in zip(a, b):
+            close(v, u.double().cpu(), 2e-5)
