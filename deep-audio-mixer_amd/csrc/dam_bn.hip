@@ -22,6 +22,7 @@ namespace dam {
 namespace {
 
 constexpr int BN_MAX_PARTS = 1024;
+static_assert(BN_MAX_PARTS == BN_BWD_RECORDS_MAX, "records a data-gradient epilogue may leave");
 
 struct BnLaunch { int threads, q, r, parts; int64_t ppb; };
 

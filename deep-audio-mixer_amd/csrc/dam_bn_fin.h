@@ -18,6 +18,7 @@ namespace dam {
 // Records [parts][C][3] a statistics producer may emit (the size dam_bn_workspace_floats() provides for): the BatchNorm
 // kernels' own passes use up to 1024, the loader-wave convolution up to one per (workgroup or tile, wave).
 constexpr int BN_RECORDS_MAX = 2048;
+constexpr int BN_BWD_RECORDS_MAX = 1024;      // records [..][C][2] that dam_bn_backward_f32 takes as partials_given
 
 struct BnFinArgs {            // device pointers; the launch-side mirror of dam_bn_fin (include/dam_hip.h)
     const float* gamma;

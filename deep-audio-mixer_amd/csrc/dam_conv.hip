@@ -567,7 +567,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     if (!getenv("DAM_NO_PIPE")) {
         int parts = 0;
         const int rc = conv_pipe_try(g, h_hi - h_lo, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace,
-                                     (fin.counter || bwd.x) ? nullptr : bn_partial, &parts, st);
+                                     fin.counter ? nullptr : bn_partial, &parts, bwd, st);
         if (rc == DAM_OK && bn_partial && bn_parts_host) *bn_parts_host = parts;
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }

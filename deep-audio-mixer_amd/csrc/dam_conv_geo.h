@@ -56,6 +56,6 @@ int conv_strip_try(ConvGeo& g, int h_lo, int h_hi, const float* X, const float* 
 // DAM_ERR_UNSUPPORTED = the caller falls back to conv_igemm_kernel
 int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
                   float* Y, const float* res, const float* res_mask, float* workspace, float* stats, int* stats_parts,
-                  hipStream_t st);
+                  const BnBwdEpi& bwd, hipStream_t st);
 
 }  // namespace dam

@@ -87,13 +87,14 @@ __device__ __forceinline__ PipeUnit pipe_decode(const ConvGeo& g, int unit, int 
 // of the loader's 16 segments into registers (198 VGPRs, one workgroup per CU).
 // STATS: the launch also emits BatchNorm partial statistics (a separate instantiation: the epilogue code costs every launch
 // 1-2 us through register allocation even when it does not run).
-template <int MB, int NB, int PIPE_U, bool STATS>
+template <int MB, int NB, int PIPE_U, int STATS>   // STATS: 0 none, 1 forward statistics, 2 BatchNorm-backward sums (BnBwdEpi)
 __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g, const int nunits, const float* __restrict__ X,
                                                                  const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                                  const float* __restrict__ in_scale,
                                                                  const float* __restrict__ in_shift, float* __restrict__ Y,
                                                                  const float* __restrict__ res, const float* __restrict__ res_mask,
-                                                                 float* __restrict__ stamps, float* __restrict__ stats) {
+                                                                 float* __restrict__ stamps, float* __restrict__ stats,
+                                                                 const BnBwdEpi bwd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -367,10 +368,22 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
             for (int r = 0; r < 4; ++r) {
                 const float first = reinterpret_cast<const float*>(&acc[0][nb])[r] +
                                     (bias ? bias[(cur.nb0 + nb) * 16 + kq * 4 + r] : 0.f);
-                st_k[nb][r] = STATS ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, first), 0x150, 0xF, 0xF, false))
+                st_k[nb][r] = STATS == 1 ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, first), 0x150, 0xF, 0xF, false))
                                     : 0.f;                                     // row_newbcast:0 -- lane 0 of the row
                 st_s1[nb][r] = 0.f; st_s2[nb][r] = 0.f;
             }
+        // STATS == 2: `res` is the BatchNorm's input x (nothing is added); per channel quad the two affine maps
+        // mask = x*mscale + mshift > 0 and xhat = x*invstd - mean*invstd, fetched per unit (L2 hits) so that they cost no
+        // register outside the epilogue; st_s1 / st_s2 take sum(dz) / sum(dz * xhat)
+        v4f bw_ms[STATS == 2 ? NB : 1], bw_mh[STATS == 2 ? NB : 1], bw_k1[STATS == 2 ? NB : 1], bw_k2[STATS == 2 ? NB : 1];
+#pragma unroll
+        for (int nb = 0; nb < (STATS == 2 ? NB : 0); ++nb) {
+            const int ch = (cur.nb0 + nb) * 16 + kq * 4;
+            bw_ms[nb] = *reinterpret_cast<const v4f*>(bwd.mscale + ch);
+            bw_mh[nb] = *reinterpret_cast<const v4f*>(bwd.mshift + ch);
+            bw_k1[nb] = *reinterpret_cast<const v4f*>(bwd.invstd + ch);
+            bw_k2[nb] = -(*reinterpret_cast<const v4f*>(bwd.mean + ch)) * bw_k1[nb];
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int p = cur.p0 + wave * MW + mb * 16 + j;
@@ -387,7 +400,18 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                     const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 }
-                if (res) {
+                if (STATS == 2) {
+                    const v4f rv = *reinterpret_cast<const v4f*>(res + o);
+                    const v4f m = __builtin_elementwise_fma(rv, bw_ms[nb], bw_mh[nb]);
+                    const v4f xh = __builtin_elementwise_fma(rv, bw_k1[nb], bw_k2[nb]);
+                    const float dz[4] = {m.x > 0.f ? v.x : 0.f, m.y > 0.f ? v.y : 0.f, m.z > 0.f ? v.z : 0.f, m.w > 0.f ? v.w : 0.f};
+                    const float xe[4] = {xh.x, xh.y, xh.z, xh.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st_s1[nb][r] += dz[r];
+                        st_s2[nb][r] = fmaf(dz[r], xe[r], st_s2[nb][r]);
+                    }
+                } else if (res) {
                     const float4 rv = *reinterpret_cast<const float4*>(res + o);
                     if (res_mask) {
                         const float4 mv = *reinterpret_cast<const float4*>(res_mask + o);
@@ -399,7 +423,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                 }
                 if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<float4*>(Y + o) = make_float4(v.x, v.y, v.z, v.w);
-                if (STATS) {
+                if (STATS == 1) {
                     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -409,7 +433,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                     }
                 }
             }
-            if (STATS) st_n += 1.f;
+            if (STATS == 1) st_n += 1.f;
         }
         if (STATS) {
             // row sums by rotation (ror 8, 4, 2, 1: every lane ends up with the total), then lane 0 of the row writes
@@ -431,7 +455,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                     DAM_ROW_SUM(s1);
                     DAM_ROW_SUM(s2);
                     const int ch = (cur.nb0 + nb) * 16 + kq * 4 + r;
-                    if (j == 0 && ch < g.N) {
+                    if (STATS == 2) {
+                        if (j == 0 && ch < g.N) { float* o = stats + (rec * g.N + ch) * 2; o[0] = s1; o[1] = s2; }
+                    } else if (j == 0 && ch < g.N) {
                         const float md = n > 0.f ? s1 / n : 0.f;
                         float* o = stats + (rec * g.N + ch) * 3;
                         o[0] = n; o[1] = st_k[nb][r] + md; o[2] = n > 0.f ? fmaxf(s2 - s1 * md, 0.f) : 0.f;
@@ -450,7 +476,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
 }
 
 // resident workgroups per launch: occupancy x CUs, asked once per instance and LDS size
-template <int MB, int NB, int PU, bool STATS>
+template <int MB, int NB, int PU, int STATS>
 int pipe_slots(size_t lds) {
     static int cus = 0;
     static size_t cached_lds = ~(size_t)0;
@@ -474,24 +500,25 @@ int pipe_slots(size_t lds) {
 template <int MB, int NB, int PU>
 int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
                 float* Y, const float* res, const float* res_mask, float* workspace, float* stats, int* stats_parts,
-                hipStream_t st) {
+                const BnBwdEpi& bwd, hipStream_t st) {
     const int nunits = g.tiles_m * (g.N / 16 / NB) * g.B;
     // statistics records: one per (image tile, wave), each unit fills its own channels of it
+    int mode = 0;
     if (stats) {
         const int64_t parts = (int64_t)g.B * g.tiles_m * 4;
-        if (parts > BN_RECORDS_MAX) stats = nullptr;            // the caller runs the statistics pass instead
-        else if (stats_parts) *stats_parts = (int)parts;
+        if (parts > (bwd.x ? BN_BWD_RECORDS_MAX : BN_RECORDS_MAX)) stats = nullptr;    // the caller runs the separate pass instead
+        else { mode = bwd.x ? 2 : 1; if (stats_parts) *stats_parts = (int)parts; }
     }
-    int wgs = stats ? pipe_slots<MB, NB, PU, true>(lds) : pipe_slots<MB, NB, PU, false>(lds);
+    if (bwd.x) res = mode == 2 ? bwd.x : nullptr;               // the sums epilogue reads x through the residual operand
+    int wgs = mode == 2 ? pipe_slots<MB, NB, PU, 2>(lds) : (mode == 1 ? pipe_slots<MB, NB, PU, 1>(lds) : pipe_slots<MB, NB, PU, 0>(lds));
     if (const char* e = getenv("DAM_PIPE_WGS")) wgs = atoi(e);          // diagnostic
     if (wgs < 1) wgs = 1;
     if (wgs > nunits) wgs = nunits;
-    if (stats)
-        hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, true>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
-                           reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats);
-    else
-        hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, false>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,
-                           reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats);
+#define DAM_PIPE_LAUNCH(S_)                                                                                                 \
+    hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, S_>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,  \
+                       reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats, bwd)
+    if (mode == 2) DAM_PIPE_LAUNCH(2); else if (mode == 1) DAM_PIPE_LAUNCH(1); else DAM_PIPE_LAUNCH(0);
+#undef DAM_PIPE_LAUNCH
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
@@ -504,7 +531,8 @@ int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
 // workgroups, their patches are staged beside the MFMAs and cost the matrix pipe nothing.
 int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
                   float* Y, const float* res, const float* res_mask, float* workspace, float* stats, int* stats_parts,
-                  hipStream_t st) {
+                  const BnBwdEpi& bwd, hipStream_t st) {
+    if (bwd.x && (res || !stats)) return DAM_ERR_BAD_ARG;
     if (g.nA != 3 || g.nB != 3 || g.in_nchw || g.nchunks < 2) return DAM_ERR_UNSUPPORTED;
     if ((size_t)g.H * g.W * g.C * 4 >= ((size_t)1 << 30)) return DAM_ERR_UNSUPPORTED;      // offsets of the range-checked loads
     const int64_t npix = (int64_t)g.Ho * g.Wo;
@@ -544,8 +572,8 @@ int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, cons
     const bool big = g.PR * g.PWin * 4 > PIPE_LT * 5;      // items per loader thread: 5 or 8
 #define DAM_PIPE_CASE(M_, N_)                                                                                              \
     if (MB == M_ && NB == N_)                                                                                              \
-        return big ? launch_pipe<M_, N_, 8>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, st) \
-                   : launch_pipe<M_, N_, 5>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, st)
+        return big ? launch_pipe<M_, N_, 8>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, bwd, st) \
+                   : launch_pipe<M_, N_, 5>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, bwd, st)
     DAM_PIPE_CASE(1, 4); DAM_PIPE_CASE(2, 2); DAM_PIPE_CASE(1, 2); DAM_PIPE_CASE(2, 1); DAM_PIPE_CASE(1, 1);
 #undef DAM_PIPE_CASE
     return DAM_ERR_UNSUPPORTED;

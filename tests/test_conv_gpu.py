@@ -344,11 +344,13 @@ def test_loader_wave_kernel_statistics_epilogue(ops, B, C, H, W, s, Co):
 
 
 @pytest.mark.parametrize('B,C,H,W', [(2, 16, 41, 130), (3, 16, 23, 127), (2, 32, 37, 65), (1, 32, 20, 66), (1, 16, 9, 216),
-                                     (1, 32, 7, 108), (1, 64, 19, 33)])
+                                     (1, 32, 7, 108), (1, 64, 19, 33), (2, 96, 33, 17), (2, 128, 17, 9), (1, 256, 9, 5),
+                                     (8, 64, 65, 33)])
 def test_dgrad_bn_backward_sums_epilogue(ops, B, C, H, W):
     """conv2d_dgrad(bn_bwd=...): the data gradient is bitwise the plain one, and the records it leaves are the two sums of
     the BatchNorm backward pass of relu(bn(x)) -- checked against float64 and through bn_backward(partials=) against the
-    separate pass.  Thick layers (64 channels here) take a kernel without the epilogue: partials is None."""
+    separate pass.  Both kernels that have the epilogue are covered (row-ring kernel: 16 / 32 channels; loader-wave tile kernel:
+    thick layers); a thick layer whose tiles would leave more than 1024 records returns partials None (last case)."""
     g = torch.Generator().manual_seed(B * 100 + C + H + W)
     dy = torch.randn(B, H, W, C, generator=g).cuda()
     w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
@@ -363,9 +365,10 @@ def test_dgrad_bn_backward_sums_epilogue(ops, B, C, H, W):
     plain = ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1)
     dx, partials = ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1, bn_bwd=(x, mean, invstd, msc, msh))
     assert torch.equal(dx, plain)
-    if C >= 64:
-        assert partials is None
+    if partials is None:
+        assert (B, C) == (8, 64)
         return
+    assert (B, C) != (8, 64)
     rec, parts = partials
     assert 0 < parts <= 1024
     sums = rec[:parts * C * 2].view(parts, C, 2).double().sum(0).cpu()
