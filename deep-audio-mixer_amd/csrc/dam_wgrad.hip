@@ -322,8 +322,17 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kq = lane >> 4;
-    const int tn = blockIdx.x / g.tiles_k, tk = blockIdx.x - tn * g.tiles_k;
-    const int img = blockIdx.y / g.spi, r_begin = (blockIdx.y - img * g.spi) * g.rps;
+    // XCD-aware placement: workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), so the nx workgroups that
+    // stream the SAME rows (one per (out tile, in tile)) would sit on nx different L2s and every row would be fetched from the
+    // fabric nx times (measured: 6 x the algorithmic bytes on the 96-channel stage).  Re-index so that they share an XCD:
+    // position r inside XCD c -> (tile r % nx, strip (r / nx) * 8 + c); the strips beyond a multiple of 8 keep their place.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nxg = gridDim.x, L = blockIdx.y * nxg + blockIdx.x, full = (gridDim.y >> 3) << 3;
+        if (L < full * nxg) { const int c = L & 7, r = L >> 3; bx = r % nxg; by = (r / nxg) * 8 + c; }
+    }
+    const int tn = bx / g.tiles_k, tk = bx - tn * g.tiles_k;
+    const int img = by / g.spi, r_begin = (by - img * g.spi) * g.rps;
     const int r_end = r_begin + g.rps < g.H ? r_begin + g.rps : g.H;
     const int n_slots = (r_end - r_begin + RPS - 1) / RPS;
     const int n_slots2 = (n_slots + 1) & ~1;
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         }
         __syncthreads();
     }
-    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NBLK * 64;
+    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)by * gridDim.x + bx) * NBLK * 64;
     for (int e = tid; e < NBLK * 64; e += RW_THREADS) out[e] = reinterpret_cast<const float4*>(red)[e];
 }
 
@@ -624,8 +633,14 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2G
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kq = lane >> 4;
-    const int tn = blockIdx.x / g.tiles_k, tk = blockIdx.x - tn * g.tiles_k;
-    const int img = blockIdx.y / g.spi, r_begin = (blockIdx.y - img * g.spi) * g.rps;
+    // XCD-aware placement as in wgrad_rows_kernel: the nx workgroups of a strip share an L2
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nxg = gridDim.x, L = blockIdx.y * nxg + blockIdx.x, full = (gridDim.y >> 3) << 3;
+        if (L < full * nxg) { const int c = L & 7, r = L >> 3; bx = r % nxg; by = (r / nxg) * 8 + c; }
+    }
+    const int tn = bx / g.tiles_k, tk = bx - tn * g.tiles_k;
+    const int img = by / g.spi, r_begin = (by - img * g.spi) * g.rps;
     const int r_end = r_begin + g.rps < g.Ho ? r_begin + g.rps : g.Ho;
     const int n_slots = (r_end - r_begin + RPS - 1) / RPS;
     const int n_slots2 = (n_slots + 1) & ~1;
@@ -827,7 +842,7 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2G
         }
         __syncthreads();
     }
-    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NBLK * 64;
+    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)by * gridDim.x + bx) * NBLK * 64;
     for (int e = tid; e < NBLK * 64; e += RW_THREADS) out[e] = reinterpret_cast<const float4*>(red)[e];
 }
 
