@@ -165,13 +165,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
 
 // dW[n][k][kh][kw] = sum over splits of the slabs, for a BATCH of weight gradients in one launch: a reduction is 5-10 us of
 // mostly launch latency, a ResNet18 step has 20 of them and nothing but the optimizer waits for any (dam_wgrad_queue_*).
-// Block = EL elements x SL split lanes (32 x 8 for few big slabs, 8 x 32 for many): a thread adds a strided subset of the
-// splits (4 independent chains, all loads in flight), the SL subtotals are combined by a fixed tree (deterministic).
+// Block = EL elements x SL split lanes (256 x 1 for few big slabs, 32 x 8 for few small ones, 8 x 32 for many): a thread adds
+// a strided subset of the splits (4 independent chains, all loads in flight), the SL subtotals are combined by a fixed tree
+// (deterministic).
 struct ReduceJob {
     const float* partial;
     float* dw;
     int nsplit, nx, TNB, TKB, TA, TB, n_real, k_real, KH, KW, tap_groups, tiles_k;
-    int sl;                  // split lanes: 32 or 8
+    int sl;                  // split lanes: 32, 8 or 1
     int blocks;              // workgroups of the launch that work on this job
 };
 constexpr int REDUCE_MAX_JOBS = 24;
@@ -265,6 +266,11 @@ int reduce_submit(void* queue, const float* partial, float* dw, int nsplit, int 
     if (nsplit >= 64) {
         j.sl = 32;
         j.blocks = (int)(cdiv(per_split4, 8) < 4096 ? cdiv(per_split4, 8) : 4096);
+    } else if (per_split4 >= 8192 && !getenv("DAM_REDUCE_NO_SL1")) {
+        // few big slabs (the thick stages): one element per thread, the splits added in order by that thread (4 chains, all
+        // loads in flight) -- no LDS step at all; the 32 x 8 shape spent its time in one-load-then-barrier rounds
+        j.sl = 1;
+        j.blocks = (int)(cdiv(per_split4, 256) < 4096 ? cdiv(per_split4, 256) : 4096);
     } else {
         j.sl = 8;
         j.blocks = (int)(cdiv(per_split4, 32) < 2048 ? cdiv(per_split4, 32) : 2048);
