@@ -354,7 +354,7 @@ def run_train(name, cfg, args):
     def run(k, first):
         for i in range(k):
             j = ((first + i) % (n_resident // B)) * B
-            step.load_clips(clips[j:j + B])      # device-to-device: inputs stay in HBM
+            step.bind_clips(clips[j:j + B])      # inputs stay where they are in HBM: the front-end's address word is re-pointed
             step()
 
     def timed(fn, k, first):
@@ -404,7 +404,7 @@ def run_train(name, cfg, args):
 
         def run_streamed(k, first):
             for _ in range(k):
-                step.load_clips(stager.next())
+                step.bind_clips(stager.next())   # the staging buffer the upload landed in is read in place
                 step()
         run_streamed(max(2, args.warmup), 0)
         dts = timed(run_streamed, args.steps, 0)

@@ -110,7 +110,10 @@ __global__ __launch_bounds__(TF2* WAVE, 4) void stft2048_kernel(
     const PCM* __restrict__ pcm, int64_t n_samples, int64_t outer_stride, int n_inner, int64_t inner_stride, int64_t cs,
     const float* __restrict__ window, const float2* __restrict__ tw /* W_2048^k */, const float* __restrict__ gain, int hop,
     int n_frames, int tiles_per_track, int n_tiles, float amin, float floor_db, int normalize, float* __restrict__ out,
-    float* __restrict__ out_tail, int n_tail) {
+    float* __restrict__ out_tail, int n_tail, int indirect) {
+    // DAM_PCM_INDIRECT: `pcm` is a device word that holds the batch's address (a captured launch then follows whichever
+    // resident batch the word points at: no copy into a fixed input buffer)
+    if (indirect) pcm = *reinterpret_cast<const PCM* const*>(pcm);
     __shared__ __attribute__((aligned(16))) float2 tw1s[16 * 64];      // [k1][lane]  W_1024^(lane*k1)
     __shared__ __attribute__((aligned(16))) float2 tw2s[16 * 4];       // [c][b]      W_64^(b*c)
     __shared__ __attribute__((aligned(16))) float planes[TF2 * PLANE];
@@ -337,7 +340,8 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(
     const PCM* __restrict__ pcm, int64_t n_samples, int64_t outer_stride, int n_inner, int64_t inner_stride, int64_t cs,
     const float* __restrict__ window, const float2* __restrict__ tw /* W_nfft^k */, const float* __restrict__ gain, int n_fft,
     int hop, int n_frames, float amin, float floor_db, int normalize, float* __restrict__ out, float* __restrict__ out_tail,
-    int n_tail) {
+    int n_tail, int indirect) {
+    if (indirect) pcm = *reinterpret_cast<const PCM* const*>(pcm);
     extern __shared__ __attribute__((aligned(16))) float2 buf[];      // [2][M]
     __shared__ float red[256];
     const int tid = threadIdx.x;
@@ -429,6 +433,8 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     if (channels != 1 && channels != 2) return DAM_ERR_UNSUPPORTED;
     const bool fast = n_fft == NFFT && !(hop & 1);         // the tuned 2048-point kernel; else any power of two 64..4096
     if (!fast && (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))) return DAM_ERR_UNSUPPORTED;
+    const int indirect = (pcm_dtype & DAM_PCM_INDIRECT) ? 1 : 0;
+    pcm_dtype &= ~DAM_PCM_INDIRECT;
     if (pcm_dtype != DAM_PCM_F32 && pcm_dtype != DAM_PCM_F64) return DAM_ERR_UNSUPPORTED;
     const int64_t n_tracks = n_outer * n_inner;
     if (n_tracks > 65535 || n_inner > 0x7fffffff) return DAM_ERR_UNSUPPORTED;
@@ -455,7 +461,7 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
 #define DAM_STFT_GENERIC(T, C, P)                                                                                     \
     hipLaunchKernelGGL((stft_generic_kernel<T, C, P>), ggrid, dim3(256), lds, s, (const T*)pcm, n_samples, outer_stride, \
                        (int)n_inner, inner_stride, channel_stride, window, tw, gain, n_fft, hop, n_frames, amin, floor_db, \
-                       normalize, out, out_tail, n_tail)
+                       normalize, out, out_tail, n_tail, indirect)
         if (pcm_dtype == DAM_PCM_F32) {
             if (channels == 1) DAM_STFT_GENERIC(float, 1, false);
             else if (planar) DAM_STFT_GENERIC(float, 2, true);
@@ -478,7 +484,7 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
 #define DAM_STFT_LAUNCH(T, C, P)                                                                              \
     hipLaunchKernelGGL((stft2048_kernel<T, C, P>), grid, block, 0, s, (const T*)pcm, n_samples, outer_stride, \
                        (int)n_inner, inner_stride, channel_stride, window, tw, gain, hop, n_frames, tiles_per_track, \
-                       n_tiles, amin, floor_db, normalize, out, out_tail, n_tail)
+                       n_tiles, amin, floor_db, normalize, out, out_tail, n_tail, indirect)
     if (pcm_dtype == DAM_PCM_F32) {
         if (channels == 1) DAM_STFT_LAUNCH(float, 1, false);
         else if (planar) DAM_STFT_LAUNCH(float, 2, true);

@@ -36,6 +36,10 @@ typedef enum dam_status {
 } dam_status;
 
 typedef enum dam_pcm_dtype { DAM_PCM_F32 = 0, DAM_PCM_F64 = 1 } dam_pcm_dtype;
+/* OR-ed into pcm_dtype: `pcm` is a DEVICE word holding the address of the PCM (const void* const*), read when the kernel
+ * starts.  A launch captured in a hipGraph then follows whichever resident batch the word points at -- the caller re-points
+ * the word (8 bytes) instead of copying a batch into the graph's fixed input buffer.  Layout arguments describe the pointee. */
+#define DAM_PCM_INDIRECT 0x100
 struct dam_bn_fin;      /* defined in the BatchNorm section */
 struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 

@@ -245,6 +245,39 @@ def test_train_step_graph_equals_eager(dam):
     assert losses[0][-1] < losses[0][0]
 
 
+def test_train_step_bind_clips_reads_resident_batches_in_place(dam):
+    """bind_clips(): the captured step follows the front-end's address word to whichever resident batch it points at --
+    bitwise the losses of load_clips() (the copy into the static input) over a rotation of batches, back and forth."""
+    from deep_audio_mixer_amd.engine import TrainStep
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    g = torch.Generator(device='cuda').manual_seed(5)
+    pool = 0.1 * torch.randn((6, 3, 16 * 1024, 2), generator=g, device='cuda')      # three batches of two clips, mix last
+    pool[:, 2] = pool[:, :2].sum(1)
+    order = [0, 2, 1, 1, 0]
+    losses = []
+    for bind in (False, True):
+        torch.manual_seed(1)
+        model = ResNet18(n_stems=2, input_shape=(1025, 17)).cuda().train()
+        step = TrainStep(model, Adam(model.parameters(), weight_decay=1e-5), 2, 16 * 1024, 2, batch=2, use_graph=True)
+        step.load_clips(pool[:2])
+        step.capture(warmup=2)
+        out = []
+        for k in order:
+            (step.bind_clips if bind else step.load_clips)(pool[2 * k:2 * k + 2])
+            out.append(step().item())
+        if bind:        # and back to the static buffer
+            step.load_clips(pool[4:6])
+            out.append(step().item())
+        else:
+            step.load_clips(pool[4:6])
+            out.append(step().item())
+        losses.append(out)
+    assert losses[0] == losses[1]
+    with pytest.raises(ValueError):
+        step.bind_clips(pool[:2].cpu())
+
+
 def test_mix_song_smooth_matches_oracle(dam):
     from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
     from deep_audio_mixer_amd.inference_utils import mix_song_smooth
