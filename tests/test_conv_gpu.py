@@ -384,3 +384,36 @@ def test_dgrad_bn_backward_sums_epilogue(ops, B, C, H, W):
         b = ops.bn_backward(dx, None, x, gamma, mean, invstd, tr, mask_affine=(msc, msh), partials=partials)
         for u, v in zip(a, b):
             close(v, u.double().cpu(), 2e-5)
+
+
+def test_full_size_strided_wgrad_and_backward_sums(ops):
+    """BASELINE size (C3: batch 8, 1025x130): the strided 16->32 weight gradient (stride-2 row-streaming kernel, 232 strips of
+    nine two-row slots) against float64, and the BatchNorm-backward sums of the layer1 data-gradient epilogue (248 records)
+    against float64 sums of the kernel's own output."""
+    g = torch.Generator().manual_seed(77)
+    B, H, W = 8, 1025, 130
+    x = torch.randn(B, 16, H, W, generator=g)
+    dy = torch.randn(B, 32, 513, 65, generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (32, 16, 3, 3), dy.double(), 2, 1)
+    got = ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), 32, 3, 3, 2, 1, 1)
+    close(got, want, 1e-4)
+    # sums epilogue: dx of a 16->16 3x3 convolution's data gradient, x = the BatchNorm input
+    dy1 = torch.randn(B, H, W, 16, generator=g).cuda()
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12
+    c1 = (torch.randn(B, H, W, 16, generator=g) * 2 - 0.5).cuda()
+    gamma, beta = (torch.rand(16, generator=g) + 0.5).cuda(), (0.3 * torch.randn(16, generator=g)).cuda()
+    mean = c1.double().mean((0, 1, 2)).float()
+    invstd = (1.0 / torch.sqrt(c1.double().var((0, 1, 2), unbiased=False) + 1e-5)).float()
+    msc = gamma * invstd
+    msh = beta - mean * msc
+    wpt = ops.pack_weights(w.cuda(), transpose=True)
+    dx, partials = ops.conv2d_dgrad(dy1, wpt, 16, H, W, 3, 3, 1, 1, 1, bn_bwd=(c1, mean, invstd, msc, msh))
+    assert partials is not None and partials[1] == 248
+    assert torch.equal(dx, ops.conv2d_dgrad(dy1, wpt, 16, H, W, 3, 3, 1, 1, 1))
+    rec, parts = partials
+    sums = rec[:parts * 32].view(parts, 16, 2).double().sum(0)
+    dz = dx.double() * ((c1.double() * msc.double() + msh.double()) > 0)
+    xhat = (c1.double() - mean.double()) * invstd.double()
+    n = B * H * W
+    for col, ref in ((0, dz.sum((0, 1, 2))), (1, (dz * xhat).sum((0, 1, 2)))):
+        assert (sums[:, col] - ref).abs().max().item() <= 1e-5 * n ** 0.5 * dz.abs().max().item() + 1e-2
