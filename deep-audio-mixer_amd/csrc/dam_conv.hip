@@ -500,9 +500,10 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     if (bn_parts_host) *bn_parts_host = 0;
     BnBwdEpi bwd{};
     if (bn_bwd && bn_bwd->x) {
-        if (!bn_partial || !bn_parts_host || res || bn_fin || !bn_bwd->mean || !bn_bwd->invstd || !bn_bwd->mask_scale ||
+        if (!bn_partial || !bn_parts_host || bn_fin || !bn_bwd->mean || !bn_bwd->invstd || !bn_bwd->mask_scale ||
             !bn_bwd->mask_shift) return DAM_ERR_BAD_ARG;
-        bwd = BnBwdEpi{bn_bwd->x, bn_bwd->mean, bn_bwd->invstd, bn_bwd->mask_scale, bn_bwd->mask_shift};
+        if (res && (!bn_bwd->res_mask_bits || !res_mask)) return DAM_ERR_BAD_ARG;      // bytes for the kernels that can, floats for the rest
+        bwd = BnBwdEpi{bn_bwd->x, bn_bwd->mean, bn_bwd->invstd, bn_bwd->mask_scale, bn_bwd->mask_shift, bn_bwd->res_mask_bits};
     }
     BnFinArgs fin{};
     if (bn_fin && bn_partial) {
@@ -567,7 +568,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     if (!getenv("DAM_NO_PIPE")) {
         int parts = 0;
         const int rc = conv_pipe_try(g, h_hi - h_lo, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace,
-                                     fin.counter ? nullptr : bn_partial, &parts, bwd, st);
+                                     (fin.counter || (bwd.x && res)) ? nullptr : bn_partial, &parts, (bwd.x && res) ? BnBwdEpi{} : bwd, st);
         if (rc == DAM_OK && bn_partial && bn_parts_host) *bn_parts_host = parts;
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
     }

@@ -34,6 +34,7 @@ struct ConvGeo {
 struct BnBwdEpi {
     const float* x;          // null: off
     const float* mean; const float* invstd; const float* mscale; const float* mshift;
+    const unsigned char* res_bits;   // with a residual operand: its ReLU mask as sign bytes (the float mask stays the fallback)
 };
 
 struct StripGeo {

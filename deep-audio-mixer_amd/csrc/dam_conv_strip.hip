@@ -114,8 +114,10 @@ __device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&
 // LW: loader shape -- false: rows of up to 144 (16 ch) / 80 (32 ch) cells, true: up to 224 / 112 cells (the reference's native
 // 216-frame spectrograms and their half-resolution stage)
 // EPI: the BatchNorm-backward sums epilogue (BnBwdEpi) is compiled in -- its per-lane constants cost 16*NB registers, so only
-// the data-gradient shapes that use it are instantiated with it
-template <int MB, int NB, int NCH, bool T33, bool LW, bool EPI>
+// the data-gradient shapes that use it are instantiated with it.  1: the launch has no residual, x rides in the residual
+// operand.  2: the launch carries the identity shortcut (residual operand, its ReLU mask as sign BYTES in `res_mask`) and the
+// sums are those of the BatchNorm UPSTREAM of the block input (its x is a third prefetched operand)
+template <int MB, int NB, int NCH, bool T33, bool LW, int EPI>
 __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
@@ -350,6 +352,12 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         const_cast<char*>(reinterpret_cast<const char*>(res)) + (res ? (size_t)img * img_bytes_o : 0), 0, res ? img_bytes_o : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(res_mask)) + (res_mask ? (size_t)img * img_bytes_o : 0), 0, res_mask ? img_bytes_o : 0, 0x00020000);
+    // EPI == 2: the sums' x (same geometry as the output) and the residual's sign bytes (one per channel quad)
+    const __amdgpu_buffer_rsrc_t x2rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(bwd.x)) + (EPI == 2 ? (size_t)img * img_bytes_o : 0), 0, EPI == 2 ? img_bytes_o : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bbrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(res_mask)) + (EPI == 2 ? (size_t)img * (img_bytes_o >> 4) : 0), 0,
+        EPI == 2 ? (img_bytes_o >> 4) : 0, 0x00020000);
     v4f bias4[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 
     // BatchNorm-backward sums epilogue (BnBwdEpi): `res` is the BatchNorm's input x; per lane the two affine maps of its
     // channel quad: mask = x*mscale + mshift > 0, xhat = x*invstd - mean*invstd.  The sums live in st_s1 / st_s2.
-    constexpr bool epi_bwd = EPI;
+    constexpr bool epi_bwd = EPI != 0;
     v4f bw_ms[EPI ? NB : 1], bw_mh[EPI ? NB : 1], bw_k1[EPI ? NB : 1], bw_k2[EPI ? NB : 1];
 #pragma unroll
     for (int nb = 0; nb < (EPI ? NB : 0); ++nb) {
@@ -396,7 +404,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     // one slot before they are needed -- in the write-out slot the group's vector instructions only get to issue once the
     // other group's MFMA stream has drained, and a load issued then would put its whole latency into the slot's tail
     constexpr bool RES_PF = MB * NB <= 4;
-    v4f res_pf[RES_PF ? MB : 1][RES_PF ? NB : 1], msk_pf[RES_PF ? MB : 1][RES_PF ? NB : 1];
+    v4f res_pf[RES_PF ? MB : 1][RES_PF ? NB : 1], msk_pf[RES_PF && EPI != 2 ? MB : 1][RES_PF && EPI != 2 ? NB : 1];
+    v4f x_pf[EPI == 2 ? MB : 1][EPI == 2 ? NB : 1];
+    int mskb_pf[EPI == 2 ? MB : 1][EPI == 2 ? NB : 1];
+    static_assert(EPI != 2 || RES_PF, "the residual + sums epilogue is built on the prefetch path");
 
     for (int s = 0; grp < 2 && s < n_slots; ++s) {
         if (false) {
@@ -526,7 +537,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {       // pixels past the image: out of the buffer's range, reads 0
                             res_pf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
-                            if (res_mask)
+                            if constexpr (EPI == 2) {
+                                mskb_pf[mb][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(bbrsrc, (voff + nb * 64) >> 4, 0, 0);
+                                x_pf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(x2rsrc, voff + nb * 64, 0, 0));
+                            } else if (res_mask)
                                 msk_pf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
                         }
                     }
@@ -554,12 +568,17 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                         v4f v = acc[mb][nb] + bias4[nb];
                         if (res) {
                             v4f rv, mv;
-                            if constexpr (RES_PF) { rv = res_pf[mb][nb]; mv = msk_pf[mb][nb]; }
+                            if constexpr (EPI == 2) { rv = res_pf[mb][nb]; }
+                            else if constexpr (RES_PF) { rv = res_pf[mb][nb]; mv = msk_pf[mb][nb]; }
                             else {
                                 rv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
                                 if (res_mask) mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
                             }
-                            if constexpr (epi_bwd) {    // rv = the BatchNorm's input at this pixel: sums only, v goes out as it is
+                            if constexpr (EPI == 2) {   // identity shortcut: + res where the block output was positive (sign bytes)
+                                const int b8 = mskb_pf[mb][nb];
+                                v.x += (b8 & 1) ? rv.x : 0.f; v.y += (b8 & 2) ? rv.y : 0.f;
+                                v.z += (b8 & 4) ? rv.z : 0.f; v.w += (b8 & 8) ? rv.w : 0.f;
+                            } else if constexpr (EPI == 1) {    // rv = the BatchNorm's input at this pixel: sums only, v goes out as it is
                                 const v4f m = __builtin_elementwise_fma(rv, bw_ms[nb], bw_mh[nb]);
                                 const v4f xh = __builtin_elementwise_fma(rv, bw_k1[nb], bw_k2[nb]);
                                 v4f dz;
@@ -577,6 +596,17 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                         }
                         if (relu_out) v = __builtin_elementwise_max(v, (v4f){0.f, 0.f, 0.f, 0.f});
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), yrsrc, voff + nb * 64, 0, 0);
+                        if constexpr (EPI == 2) {       // v is the gradient reaching relu(bn(x)) of the block input: its two sums
+                            const v4f xq = x_pf[mb][nb];
+                            const v4f m = __builtin_elementwise_fma(xq, bw_ms[nb], bw_mh[nb]);
+                            const v4f xh = __builtin_elementwise_fma(xq, bw_k1[nb], bw_k2[nb]);
+                            v4f dz;
+                            dz.x = m.x > 0.f ? v.x : 0.f; dz.y = m.y > 0.f ? v.y : 0.f;
+                            dz.z = m.z > 0.f ? v.z : 0.f; dz.w = m.w > 0.f ? v.w : 0.f;
+                            st_s1[nb][0] += dz.xy; st_s1[nb][1] += dz.zw;
+                            st_s2[nb][0] = __builtin_elementwise_fma(dz.xy, xh.xy, st_s2[nb][0]);
+                            st_s2[nb][1] = __builtin_elementwise_fma(dz.zw, xh.zw, st_s2[nb][1]);
+                        }
 #ifndef DAM_STAMPS
                         if (stats && !epi_bwd) {
                             if (!st_have) { st_nk[nb][0] = -v.xy; st_nk[nb][1] = -v.zw; }
@@ -696,7 +726,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 }  // namespace
 
 // Returns DAM_OK if launched, DAM_ERR_UNSUPPORTED if the layer does not fit this variant (caller falls back).
-template <int MB, int NB, int NCH, bool T33, bool LW = false, bool EPI = false>
+template <int MB, int NB, int NCH, bool T33, bool LW = false, int EPI = 0>
 static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, const float* Wp, const float* bias, float* Y,
                         const float* res, const float* res_mask, float* stats, const float* in_scale, const float* in_shift,
                         const BnFinArgs& fin, const BnBwdEpi& bwd, hipStream_t st) {
@@ -721,9 +751,10 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
                    const float* in_scale, const float* in_shift, const BnBwdEpi& bwd, hipStream_t st) {
     BnFinArgs fin{};
     if (fin_in && stats && !bwd.x) fin = *fin_in;
-    if (bwd.x && (res || !stats)) return DAM_ERR_BAD_ARG;      // the epilogue reads x through the residual path
+    if (bwd.x && !stats) return DAM_ERR_BAD_ARG;
+    if (bwd.x && res && !bwd.res_bits) return DAM_ERR_UNSUPPORTED;     // with a residual the sums need its mask as sign bytes
     ConvGeo g = g_in;                 // the caller's copy stays as it is for the tile kernel
-    g.epi_bwd = bwd.x ? 1 : 0;
+    g.epi_bwd = bwd.x ? (res ? 2 : 1) : 0;
     if (g.nB == 3 && g.step_w < 0) {  // same taps walked left to right: column step becomes +1, weight taps are re-indexed
         g.off_w += 2 * g.step_w; g.step_w = -g.step_w;
         g.wt_base += 2 * g.wt_sb; g.wt_sb = -g.wt_sb;
@@ -782,13 +813,17 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     if (fin.counter && lds < (size_t)32 * 1024 + STRIP_THREADS * 3 * sizeof(double)) lds = (size_t)32 * 1024 + STRIP_THREADS * 3 * sizeof(double);
     // 3x3 taps, stride 1, unit column step: compile-time item grid with immediate operand offsets
     const bool t33 = g.nA == 3 && g.nB == 3 && g.s == 1 && g.step_w == 1;
-#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, (bwd.x ? bwd.x : res), res_mask, stats, in_scale, in_shift, fin, bwd, st
+#define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, (bwd.x && !res ? bwd.x : res), (bwd.x && res ? reinterpret_cast<const float*>(bwd.res_bits) : res_mask), stats, in_scale, in_shift, fin, bwd, st
+    if (bwd.x && res) { // residual + upstream sums: the 16-channel full-resolution data gradient only (stem <- first block)
+        if (!t33 || g.nchunks != 1 || MB != 4 || NB != 1) return DAM_ERR_UNSUPPORTED;
+        return wide ? launch_strip<4, 1, 1, true, true, 2>(DAM_STRIP_ARGS) : launch_strip<4, 1, 1, true, false, 2>(DAM_STRIP_ARGS);
+    }
     if (bwd.x) {        // sums epilogue: the 3x3 / stride-1 data gradients of the 16- and 32-channel stages only
         if (!t33) return DAM_ERR_UNSUPPORTED;
         if (g.nchunks == 1 && MB == 4 && NB == 1)
-            return wide ? launch_strip<4, 1, 1, true, true, true>(DAM_STRIP_ARGS) : launch_strip<4, 1, 1, true, false, true>(DAM_STRIP_ARGS);
+            return wide ? launch_strip<4, 1, 1, true, true, 1>(DAM_STRIP_ARGS) : launch_strip<4, 1, 1, true, false, 1>(DAM_STRIP_ARGS);
         if (g.nchunks == 2 && MB == 2 && NB == 2)
-            return wide ? launch_strip<2, 2, 2, true, true, true>(DAM_STRIP_ARGS) : launch_strip<2, 2, 2, true, false, true>(DAM_STRIP_ARGS);
+            return wide ? launch_strip<2, 2, 2, true, true, 1>(DAM_STRIP_ARGS) : launch_strip<2, 2, 2, true, false, 1>(DAM_STRIP_ARGS);
         return DAM_ERR_UNSUPPORTED;
     }
 #define DAM_STRIP_CASE(M_, N_)                                                                                           \

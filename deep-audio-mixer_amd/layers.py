@@ -207,6 +207,17 @@ def inference_mode(module):
     return not module.training and not torch.is_grad_enabled()
 
 
+class _UpstreamBn:
+    """What the consumer of a relu(bn(c)) activation needs to take that BatchNorm's two backward sums in its own data-gradient
+    epilogue (ops.conv2d_dgrad(bn_bwd=)), and the slot where it leaves them for the producer's backward.  Travels as an attribute
+    of the activation tensor: ConvBnReluFn.forward attaches it, an identity BasicBlock that receives the tensor picks it up."""
+    __slots__ = ('c', 'mean', 'invstd', 'scale', 'shift', 'partials', 'dx_ptr')
+
+    def __init__(self, c, mean, invstd, scale, shift):
+        self.c, self.mean, self.invstd, self.scale, self.shift = c, mean, invstd, scale, shift
+        self.partials, self.dx_ptr = None, None
+
+
 class ConvBnReluFn(torch.autograd.Function):
     """a = relu(bn(conv(x) [+ bias]))  -- ResNet stem (models/model_resnet.py:97) and
     ConvBlock2d (models/model_scalar_1s.py:179-190 without the dropout)."""
@@ -218,6 +229,7 @@ class ConvBnReluFn(torch.autograd.Function):
         c, mean, invstd, scale, shift = spec.fwd_bn(x, w.detach(), bn, training, None if bias is None else bias.detach())
         a = ops.bn_apply(c, scale, shift, relu=True)
         ctx.save_for_backward(x, w, c, gamma, mean, invstd, scale, shift)
+        ctx.up = a._dam_upstream = _UpstreamBn(c, mean, invstd, scale, shift) if ops.DGRAD_BN_SUMS else None
         ctx.spec, ctx.training, ctx.has_bias = spec, training, bias is not None
         ctx.slots = (_slot(w), _slot(bias), _slot(gamma), _slot(beta))
         return a
@@ -228,8 +240,15 @@ class ConvBnReluFn(torch.autograd.Function):
         spec = ctx.spec
         # relu mask recomputed from c and the forward's affine: the saved activation is not read (nor kept by this node)
         sw, sb, sg, sbt = ctx.slots
-        dc, dgamma, dbeta = ops.bn_backward(da.contiguous(), None, c, gamma, mean, invstd, ctx.training,
-                                            mask_affine=(scale, shift), dgamma=sg, dbeta=sbt)
+        da = da.contiguous()
+        # the consumer (an identity block's conv1 data gradient) may have left this BatchNorm's two sums beside the gradient
+        up, sums = ctx.up, None
+        if up is not None:
+            if up.partials is not None and up.dx_ptr == da.data_ptr():
+                sums = up.partials
+            up.partials = None
+        dc, dgamma, dbeta = ops.bn_backward(da, None, c, gamma, mean, invstd, ctx.training,
+                                            mask_affine=(scale, shift), dgamma=sg, dbeta=sbt, partials=sums)
         dw = spec.wgrad(x, dc, out=None if sw is None else sw.view(w.shape))
         dbias = ops.channel_sum(dc, spec.cout, out=sb) if ctx.has_bias else None
         dx = spec.dgrad(dc, w, _hw(x, spec.in_nchw)) if ctx.needs_input_grad[0] else None
@@ -282,6 +301,9 @@ class BasicBlockFn(torch.autograd.Function):
                                                                        res=x, sign_bits=True)
             ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, bits)
         ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None
+        # an identity block's conv1 data gradient + shortcut IS the gradient of its input: if that input is a relu(bn(c)) whose
+        # producer left its record (_UpstreamBn: the stem in front of the first block), backward takes that BatchNorm's sums too
+        ctx.upstream = getattr(x, '_dam_upstream', None) if wsc is None else None
         ctx.slots = tuple(_slot(p) for p in (w1, g1, b1, w2, g2, b2, wsc, gsc, bsc))
         return out
 
@@ -319,7 +341,13 @@ class BasicBlockFn(torch.autograd.Function):
             dx = blk.spec1.dgrad(dc1, w1, hw)
             blk.spec_sc.dgrad(dcs, wsc, hw, accumulate_into=dx)
             return (dx,) + first + (keep(dws, s_ws), keep(dgs, s_gs), keep(dbs, s_bs), None, None)
-        dx = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out)      # + dout * (out > 0): identity shortcut
+        up = ctx.upstream
+        if up is not None and ops.DGRAD_BN_SUMS and up.c.shape == x.shape:
+            dx, sums = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out, res_mask_bits=bits,
+                                       bn_bwd=(up.c, up.mean, up.invstd, up.scale, up.shift))
+            up.partials, up.dx_ptr = sums, dx.data_ptr()
+        else:
+            dx = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out)      # + dout * (out > 0): identity shortcut
         return (dx,) + first + (None, None, None, None, None)
 
 

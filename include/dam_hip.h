@@ -137,7 +137,7 @@ int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int6
  * in *bn_parts_host (a HOST int); 0 there means "not produced" and the caller runs dam_bn_stats_f32 instead.
  * Feed the records to dam_bn_finalize_f32 -- or pass bn_fin (see dam_bn_fin below): the launch's last workgroup then
  * merges them itself and writes save_mean / save_invstd / scale / shift (+ running statistics), no finalize launch.
- * bn_bwd (optional, see dam_bn_bwd_sums below; excludes res / bn_fin, needs bn_partial): the launch is a data gradient whose
+ * bn_bwd (optional, see dam_bn_bwd_sums below; excludes bn_fin, needs bn_partial; with res only if res_mask_bits is set there): the launch is a data gradient whose
  * output dy feeds the backward pass of y = relu(bn(x)); if it can, it also writes that pass's two per-channel sums as records
  * [*bn_parts_host][n_out][2] into bn_partial (then hand them to dam_bn_backward_f32 as partials_given); 0 records = not produced.
  * workspace (optional): scratch for split-K over the input channels (used for small-spatial, wide layers; at most
@@ -218,6 +218,11 @@ typedef struct dam_bn_fin {       /* host struct of device pointers: what dam_bn
  * Host struct of device pointers (x: the BatchNorm's input, shape of the launch's output; the rest: per channel). */
 typedef struct dam_bn_bwd_sums {
     const float* x; const float* mean; const float* invstd; const float* mask_scale; const float* mask_shift;
+    /* A data gradient that also carries an identity shortcut (res / res_mask given: dy = conv^T(..) + res * (res_mask > 0), the
+     * gradient reaching the block INPUT) can take the sums of the BatchNorm that produced that input -- the ResNet stem's
+     * relu(bn1(conv1(x))), models/model_resnet.py:97 -- if the shortcut's mask is also available as the sign bytes
+     * dam_bn_apply_f32 wrote (one byte per channel quad); res_mask stays the fallback of launches that cannot. */
+    const uint8_t* res_mask_bits;
 } dam_bn_bwd_sums;
 
 /* Training-mode statistics of x: save_mean, save_invstd = 1/sqrt(biased var + eps), the fused affine

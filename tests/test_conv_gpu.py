@@ -417,3 +417,41 @@ def test_full_size_strided_wgrad_and_backward_sums(ops):
     n = B * H * W
     for col, ref in ((0, dz.sum((0, 1, 2))), (1, (dz * xhat).sum((0, 1, 2)))):
         assert (sums[:, col] - ref).abs().max().item() <= 1e-5 * n ** 0.5 * dz.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 16, 41, 130), (3, 16, 23, 127), (1, 16, 9, 216), (2, 32, 21, 65), (1, 64, 19, 33)])
+def test_dgrad_identity_shortcut_with_upstream_sums(ops, B, C, H, W):
+    """conv2d_dgrad(res=, res_mask=, res_mask_bits=, bn_bwd=): the data gradient that carries an identity shortcut is the
+    gradient reaching the block input, i.e. relu(bn(x)) of the layer upstream (the stem in front of the first block).  The
+    result is bitwise the float-mask launch; the 16-channel row-ring kernel also leaves the upstream BatchNorm's two sums,
+    the other kernels return partials None."""
+    g = torch.Generator().manual_seed(B * 10 + C + H + W)
+    dy = torch.randn(B, H, W, C, generator=g).cuda()
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    r = torch.randn(B, H, W, C, generator=g).cuda()
+    m = torch.randn(B, H, W, C, generator=g).cuda()
+    bits = ((m > 0).view(B, H, W, C // 4, 4).to(torch.int32) * torch.tensor([1, 2, 4, 8], device='cuda', dtype=torch.int32)
+            ).sum(-1).to(torch.uint8).contiguous()
+    x = (torch.randn(B, H, W, C, generator=g) * 1.3 + 0.2).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (0.3 * torch.randn(C, generator=g)).cuda()
+    mean = x.double().mean((0, 1, 2)).float()
+    invstd = (1.0 / torch.sqrt(x.double().var((0, 1, 2), unbiased=False) + 1e-5)).float()
+    msc = gamma * invstd
+    msh = beta - mean * msc
+    wpt = ops.pack_weights(w.cuda(), transpose=True)
+    plain = ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1, res=r, res_mask=m)
+    dx, partials = ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1, res=r, res_mask=m, res_mask_bits=bits,
+                                    bn_bwd=(x, mean, invstd, msc, msh))
+    assert torch.equal(dx, plain)
+    if C != 16:
+        assert partials is None
+        return
+    rec, parts = partials
+    sums = rec[:parts * C * 2].view(parts, C, 2).double().sum(0).cpu()
+    dz = dx.double() * ((x.double() * msc.double() + msh.double()) > 0)
+    xhat = (x.double() - mean.double()) * invstd.double()
+    n = B * H * W
+    for col, ref in ((0, dz.sum((0, 1, 2)).cpu()), (1, (dz * xhat).sum((0, 1, 2)).cpu())):
+        assert (sums[:, col] - ref).abs().max().item() <= 2e-5 * n ** 0.5 * dz.abs().max().item() + 1e-3
+    with pytest.raises(ValueError):
+        ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1, res=r, res_mask=m, bn_bwd=(x, mean, invstd, msc, msh))
