@@ -80,7 +80,8 @@ class BnFin(ctypes.Structure):
 
 class BnBwdSums(ctypes.Structure):
     """struct dam_bn_bwd_sums (include/dam_hip.h): BatchNorm-backward sums taken in a data-gradient epilogue."""
-    _fields_ = [('x', c_p), ('mean', c_p), ('invstd', c_p), ('mask_scale', c_p), ('mask_shift', c_p), ('res_mask_bits', c_p)]
+    _fields_ = [('x', c_p), ('mean', c_p), ('invstd', c_p), ('mask_scale', c_p), ('mask_shift', c_p), ('res_mask_bits', c_p),
+                ('mask_bits', c_p)]
 
 
 _lib = None

@@ -500,10 +500,12 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     if (bn_parts_host) *bn_parts_host = 0;
     BnBwdEpi bwd{};
     if (bn_bwd && bn_bwd->x) {
-        if (!bn_partial || !bn_parts_host || bn_fin || !bn_bwd->mean || !bn_bwd->invstd || !bn_bwd->mask_scale ||
-            !bn_bwd->mask_shift) return DAM_ERR_BAD_ARG;
+        if (!bn_partial || !bn_parts_host || bn_fin || !bn_bwd->mean || !bn_bwd->invstd) return DAM_ERR_BAD_ARG;
+        if (bn_bwd->mask_bits ? (bn_bwd->mask_scale || bn_bwd->mask_shift || !res) : (!bn_bwd->mask_scale || !bn_bwd->mask_shift))
+            return DAM_ERR_BAD_ARG;
         if (res && (!bn_bwd->res_mask_bits || !res_mask)) return DAM_ERR_BAD_ARG;      // bytes for the kernels that can, floats for the rest
-        bwd = BnBwdEpi{bn_bwd->x, bn_bwd->mean, bn_bwd->invstd, bn_bwd->mask_scale, bn_bwd->mask_shift, bn_bwd->res_mask_bits};
+        bwd = BnBwdEpi{bn_bwd->x, bn_bwd->mean, bn_bwd->invstd, bn_bwd->mask_scale, bn_bwd->mask_shift, bn_bwd->res_mask_bits,
+                       bn_bwd->mask_bits};
     }
     BnFinArgs fin{};
     if (bn_fin && bn_partial) {

@@ -35,6 +35,7 @@ struct BnBwdEpi {
     const float* x;          // null: off
     const float* mean; const float* invstd; const float* mscale; const float* mshift;
     const unsigned char* res_bits;   // with a residual operand: its ReLU mask as sign bytes (the float mask stays the fallback)
+    const unsigned char* mask_bits;  // the BatchNorm's own ReLU mask as sign bytes instead of mscale / mshift (relu(bn(x) + shortcut))
 };
 
 struct StripGeo {

@@ -116,7 +116,8 @@ __device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&
 // EPI: the BatchNorm-backward sums epilogue (BnBwdEpi) is compiled in -- its per-lane constants cost 16*NB registers, so only
 // the data-gradient shapes that use it are instantiated with it.  1: the launch has no residual, x rides in the residual
 // operand.  2: the launch carries the identity shortcut (residual operand, its ReLU mask as sign BYTES in `res_mask`) and the
-// sums are those of the BatchNorm UPSTREAM of the block input (its x is a third prefetched operand)
+// sums are those of the BatchNorm UPSTREAM of the block input (its x is a third prefetched operand).  3: as 2, the upstream ReLU
+// mask comes as sign bytes as well (bwd.mask_bits: the upstream layer is relu(bn(x) + shortcut), a residual block's bn2)
 template <int MB, int NB, int NCH, bool T33, bool LW, int EPI>
 __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
@@ -354,10 +355,13 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         const_cast<char*>(reinterpret_cast<const char*>(res_mask)) + (res_mask ? (size_t)img * img_bytes_o : 0), 0, res_mask ? img_bytes_o : 0, 0x00020000);
     // EPI == 2: the sums' x (same geometry as the output) and the residual's sign bytes (one per channel quad)
     const __amdgpu_buffer_rsrc_t x2rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(bwd.x)) + (EPI == 2 ? (size_t)img * img_bytes_o : 0), 0, EPI == 2 ? img_bytes_o : 0, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(bwd.x)) + (EPI >= 2 ? (size_t)img * img_bytes_o : 0), 0, EPI >= 2 ? img_bytes_o : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t bbrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(res_mask)) + (EPI == 2 ? (size_t)img * (img_bytes_o >> 4) : 0), 0,
-        EPI == 2 ? (img_bytes_o >> 4) : 0, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(res_mask)) + (EPI >= 2 ? (size_t)img * (img_bytes_o >> 4) : 0), 0,
+        EPI >= 2 ? (img_bytes_o >> 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ubrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(bwd.mask_bits)) + (EPI == 3 ? (size_t)img * (img_bytes_o >> 4) : 0), 0,
+        EPI == 3 ? (img_bytes_o >> 4) : 0, 0x00020000);
     v4f bias4[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -370,8 +374,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #pragma unroll
     for (int nb = 0; nb < (EPI ? NB : 0); ++nb) {
         const int ch = (nb0 + nb) * 16 + kq * 4;
-        bw_ms[nb] = *reinterpret_cast<const v4f*>(bwd.mscale + ch);
-        bw_mh[nb] = *reinterpret_cast<const v4f*>(bwd.mshift + ch);
+        if constexpr (EPI != 3) {
+            bw_ms[nb] = *reinterpret_cast<const v4f*>(bwd.mscale + ch);
+            bw_mh[nb] = *reinterpret_cast<const v4f*>(bwd.mshift + ch);
+        }
         bw_k1[nb] = *reinterpret_cast<const v4f*>(bwd.invstd + ch);
         bw_k2[nb] = -(*reinterpret_cast<const v4f*>(bwd.mean + ch)) * bw_k1[nb];
     }
@@ -404,10 +410,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     // one slot before they are needed -- in the write-out slot the group's vector instructions only get to issue once the
     // other group's MFMA stream has drained, and a load issued then would put its whole latency into the slot's tail
     constexpr bool RES_PF = MB * NB <= 4;
-    v4f res_pf[RES_PF ? MB : 1][RES_PF ? NB : 1], msk_pf[RES_PF && EPI != 2 ? MB : 1][RES_PF && EPI != 2 ? NB : 1];
-    v4f x_pf[EPI == 2 ? MB : 1][EPI == 2 ? NB : 1];
-    int mskb_pf[EPI == 2 ? MB : 1][EPI == 2 ? NB : 1];
-    static_assert(EPI != 2 || RES_PF, "the residual + sums epilogue is built on the prefetch path");
+    v4f res_pf[RES_PF ? MB : 1][RES_PF ? NB : 1], msk_pf[RES_PF && EPI < 2 ? MB : 1][RES_PF && EPI < 2 ? NB : 1];
+    v4f x_pf[EPI >= 2 ? MB : 1][EPI >= 2 ? NB : 1];
+    int mskb_pf[EPI >= 2 ? MB : 1][EPI >= 2 ? NB : 1], upb_pf[EPI == 3 ? MB : 1][EPI == 3 ? NB : 1];
+    static_assert(EPI < 2 || RES_PF, "the residual + sums epilogue is built on the prefetch path");
 
     for (int s = 0; grp < 2 && s < n_slots; ++s) {
         if (false) {
@@ -537,9 +543,11 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {       // pixels past the image: out of the buffer's range, reads 0
                             res_pf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
-                            if constexpr (EPI == 2) {
+                            if constexpr (EPI >= 2) {
                                 mskb_pf[mb][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(bbrsrc, (voff + nb * 64) >> 4, 0, 0);
                                 x_pf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(x2rsrc, voff + nb * 64, 0, 0));
+                                if constexpr (EPI == 3)
+                                    upb_pf[mb][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(ubrsrc, (voff + nb * 64) >> 4, 0, 0);
                             } else if (res_mask)
                                 msk_pf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
                         }
@@ -568,13 +576,13 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                         v4f v = acc[mb][nb] + bias4[nb];
                         if (res) {
                             v4f rv, mv;
-                            if constexpr (EPI == 2) { rv = res_pf[mb][nb]; }
+                            if constexpr (EPI >= 2) { rv = res_pf[mb][nb]; }
                             else if constexpr (RES_PF) { rv = res_pf[mb][nb]; mv = msk_pf[mb][nb]; }
                             else {
                                 rv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, voff + nb * 64, 0, 0));
                                 if (res_mask) mv = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff + nb * 64, 0, 0));
                             }
-                            if constexpr (EPI == 2) {   // identity shortcut: + res where the block output was positive (sign bytes)
+                            if constexpr (EPI >= 2) {   // identity shortcut: + res where the block output was positive (sign bytes)
                                 const int b8 = mskb_pf[mb][nb];
                                 v.x += (b8 & 1) ? rv.x : 0.f; v.y += (b8 & 2) ? rv.y : 0.f;
                                 v.z += (b8 & 4) ? rv.z : 0.f; v.w += (b8 & 8) ? rv.w : 0.f;
@@ -596,13 +604,19 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                         }
                         if (relu_out) v = __builtin_elementwise_max(v, (v4f){0.f, 0.f, 0.f, 0.f});
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), yrsrc, voff + nb * 64, 0, 0);
-                        if constexpr (EPI == 2) {       // v is the gradient reaching relu(bn(x)) of the block input: its two sums
+                        if constexpr (EPI >= 2) {       // v is the gradient reaching relu(bn(x) [+ ..]) of the block input: its two sums
                             const v4f xq = x_pf[mb][nb];
-                            const v4f m = __builtin_elementwise_fma(xq, bw_ms[nb], bw_mh[nb]);
                             const v4f xh = __builtin_elementwise_fma(xq, bw_k1[nb], bw_k2[nb]);
                             v4f dz;
-                            dz.x = m.x > 0.f ? v.x : 0.f; dz.y = m.y > 0.f ? v.y : 0.f;
-                            dz.z = m.z > 0.f ? v.z : 0.f; dz.w = m.w > 0.f ? v.w : 0.f;
+                            if constexpr (EPI == 3) {
+                                const int ub = upb_pf[mb][nb];
+                                dz.x = (ub & 1) ? v.x : 0.f; dz.y = (ub & 2) ? v.y : 0.f;
+                                dz.z = (ub & 4) ? v.z : 0.f; dz.w = (ub & 8) ? v.w : 0.f;
+                            } else {
+                                const v4f m = __builtin_elementwise_fma(xq, bw_ms[nb], bw_mh[nb]);
+                                dz.x = m.x > 0.f ? v.x : 0.f; dz.y = m.y > 0.f ? v.y : 0.f;
+                                dz.z = m.z > 0.f ? v.z : 0.f; dz.w = m.w > 0.f ? v.w : 0.f;
+                            }
                             st_s1[nb][0] += dz.xy; st_s1[nb][1] += dz.zw;
                             st_s2[nb][0] = __builtin_elementwise_fma(dz.xy, xh.xy, st_s2[nb][0]);
                             st_s2[nb][1] = __builtin_elementwise_fma(dz.zw, xh.zw, st_s2[nb][1]);
@@ -754,7 +768,8 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     if (bwd.x && !stats) return DAM_ERR_BAD_ARG;
     if (bwd.x && res && !bwd.res_bits) return DAM_ERR_UNSUPPORTED;     // with a residual the sums need its mask as sign bytes
     ConvGeo g = g_in;                 // the caller's copy stays as it is for the tile kernel
-    g.epi_bwd = bwd.x ? (res ? 2 : 1) : 0;
+    g.epi_bwd = bwd.x ? (res ? (bwd.mask_bits ? 3 : 2) : 1) : 0;
+    if (bwd.x && bwd.mask_bits && !res) return DAM_ERR_UNSUPPORTED;    // byte-masked sums exist with the residual epilogue only
     if (g.nB == 3 && g.step_w < 0) {  // same taps walked left to right: column step becomes +1, weight taps are re-indexed
         g.off_w += 2 * g.step_w; g.step_w = -g.step_w;
         g.wt_base += 2 * g.wt_sb; g.wt_sb = -g.wt_sb;
@@ -816,6 +831,8 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
 #define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, (bwd.x && !res ? bwd.x : res), (bwd.x && res ? reinterpret_cast<const float*>(bwd.res_bits) : res_mask), stats, in_scale, in_shift, fin, bwd, st
     if (bwd.x && res) { // residual + upstream sums: the 16-channel full-resolution data gradient only (stem <- first block)
         if (!t33 || g.nchunks != 1 || MB != 4 || NB != 1) return DAM_ERR_UNSUPPORTED;
+        if (bwd.mask_bits)
+            return wide ? launch_strip<4, 1, 1, true, true, 3>(DAM_STRIP_ARGS) : launch_strip<4, 1, 1, true, false, 3>(DAM_STRIP_ARGS);
         return wide ? launch_strip<4, 1, 1, true, true, 2>(DAM_STRIP_ARGS) : launch_strip<4, 1, 1, true, false, 2>(DAM_STRIP_ARGS);
     }
     if (bwd.x) {        // sums epilogue: the 3x3 / stride-1 data gradients of the 16- and 32-channel stages only

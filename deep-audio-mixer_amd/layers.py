@@ -211,11 +211,21 @@ class _UpstreamBn:
     """What the consumer of a relu(bn(c)) activation needs to take that BatchNorm's two backward sums in its own data-gradient
     epilogue (ops.conv2d_dgrad(bn_bwd=)), and the slot where it leaves them for the producer's backward.  Travels as an attribute
     of the activation tensor: ConvBnReluFn.forward attaches it, an identity BasicBlock that receives the tensor picks it up."""
-    __slots__ = ('c', 'mean', 'invstd', 'scale', 'shift', 'partials', 'dx_ptr')
+    __slots__ = ('c', 'mean', 'invstd', 'scale', 'shift', 'bits', 'partials', 'dx_ptr')
 
-    def __init__(self, c, mean, invstd, scale, shift):
-        self.c, self.mean, self.invstd, self.scale, self.shift = c, mean, invstd, scale, shift
+    def __init__(self, c, mean, invstd, scale, shift, bits=None):
+        # ReLU mask of the activation: fma(c, scale, shift) > 0 (plain relu(bn(c))) or the sign bytes of relu(bn(c) + shortcut)
+        self.c, self.mean, self.invstd, self.scale, self.shift, self.bits = c, mean, invstd, scale, shift, bits
         self.partials, self.dx_ptr = None, None
+
+    def request(self):
+        return (self.c, self.mean, self.invstd, self.scale, self.shift) + ((self.bits,) if self.bits is not None else ())
+
+    def take(self, grad):
+        """The sums the consumer left, if they belong to this gradient tensor; the slot is cleared either way."""
+        sums = self.partials if self.partials is not None and self.dx_ptr == grad.data_ptr() else None
+        self.partials = None
+        return sums
 
 
 class ConvBnReluFn(torch.autograd.Function):
@@ -242,11 +252,7 @@ class ConvBnReluFn(torch.autograd.Function):
         sw, sb, sg, sbt = ctx.slots
         da = da.contiguous()
         # the consumer (an identity block's conv1 data gradient) may have left this BatchNorm's two sums beside the gradient
-        up, sums = ctx.up, None
-        if up is not None:
-            if up.partials is not None and up.dx_ptr == da.data_ptr():
-                sums = up.partials
-            up.partials = None
+        sums = ctx.up.take(da) if ctx.up is not None else None
         dc, dgamma, dbeta = ops.bn_backward(da, None, c, gamma, mean, invstd, ctx.training,
                                             mask_affine=(scale, shift), dgamma=sg, dbeta=sbt, partials=sums)
         dw = spec.wgrad(x, dc, out=None if sw is None else sw.view(w.shape))
@@ -300,6 +306,10 @@ class BasicBlockFn(torch.autograd.Function):
             c2, m2, i2, sc2, sh2, (out, bits) = blk.spec2.fwd_bn_apply(c1, w2.detach(), blk.bn2, training, in_affine=(sc1, sh1),
                                                                        res=x, sign_bits=True)
             ctx.save_for_backward(x, w1, g1, w2, g2, c1, c2, out, m1, i1, m2, i2, sc1, sh1, bits)
+        # this block's bn2 can be the upstream BatchNorm of the next identity block in turn (mask = the sign bytes of `out`)
+        ctx.up_self = None
+        if wsc is None and ops.DGRAD_BN_SUMS:
+            ctx.up_self = out._dam_upstream = _UpstreamBn(c2, m2, i2, None, None, bits)
         ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None
         # an identity block's conv1 data gradient + shortcut IS the gradient of its input: if that input is a relu(bn(c)) whose
         # producer left its record (_UpstreamBn: the stem in front of the first block), backward takes that BatchNorm's sums too
@@ -323,7 +333,8 @@ class BasicBlockFn(torch.autograd.Function):
             (dc2, dg2, db2), (dcs, dgs, dbs) = ops.bn_backward_pair(dout, None, (c2, g2, m2, i2, s_g2, s_b2),
                                                                     (cs, gsc, ms, is_, s_gs, s_bs), tr, mask_bits=bits)
         else:
-            dc2, dg2, db2 = ops.bn_backward(dout, None, c2, g2, m2, i2, tr, dgamma=s_g2, dbeta=s_b2, mask_bits=bits)
+            sums2 = ctx.up_self.take(dout) if ctx.up_self is not None else None      # left by the next block's data gradient
+            dc2, dg2, db2 = ops.bn_backward(dout, None, c2, g2, m2, i2, tr, dgamma=s_g2, dbeta=s_b2, mask_bits=bits, partials=sums2)
         dw2 = blk.spec2.wgrad(c1, dc2, in_affine=(sc1, sh1), out=wview(s_w2, w2))
         # conv2's data gradient IS the gradient reaching relu(bn1(c1)): where the kernel can, bn1's two backward sums come out
         # of its epilogue (sums = (records, count)) and bn_backward only finalizes and applies
@@ -343,8 +354,7 @@ class BasicBlockFn(torch.autograd.Function):
             return (dx,) + first + (keep(dws, s_ws), keep(dgs, s_gs), keep(dbs, s_bs), None, None)
         up = ctx.upstream
         if up is not None and ops.DGRAD_BN_SUMS and up.c.shape == x.shape:
-            dx, sums = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out, res_mask_bits=bits,
-                                       bn_bwd=(up.c, up.mean, up.invstd, up.scale, up.shift))
+            dx, sums = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out, res_mask_bits=bits, bn_bwd=up.request())
             up.partials, up.dx_ptr = sums, dx.data_ptr()
         else:
             dx = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out)      # + dout * (out > 0): identity shortcut

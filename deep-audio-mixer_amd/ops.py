@@ -147,7 +147,8 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
                  bn_bwd=None, res_mask_bits=None):
     """dy: NHWC [B,Ho,Wo,Cout]; wpt packed with transpose=True.  Returns dx NHWC [B,H,W,n_in16]
     (+ res * (res_mask > 0) if given).  With accumulate_into=dx0 the result is added to dx0 in place.
-    bn_bwd=(x, save_mean, save_invstd, mask_scale, mask_shift): dx is the gradient reaching relu(bn(x)); returns
+    bn_bwd=(x, save_mean, save_invstd, mask_scale, mask_shift[, mask_bits]): dx is the gradient reaching relu(bn(x)) (or, with
+    mask_bits and scale = shift = None, relu(bn(x) + shortcut) whose sign bytes they are); returns
     (dx, partials) where partials = (records, count) for bn_backward(partials=) when the launch could also take that
     BatchNorm's two backward sums from its epilogue, else None (stride 1; with a residual only when its mask is also given
     as the sign bytes of bn_apply, res_mask_bits -- the float res_mask serves the launches that cannot use them)."""
@@ -158,7 +159,10 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
         if res is not None and (res_mask is None or res_mask_bits is None):
             raise ValueError('bn_bwd with a residual: res_mask and res_mask_bits')
         _f32c(dy, 'dy'), _f32c(res, 'res'), _f32c(res_mask, 'res_mask')
-        xb, mean, invstd, msc, msh = bn_bwd
+        xb, mean, invstd, msc, msh = bn_bwd[:5]
+        up_bits = bn_bwd[5] if len(bn_bwd) > 5 else None     # the BatchNorm's own mask as sign bytes (msc = msh = None then)
+        if (up_bits is None) == (msc is None) or (up_bits is not None and res is None):
+            raise ValueError('bn_bwd: the mask as (scale, shift) or -- with a residual -- as sign bytes')
         _lib.require_cuda(xb)
         B, Ho, Wo, Co = dy.shape
         n16 = (n_in + 15) // 16 * 16
@@ -166,7 +170,8 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
             raise ValueError('bn_bwd: x has the shape of the data gradient')
         dx = torch.empty((B, H, W, n16), dtype=torch.float32, device=dy.device)
         rec = torch.empty(_lib.lib().dam_bn_workspace_floats(n16), dtype=torch.float32, device=dy.device)
-        epi = _lib.BnBwdSums(_lib.ptr(xb), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(msc), _lib.ptr(msh), _lib.ptr(res_mask_bits))
+        epi = _lib.BnBwdSums(_lib.ptr(xb), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(msc), _lib.ptr(msh), _lib.ptr(res_mask_bits),
+                             _lib.ptr(up_bits))
         parts = _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, H, W, 1, 0, 0, 1,
                          kh, kw, pad, -dil, pad, -dil, 0, kw, 1, res, res_mask, bn_partial=rec, bn_bwd=epi)
         return dx, ((rec, parts) if parts > 0 else None)

@@ -223,6 +223,10 @@ typedef struct dam_bn_bwd_sums {
      * relu(bn1(conv1(x))), models/model_resnet.py:97 -- if the shortcut's mask is also available as the sign bytes
      * dam_bn_apply_f32 wrote (one byte per channel quad); res_mask stays the fallback of launches that cannot. */
     const uint8_t* res_mask_bits;
+    /* mask_bits (instead of mask_scale / mask_shift): the BatchNorm's ReLU mask as sign bytes -- the upstream layer is
+     * relu(bn(x) + shortcut), a residual block's bn2 (models/model_resnet.py:26-27), whose mask is that of the block output.
+     * Only together with res / res_mask_bits. */
+    const uint8_t* mask_bits;
 } dam_bn_bwd_sums;
 
 /* Training-mode statistics of x: save_mean, save_invstd = 1/sqrt(biased var + eps), the fused affine

@@ -455,3 +455,15 @@ def test_dgrad_identity_shortcut_with_upstream_sums(ops, B, C, H, W):
         assert (sums[:, col] - ref).abs().max().item() <= 2e-5 * n ** 0.5 * dz.abs().max().item() + 1e-3
     with pytest.raises(ValueError):
         ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1, res=r, res_mask=m, bn_bwd=(x, mean, invstd, msc, msh))
+    # the upstream mask as sign bytes (the upstream layer is a residual block's relu(bn2(c2) + shortcut))
+    um = torch.randn(B, H, W, C, generator=g).cuda()
+    ubits = ((um > 0).view(B, H, W, C // 4, 4).to(torch.int32) * torch.tensor([1, 2, 4, 8], device='cuda', dtype=torch.int32)
+             ).sum(-1).to(torch.uint8).contiguous()
+    dx3, partials3 = ops.conv2d_dgrad(dy, wpt, C, H, W, 3, 3, 1, 1, 1, res=r, res_mask=m, res_mask_bits=bits,
+                                      bn_bwd=(x, mean, invstd, None, None, ubits))
+    assert torch.equal(dx3, plain) and partials3 is not None
+    rec, parts = partials3
+    sums = rec[:parts * C * 2].view(parts, C, 2).double().sum(0).cpu()
+    dz = dx3.double() * (um > 0)
+    for col, ref in ((0, dz.sum((0, 1, 2)).cpu()), (1, (dz * xhat).sum((0, 1, 2)).cpu())):
+        assert (sums[:, col] - ref).abs().max().item() <= 2e-5 * n ** 0.5 * dz.abs().max().item() + 1e-3
