@@ -573,6 +573,30 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
                                      (fin.counter || (bwd.x && res)) ? nullptr : bn_partial, &parts, (bwd.x && res) ? BnBwdEpi{} : bwd, st);
         if (rc == DAM_OK && bn_partial && bn_parts_host) *bn_parts_host = parts;
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
+        // Too wide for its patch buffers (the strided 16 -> 32 convolution on 1025x130: 131 input columns x 5 rows): the same
+        // kernel on 2-4 column ranges of the output, one launch each -- a range is just another output sub-grid of this entry
+        // point's geometry (width, output column offset, input column offset).  Not with an epilogue that leaves records.
+        if (nA == 3 && nB == 3 && !in_nchw && !bn_partial && !getenv("DAM_PIPE_NO_COLSPLIT")) {
+            for (int ns = 2; ns <= 4; ++ns) {
+                const int wd0 = (int)cdiv(Wo, ns);
+                if (wd0 < 16) break;
+                int rc2 = DAM_OK, done = 0;
+                for (int ow0 = 0; ow0 < Wo && rc2 == DAM_OK; ow0 += wd0, ++done) {
+                    ConvGeo g2 = g;
+                    g2.Wo = Wo - ow0 < wd0 ? Wo - ow0 : wd0;
+                    g2.oo_w = out_off_w + ow0 * out_stride;
+                    g2.off_w = off_w + ow0 * in_stride;
+                    g2.c0 = w_lo + ow0 * in_stride;
+                    g2.PWin = (g2.Wo - 1) * in_stride + (w_hi - w_lo) + 1;
+                    g2.PWs = (int)cdiv(g2.PWin, in_stride);
+                    g2.PWT = g2.PWs * in_stride;
+                    rc2 = conv_pipe_try(g2, h_hi - h_lo, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, nullptr,
+                                        nullptr, BnBwdEpi{}, st);
+                }
+                if (rc2 == DAM_OK) return DAM_OK;
+                if (rc2 != DAM_ERR_UNSUPPORTED || done > 1) return rc2 == DAM_ERR_UNSUPPORTED ? DAM_ERR_LAUNCH : rc2;   // a later range cannot fail where the first fitted
+            }
+        }
     }
     // tile choice.  With a workspace: keep big tiles (weights are streamed per workgroup: FLOPs per weight byte grow with
     // the tile) and get the workgroup count from split-K over channel groups; otherwise shrink tiles to fill the chip.

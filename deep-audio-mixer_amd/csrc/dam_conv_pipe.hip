@@ -533,7 +533,7 @@ int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, cons
                   float* Y, const float* res, const float* res_mask, float* workspace, float* stats, int* stats_parts,
                   const BnBwdEpi& bwd, hipStream_t st) {
     if (bwd.x && (res || !stats)) return DAM_ERR_BAD_ARG;
-    if (g.nA != 3 || g.nB != 3 || g.in_nchw || g.nchunks < 2) return DAM_ERR_UNSUPPORTED;
+    if (g.nA != 3 || g.nB != 3 || g.in_nchw) return DAM_ERR_UNSUPPORTED;     // (16-channel stride-1 layers never get here: row-ring kernel)
     if ((size_t)g.H * g.W * g.C * 4 >= ((size_t)1 << 30)) return DAM_ERR_UNSUPPORTED;      // offsets of the range-checked loads
     const int64_t npix = (int64_t)g.Ho * g.Wo;
     const int nblk = g.N / 16;

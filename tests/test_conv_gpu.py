@@ -43,6 +43,8 @@ CASES = [  # B, Cin, Cout, H, W, k, stride, pad, dil, bias
     (2, 16, 32, 45, 31, 5, 1, 0, 1, True),
     (1, 16, 16, 40, 216, 3, 1, 1, 1, False),     # the reference's native 216-frame rows: wide-row strip loader
     (1, 32, 32, 30, 108, 3, 1, 1, 1, False),
+    (2, 16, 32, 21, 130, 3, 2, 1, 1, True),      # too wide for the loader-wave kernel's patch buffers: two column ranges
+    (1, 16, 32, 9, 216, 3, 2, 1, 1, False),      # three
 ]
 
 
