@@ -60,11 +60,43 @@ def free_port():
     return p
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT touching a GPU runtime (the parent of an N-rank run must not initialise the
+    device before it starts its children): the KFD topology nodes that have SIMDs (CPUs have none) and whose DRM render
+    node is accessible to this user / container, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    when one of them is set.  Returns None when /sys/class/kfd is not readable (not a ROCm host)."""
+    import glob
+    nodes = []
+    for path in sorted(glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'),
+                       key=lambda q: int(q.split('/')[-2]) if q.split('/')[-2].isdigit() else 0):
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get('simd_count', '0')) <= 0:
+            continue
+        minor = int(props.get('drm_render_minor', '-1'))
+        dev = '/dev/dri/renderD%d' % minor
+        if minor >= 0 and os.path.exists(dev) and os.access(dev, os.R_OK | os.W_OK):
+            nodes.append(minor)
+    if not nodes and not os.path.isdir('/sys/class/kfd/kfd/topology/nodes'):
+        return None
+    n = len(nodes)
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [t for t in v.split(',') if t.strip() != '']
+            n = min(n, len(ids))
+    return n
+
+
 def spawn_ranks(args, argv):
-    """Parent of an N-rank run: no GPU call has been made in this process (torch.cuda.device_count() does not
-    initialise the device on this image)."""
-    import torch
-    n_dev = torch.cuda.device_count()
+    """Parent of an N-rank run: no GPU runtime call is made in this process -- the GPUs are counted from sysfs."""
+    n_dev = visible_gpu_count()
+    if n_dev is None:
+        sys.stderr.write('bench.py: --gpus %d but /sys/class/kfd is not readable here (no ROCm GPU): refusing to run fewer '
+                         'ranks\n' % args.gpus)
+        return 2
     rehearsal = os.environ.get('DAM_DIST_BACKEND', 'nccl') != 'nccl'       # gloo rehearsal: ranks may share a GPU
     if n_dev < args.gpus and not rehearsal:
         sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) visible; refusing to run fewer ranks\n' % (args.gpus, n_dev))
@@ -136,18 +168,27 @@ def roofline_resnet_layer1(device, batch, t_frames):
     # 3 forward with BatchNorm statistics, 2 forward with statistics and the fused input affine, 2 plain data gradients,
     # 2 data gradients with the residual / mask epilogue -- what a kernel trace of the step averages
     sc, sh = torch.rand(c, device=device) + 0.5, torch.randn(c, device=device)
+    mean, invstd = torch.randn(c, device=device), torch.rand(c, device=device) + 0.5
     buf = ops.bn_partial_buffer(device, c)
     msk = torch.randn((B, H, W, c), device=device)
+    bits = torch.randint(0, 16, (B, H, W, c // 4), device=device, dtype=torch.uint8)
+    x2 = torch.randn((B, H, W, c), device=device)
 
+    # exactly the nine launches of this kernel in a captured C3 step (profiles/r0N_C3_kernel_trace_summary.txt):
+    #   EPI 0 x 5: three forwards with the BatchNorm statistics epilogue + two that also apply the producer's affine+ReLU on load
+    #   EPI 1 x 2: conv2's data gradient with bn1's backward sums in the epilogue
+    #   EPI 2 x 1: layer1.0's conv1 data gradient: residual + sign-byte mask + the stem BatchNorm's sums (mask from its affine)
+    #   EPI 3 x 1: layer1.1's conv1 data gradient: residual + sign-byte mask + layer1.0.bn2's sums (mask from sign bytes)
     def step_mix():
         for _ in range(3):
             ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1, bn_partial=buf)
         for _ in range(2):
             ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1, bn_partial=buf, in_scale=sc, in_shift=sh, relu_in=True)
         for _ in range(2):
-            ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1)
-        for _ in range(2):
-            ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1, res=x, res_mask=msk)
+            ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1, bn_bwd=(x, mean, invstd, sc, sh))
+        ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1, res=x2, res_mask=msk, res_mask_bits=bits, bn_bwd=(x, mean, invstd, sc, sh))
+        ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1, res=x2, res_mask=msk, res_mask_bits=bits,
+                         bn_bwd=(x, mean, invstd, None, None, bits))
     out['step_mix_s'] = time_kernel(step_mix) / 9.0
     return out
 
@@ -174,7 +215,8 @@ def roofline_object(name, cfg, device, t_frames):
         t = k['step_mix_s'] if train else k['fwd_s']
         tf = k['flops_per_launch'] / t / 1e12
         kern = ('conv_strip_kernel<4,1,1,true> (ResNet layer1 3x3 conv 16->16, %dx1025x%d px: ' % (cfg['batch'], t_frames) +
-                ('5 forward + 4 dgrad launches per step)' if train else 'forward launches of the eval-mode chunk batch)'))
+                ('its 9 launches per step: 5 forward with statistics, 4 data gradients with the BatchNorm-backward / residual / '
+                 'upstream-sum epilogues)' if train else 'forward launches of the eval-mode chunk batch)'))
         # traffic: measured in a SEPARATE rocprofv3 --pmc run (bench.py cannot read PMC counters of its own launches);
         # the figure below was taken at batch 8 on the forward launch of this kernel at the commit named in traffic_source
         obj = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_MFMA / 1e12, 'unit': 'TFLOP/s', 'frac': tf * 1e12 / PEAK_F32_MFMA,
@@ -285,15 +327,26 @@ def cpu_baseline(cfg):
     legs = {'front_end_single_process_s': fe, 'model_train_step_s': mo, 'end_to_end_s': e2e,
             'front_end_single_process_frames_per_s': frames / fe, 'model_train_step_frames_per_s': frames / mo}
     try:        # the reference's arrangement: 6 DataLoader workers computing features (training.ipynb cell 6)
-        loader = torch.utils.data.DataLoader(_CpuClipFeatures([clips[b % B] for b in range(4 * B)], hop), batch_size=B,
-                                             num_workers=6, shuffle=False)
+        # steady state only: prefetch_factor 2 x 6 workers = 12 batches may be finished before the clock starts, so the first
+        # 12 batches are skipped and the NEXT 48 are timed (at most ~3 batches' worth of work was under way at t0: <= 6 %)
+        n_skip, n_timed = 12, 48
+        torch.set_num_threads(1)                    # worker processes inherit it: six single-threaded workers, as torch sets up
+        loader = torch.utils.data.DataLoader(_CpuClipFeatures([clips[b % B] for b in range((n_skip + n_timed) * B)], hop),
+                                             batch_size=B, num_workers=6, shuffle=False)
         it = iter(loader)
-        next(it)
+        for _ in range(n_skip):
+            next(it)
         t0 = time.perf_counter()
         k = sum(1 for _ in it)
         fe6 = (time.perf_counter() - t0) / max(k, 1)
+        torch.set_num_threads(cores)
         legs['front_end_6_workers_s'] = fe6
         legs['front_end_6_workers_frames_per_s'] = frames / fe6
+        legs['front_end_6_workers_batches_timed'] = k
+        # sanity: six workers cannot beat six times one process (numpy's FFT is single-threaded)
+        legs['front_end_6_workers_speedup_vs_single'] = fe / fe6
+        if fe / fe6 > 6.5:
+            legs['front_end_6_workers_warning'] = 'speed-up above 6x: prefetched batches leaked into the timed span'
     except Exception as e:      # worker processes unavailable on this host: the leg is reported as missing, not invented
         legs['front_end_6_workers_error'] = repr(e)[:200]
     return {'value': frames / e2e, 'unit': 'stem-spectrogram-frames/s', 'cores': cores, 'cores_visible': visible,
@@ -373,11 +426,30 @@ def run_train(name, cfg, args):
             dt = tt.item()
         return dt
 
+    def local_time(fn, k, first):
+        """This rank's own clock around k steps (no barrier inside): per-rank spread of the N-rank line."""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(k, first)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     run(args.warmup, 0)
+    step.measure_exposed = world > 1
     dt = timed(run, args.steps, args.warmup)
+    exposed = step.exposed_wait_ms()
+    step.measure_exposed = False
     loss = step.loss.item()
     frames_per_step = step.frames_per_step * world
     value = frames_per_step * args.steps / dt
+    # the same region repeated (diagnostic: run-to-run spread of a 0.1 s region; `value` stays the region above)
+    reps = [1e3 * timed(run, args.steps, args.warmup + (r + 1) * args.steps) / args.steps for r in range(args.repeat)]
+    rank_ms = 1e3 * local_time(run, args.steps, 0) / args.steps
+    if world > 1:
+        allr = [None] * world
+        torch.distributed.all_gather_object(allr, (rank_ms, exposed))
+    else:
+        allr = [(rank_ms, exposed)]
     gflop_step = cfg['gflop_fwd'] * 2.98 * B            # fwd+bwd algorithmic FLOPs per rank and step (SURVEY 8d ratio)
 
     result = {
@@ -388,8 +460,21 @@ def run_train(name, cfg, args):
                    'hip_graph': not args.no_graph, 'final_loss': loss, 'world_size': world, 'device_index': dev_index,
                    'dist_backend': (backend if world > 1 else None),
                    'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == 'nccl' else None,
-                   'grad_buckets': opt.n_buckets, 'allreduce_overlap': bool(step.staged)},
+                   'grad_buckets': opt.n_buckets, 'allreduce_overlap': bool(step.staged),
+                   # the reference loop reads loss.item() every batch (model_trainer.py:41,43); the timed region here does not
+                   # (throughput metric): the host only enqueues graph replays.  `--via-trainer` times the loop WITH the sync.
+                   'sync_per_step': False},
     }
+    if reps:
+        srt = sorted(reps)
+        result['repeat'] = {'regions': len(reps), 'steps_per_region': args.steps, 'ms_per_step_median': srt[len(srt) // 2],
+                            'ms_per_step_min': srt[0], 'ms_per_step_max': srt[-1]}
+    if world > 1:
+        result['per_rank'] = {'ms_per_step_min': min(a[0] for a in allr), 'ms_per_step_max': max(a[0] for a in allr),
+                              'ms_per_step': [a[0] for a in allr],
+                              # device time between the end of backward (graph A2) and both buckets having arrived: the part of
+                              # the all-reduce that did NOT hide behind backward, per step
+                              'exposed_allreduce_wait_ms': [a[1] for a in allr]}
     if args.breakdown and world > 1:
         result['breakdown'] = ddp_breakdown(step, device)
     # the same steps fed from page-locked HOST memory (512 clips in pinned host memory): batch k+1 is uploaded on
@@ -422,6 +507,150 @@ def run_train(name, cfg, args):
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def _setup_single(device_index=0):
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    torch.cuda.set_device(device_index)
+    import deep_audio_mixer_amd  # noqa: F401
+    from deep_audio_mixer_amd import build
+    build.build_lib()
+    return torch.device('cuda', device_index)
+
+
+def _synthetic_songs(cfg, n_songs, chunks_per_song, seed=1234):
+    """In-memory songs of SURVEY 8(d)'s synthetic clips: {song: {track: float32 [n, 2]}}, S stems + 'mix'."""
+    import numpy as np
+    S, n = cfg['n_stems'], cfg['sr'] * cfg['seconds']
+    rng = np.random.default_rng(seed)
+    g = np.linspace(0.5, 1.5, S, dtype=np.float32)
+    tracklist = ['stem%d' % i for i in range(S)] + ['mix']
+    songs = {}
+    for j in range(n_songs):
+        stems = [(0.1 * rng.standard_normal((chunks_per_song * n, CHANNELS))).astype(np.float32) for _ in range(S)]
+        songs['song%02d' % j] = dict(zip(tracklist, stems + [sum(gi * st for gi, st in zip(g, stems))]))
+    return songs, tracklist
+
+
+def run_via_trainer(name, cfg, args):
+    """The reference API at the measured speed: ModelTrainer.fit over MultitrackAudioDataset.batch_loader
+    (in-memory songs -> decode threads -> page-locked staging -> H2D -> one front-end launch per batch), the loop body
+    captured by ModelTrainer after its first batches, WITH the reference's per-batch loss.item() and progress prints."""
+    import contextlib
+    import io
+    import tempfile
+    import torch
+    device = _setup_single()
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    from deep_audio_mixer_amd.model_trainer import ModelTrainer
+    from deep_audio_mixer_amd.optim import Adam
+    S, B = cfg['n_stems'], cfg['batch']
+    n_songs, chunks = 6, 16                                      # 96 clips = 12 batches of 8 per epoch (0.9 GB of float32 PCM)
+    songs, tracklist = _synthetic_songs(cfg, n_songs, chunks)
+    ds = MultitrackAudioDataset.from_arrays(songs, chunk_length=cfg['seconds'], sr=cfg['sr'], tracklist=tracklist, seed=1)
+    train = ds.batch_loader(B, drop_last=True, workers=args.workers)
+    val = ds.batch_loader(B, indices=list(range(B)), workers=args.workers)
+    model = build_model(cfg, device)
+    opt = Adam(model.parameters(), weight_decay=1e-5)
+    trainer = ModelTrainer(model, torch.nn.MSELoss(), opt, device, model_name='bench')
+    epoch_s = []
+    inner = trainer._train_epoch
+
+    def timed_epoch(loader):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = inner(loader)
+        torch.cuda.synchronize()
+        epoch_s.append(time.perf_counter() - t0)
+        return out
+    trainer._train_epoch = timed_epoch
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        os.mkdir('weights')
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                trainer.fit(train, val, 0, 1)                    # epoch 0: two eager batches, the capture, replays
+                n_epochs = max(1, args.steps // len(train))
+                t0 = time.perf_counter()
+                tl, vl = trainer.fit(train, val, 1, n_epochs)
+                torch.cuda.synchronize()
+                fit_s = time.perf_counter() - t0
+        finally:
+            os.chdir(cwd)
+    steps = n_epochs * len(train)
+    train_s = sum(epoch_s[1:])
+    t_frames = 1 + cfg['sr'] * cfg['seconds'] // cfg['hop']
+    frames = B * S * t_frames
+    print(json.dumps({
+        'metric': 'stem-spectrogram-frames/sec (train, via ModelTrainer.fit)', 'value': frames * steps / train_s,
+        'unit': 'stem-spectrogram-frames/s', 'n_gpus': 1, 'steps': steps, 'ms_per_step': 1e3 * train_s / steps,
+        'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic', 'diagnostic': True,
+        'config': {'workload': cfg['workload'] + ' -- through ModelTrainer.fit(Dataset.batch_loader(8)) from in-memory songs',
+                   'sync_per_step': True, 'decode_threads': args.workers, 'graph_steps': trainer.graph_steps,
+                   'eager_steps': trainer.eager_steps, 'epochs_timed': n_epochs, 'batches_per_epoch': len(train),
+                   'ms_per_step_incl_validation_and_checkpoint': 1e3 * fit_s / steps, 'final_train_loss': tl[-1]}}), flush=True)
+
+
+def run_ingest(name, cfg, args):
+    """Ingest rate: 16-bit stereo WAV files on tmpfs -> iter_batches (decode threads read the file's own
+    int16 samples straight into page-locked staging -> H2D on a copy stream -> ONE front-end launch per batch) at the
+    config's clip shape, against what the training step consumes.  Also the float32-staging variant (host conversion, twice
+    the PCIe bytes) for comparison."""
+    import shutil
+    import tempfile
+    import wave
+    import numpy as np
+    import torch
+    device = _setup_single()
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    S, B, sr = cfg['n_stems'], cfg['batch'], cfg['sr']
+    n = sr * cfg['seconds']
+    n_songs, chunks = 4, 24                                      # 96 clips = 12 batches of 8
+    root = tempfile.mkdtemp(dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    tracklist = ['bass', 'drums', 'vocals', 'other', 'gtr', 'keys', 'perc', 'fx'][:S] + ['mix']
+    rng = np.random.default_rng(3)
+    try:
+        for j in range(n_songs):
+            name_j = 'Song%d' % j
+            d = os.path.join(root, name_j, name_j + '_STEMS_JOINED')
+            os.makedirs(d)
+            for t in tracklist:
+                path = (os.path.join(root, name_j, name_j + '_MIX.wav') if t == 'mix'
+                        else os.path.join(d, '%s_STEM_%s.wav' % (name_j, t.upper())))
+                with wave.open(path, 'wb') as w:
+                    w.setnchannels(CHANNELS), w.setsampwidth(2), w.setframerate(sr)
+                    w.writeframes(rng.integers(-3000, 3000, (chunks * n, CHANNELS), dtype=np.int16).tobytes())
+        t_frames = 1 + n // cfg['hop']
+        frames = B * S * t_frames
+        out = {}
+        for label, force_f32 in (('int16_staging', False), ('float32_staging', True)):
+            ds = MultitrackAudioDataset(root, chunk_length=cfg['seconds'], sr=sr, tracklist=tracklist, seed=1)
+            if force_f32:
+                ds.staging_format = lambda: (np.dtype(np.float32), CHANNELS)
+            for _ in ds.iter_batches(B, workers=args.workers, drop_last=True):        # warm pass: page cache, tables, pinned
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = 0
+            for _ in range(max(1, args.steps // 12)):
+                for x, gt in ds.iter_batches(B, workers=args.workers, drop_last=True):
+                    k += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            bytes_h2d = B * (S + 1) * n * CHANNELS * (4 if force_f32 else 2)
+            out[label] = {'frames_per_s': frames * k / dt, 'ms_per_batch': 1e3 * dt / k, 'batches': k,
+                          'h2d_bytes_per_batch': bytes_h2d, 'h2d_GBps': bytes_h2d * k / dt / 1e9}
+        print(json.dumps({
+            'metric': 'stem-spectrogram-frames/sec (ingest: WAV -> features)', 'value': out['int16_staging']['frames_per_s'],
+            'unit': 'stem-spectrogram-frames/s', 'n_gpus': 1, 'higher_is_better': True, 'data': 'synthetic 16-bit stereo WAV on tmpfs',
+            'diagnostic': True,
+            'config': {'workload': 'iter_batches(%d) at the clip shape of %s' % (B, name), 'decode_threads': args.workers,
+                       'host_cores': host_cores()[0], **out}}), flush=True)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def ddp_breakdown(step, device, iters=10):
@@ -515,6 +744,12 @@ def main():
     ap.add_argument('--no-host-stream', action='store_true')
     ap.add_argument('--host-clips', type=int, default=N_HOST_CLIPS)
     ap.add_argument('--breakdown', action='store_true', help='N > 1: add per-phase timings of the step (diagnostic)')
+    ap.add_argument('--repeat', type=int, default=5, help='extra timed regions of --steps steps: median / min / max in the line')
+    ap.add_argument('--via-trainer', action='store_true',
+                    help='diagnostic line (never the headline): ms per step of ModelTrainer.fit fed by Dataset.batch_loader')
+    ap.add_argument('--ingest', action='store_true',
+                    help='diagnostic line: frames/s of WAV files -> decode threads -> pinned -> H2D -> STFT (iter_batches)')
+    ap.add_argument('--workers', type=int, default=8, help='--ingest / --via-trainer: decode threads')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
@@ -525,6 +760,11 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     cfg = CONFIGS[args.config]
+    if args.via_trainer or args.ingest:
+        if world != 1 or args.config == 'C5':
+            raise SystemExit('--via-trainer / --ingest: one GPU, a training config')
+        (run_via_trainer if args.via_trainer else run_ingest)(args.config, cfg, args)
+        return
     if args.config == 'C5':
         if world != 1:
             raise SystemExit('C5 (one song) runs on one GPU; songs shard over ranks as independent replicas')

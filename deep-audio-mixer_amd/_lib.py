@@ -8,6 +8,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DAM_LIB_PATH') or os.path.join(_HERE, 'libdam_hip.so')   # override: diagnostic builds only
 
+# include/dam_hip.h: bumped whenever a C signature changes (together with dam_abi_version() in csrc/dam_api.hip and
+# DAM_ABI_VERSION in the header).  libdam_hip.so is git-ignored and travels prebuilt: a stale one would read device pointers
+# as streams, so lib() refuses it instead of launching.
+EXPECTED_ABI = 7
+
 _STATUS = {0: 'DAM_OK', -1: 'DAM_ERR_BAD_ARG', -2: 'DAM_ERR_UNSUPPORTED', -3: 'DAM_ERR_LAUNCH',
            -4: 'DAM_ERR_WORKSPACE'}
 
@@ -95,6 +100,11 @@ def lib():
             raise RuntimeError('libdam_hip.so is not built (%s): run `python __graft_entry__.py` or '
                                '`python deep-audio-mixer_amd/build.py`; there is no CPU fallback' % LIB_PATH)
         l = ctypes.CDLL(LIB_PATH)
+        l.dam_abi_version.restype, l.dam_abi_version.argtypes = c_i, []
+        have = l.dam_abi_version()
+        if have != EXPECTED_ABI:
+            raise RuntimeError('%s speaks ABI version %d, this package expects %d: the library is stale -- rebuild it '
+                               '(`python deep-audio-mixer_amd/build.py --force`)' % (LIB_PATH, have, EXPECTED_ABI))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args

@@ -2,4 +2,4 @@
 #include "dam_common.h"
 
 extern "C" const char* dam_arch(void) { return "gfx950"; }
-extern "C" int dam_abi_version(void) { return 6; }
+extern "C" int dam_abi_version(void) { return DAM_ABI_VERSION; }

@@ -49,25 +49,42 @@ __device__ __forceinline__ constexpr int fft16_pos(int k) { return 4 * (k & 3) +
 
 // Channel layouts: interleaved (PLANAR = false: sample p of channel c at trk[CH*p + c], what soundfile / a WAV decoder
 // hands over) and planar (PLANAR = true: trk[c*cs + p], the [channels, n] arrays inference_utils.py works on).
+// Integer PCM (DAM_PCM_S16 / DAM_PCM_S32: the samples as the WAV file holds them, data/dataset.py:192-196 reads them through
+// soundfile, which divides by 2^(bits-1)): every sample is converted to float exactly as that division rounds it, the
+// power-of-two scale 2^-(bits-1) rides on the window * gain product (exact), so the result is bit for bit what the float32
+// kernel computes from host-converted samples -- without the host conversion and with half the bytes over PCIe for 16 bit.
+template <typename PCM> struct pcm_traits { static constexpr bool integer = false; static constexpr float scale = 1.0f; };
+template <> struct pcm_traits<int16_t> { static constexpr bool integer = true; static constexpr float scale = 1.0f / 32768.0f; };
+template <> struct pcm_traits<int32_t> { static constexpr bool integer = true; static constexpr float scale = 1.0f / 2147483648.0f; };
+
+template <typename PCM>
+__device__ __forceinline__ float mean2(PCM a, PCM b) {
+    if constexpr (pcm_traits<PCM>::integer) return ((float)a + (float)b) * 0.5f;
+    else return (float)((a + b) * (PCM)0.5);
+}
+
 template <typename PCM, int CH, bool PLANAR>
 __device__ __forceinline__ float mono_at(const PCM* __restrict__ trk, int64_t cs, int64_t p) {
     if (CH == 1) return (float)trk[p];
-    if (PLANAR) return (float)((trk[p] + trk[cs + p]) * (PCM)0.5);
-    return (float)((trk[2 * p] + trk[2 * p + 1]) * (PCM)0.5);
+    if (PLANAR) return mean2<PCM>(trk[p], trk[cs + p]);
+    return mean2<PCM>(trk[2 * p], trk[2 * p + 1]);
 }
 
 typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 // Loads complex point (x[p], x[p+1]) of the reflect-padded mono signal; interior = no mirroring.
 template <typename PCM, int CH, bool PLANAR>
 __device__ __forceinline__ float2 load_pair_interior(const PCM* __restrict__ trk, int64_t cs, int64_t p) {
-    if constexpr (CH == 2 && sizeof(PCM) == 4 && !PLANAR) {
+    constexpr bool F32 = sizeof(PCM) == 4 && !pcm_traits<PCM>::integer;
+    if constexpr (CH == 2 && F32 && !PLANAR) {
         f32x4_u q = *reinterpret_cast<const f32x4_u*>(trk + 2 * p);
         return make_float2((q.x + q.y) * 0.5f, (q.z + q.w) * 0.5f);
-    } else if constexpr (CH == 2 && sizeof(PCM) == 4 && PLANAR) {
+    } else if constexpr (CH == 2 && F32 && PLANAR) {
         f32x2_u a = *reinterpret_cast<const f32x2_u*>(trk + p), b = *reinterpret_cast<const f32x2_u*>(trk + cs + p);
         return make_float2((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f);
-    } else if constexpr (CH == 1 && sizeof(PCM) == 4) {
+    } else if constexpr (CH == 1 && F32) {
         f32x2_u q = *reinterpret_cast<const f32x2_u*>(trk + p);
         return make_float2(q.x, q.y);
     } else {
@@ -131,14 +148,15 @@ __global__ __launch_bounds__(TF2* WAVE, 4) void stft2048_kernel(
         const int t = t0 + wave;
         if (t < n_frames) {             // wave-uniform
             const PCM* trk = pcm + (track / n_inner) * outer_stride + (track % n_inner) * inner_stride;
-            const float g = gain ? gain[track] : 1.0f;
+            const float g = (gain ? gain[track] : 1.0f) * pcm_traits<PCM>::scale;     // power-of-two scale: exact
             const int64_t p0 = (int64_t)t * hop - NFFT / 2;
             float2 v[16];
             const bool interior = p0 >= 0 && p0 + NFFT <= n_samples;
             // window (and, for interleaved float32 PCM, the samples) through buffer loads: scalar base + ONE lane offset
             // register + immediates, instead of sixteen 64-bit address pairs each (the register file is what limits occupancy)
             const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(window), 0, NFFT * 4, 0x00020000);
-            constexpr bool BUF = sizeof(PCM) == 4 && !PLANAR;
+            constexpr bool BUF = sizeof(PCM) <= 4 && !PLANAR;           // float32 / int32 / int16, interleaved or mono
+            constexpr int PB = (int)sizeof(PCM) * 2 * CH;               // bytes of one complex point (two frames)
             // two halves of eight points: samples and window of a half are requested together, the compiler must not hoist the
             // second half's loads over the first half's arithmetic (it would spill)
 #pragma unroll
@@ -146,15 +164,34 @@ __global__ __launch_bounds__(TF2* WAVE, 4) void stft2048_kernel(
                 if (interior) {
                     if constexpr (BUF) {
                         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-                            const_cast<PCM*>(trk + (int64_t)CH * p0), 0, NFFT * CH * 4, 0x00020000);
+                            const_cast<PCM*>(trk + (int64_t)CH * p0), 0, NFFT * CH * (int)sizeof(PCM), 0x00020000);
 #pragma unroll
                         for (int n1 = 8 * half; n1 < 8 * half + 8; ++n1) {
-                            if constexpr (CH == 2) {
-                                const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, n1 * 1024, 0));
-                                v[n1] = make_float2((q.x + q.y) * 0.5f, (q.z + q.w) * 0.5f);
-                            } else {
-                                const f32x2 q = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prs, lane * 8, n1 * 512, 0));
-                                v[n1] = make_float2(q.x, q.y);
+                            if constexpr (PB == 16) {               // 4-byte samples, stereo: L0 R0 L1 R1
+                                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, n1 * 1024, 0);
+                                if constexpr (pcm_traits<PCM>::integer) {
+                                    const i32x4 q = __builtin_bit_cast(i32x4, raw);
+                                    v[n1] = make_float2(mean2<int32_t>(q.x, q.y), mean2<int32_t>(q.z, q.w));
+                                } else {
+                                    const f32x4 q = __builtin_bit_cast(f32x4, raw);
+                                    v[n1] = make_float2((q.x + q.y) * 0.5f, (q.z + q.w) * 0.5f);
+                                }
+                            } else if constexpr (PB == 8 && sizeof(PCM) == 4) {      // 4-byte samples, mono
+                                const auto raw = __builtin_amdgcn_raw_buffer_load_b64(prs, lane * 8, n1 * 512, 0);
+                                if constexpr (pcm_traits<PCM>::integer) {
+                                    const i32x2 q = __builtin_bit_cast(i32x2, raw);
+                                    v[n1] = make_float2((float)q.x, (float)q.y);
+                                } else {
+                                    const f32x2 q = __builtin_bit_cast(f32x2, raw);
+                                    v[n1] = make_float2(q.x, q.y);
+                                }
+                            } else if constexpr (PB == 8) {         // int16 stereo: one 8-byte load = L0 R0 L1 R1
+                                const i32x2 q = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(prs, lane * 8, n1 * 512, 0));
+                                v[n1] = make_float2(mean2<int32_t>((int)(short)(q.x & 0xffff), q.x >> 16),
+                                                    mean2<int32_t>((int)(short)(q.y & 0xffff), q.y >> 16));
+                            } else {                                // int16 mono: one 4-byte load = two samples
+                                const int q = __builtin_amdgcn_raw_buffer_load_b32(prs, lane * 4, n1 * 256, 0);
+                                v[n1] = make_float2((float)(int)(short)(q & 0xffff), (float)(q >> 16));
                             }
                         }
                     } else {
@@ -349,7 +386,7 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(
     const int64_t track = blockIdx.y;
     const int t = blockIdx.x;
     const PCM* trk = pcm + (track / n_inner) * outer_stride + (track % n_inner) * inner_stride;
-    const float g = gain ? gain[track] : 1.0f;
+    const float g = (gain ? gain[track] : 1.0f) * pcm_traits<PCM>::scale;
     const int64_t p0 = (int64_t)t * hop - M;
     for (int n = tid; n < M; n += 256) {
         const int64_t a = reflect(p0 + 2 * n, n_samples), b = reflect(p0 + 2 * n + 1, n_samples);
@@ -435,7 +472,8 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     if (!fast && (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))) return DAM_ERR_UNSUPPORTED;
     const int indirect = (pcm_dtype & DAM_PCM_INDIRECT) ? 1 : 0;
     pcm_dtype &= ~DAM_PCM_INDIRECT;
-    if (pcm_dtype != DAM_PCM_F32 && pcm_dtype != DAM_PCM_F64) return DAM_ERR_UNSUPPORTED;
+    if (pcm_dtype != DAM_PCM_F32 && pcm_dtype != DAM_PCM_F64 && pcm_dtype != DAM_PCM_S16 && pcm_dtype != DAM_PCM_S32)
+        return DAM_ERR_UNSUPPORTED;
     const int64_t n_tracks = n_outer * n_inner;
     if (n_tracks > 65535 || n_inner > 0x7fffffff) return DAM_ERR_UNSUPPORTED;
     bool planar;
@@ -449,6 +487,11 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     } else {
         return DAM_ERR_UNSUPPORTED;
     }
+    const bool integer = pcm_dtype == DAM_PCM_S16 || pcm_dtype == DAM_PCM_S32;
+    if (integer && planar) return DAM_ERR_UNSUPPORTED;     // integer PCM is what a WAV decoder hands over: interleaved
+    // the 2-byte kernels fetch a complex point (two frames) with one aligned 4- / 8-byte load
+    if (pcm_dtype == DAM_PCM_S16 && !indirect && ((uintptr_t)pcm & 3)) return DAM_ERR_BAD_ARG;
+    if (pcm_dtype == DAM_PCM_S16 && ((outer_stride | inner_stride) & 1) && channels == 1) return DAM_ERR_UNSUPPORTED;
     const int n_frames = (int)(1 + n_samples / hop);
     dim3 grid, block;
     hipStream_t s = (hipStream_t)stream;
@@ -466,6 +509,12 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
             if (channels == 1) DAM_STFT_GENERIC(float, 1, false);
             else if (planar) DAM_STFT_GENERIC(float, 2, true);
             else DAM_STFT_GENERIC(float, 2, false);
+        } else if (pcm_dtype == DAM_PCM_S16) {
+            if (channels == 1) DAM_STFT_GENERIC(int16_t, 1, false);
+            else DAM_STFT_GENERIC(int16_t, 2, false);
+        } else if (pcm_dtype == DAM_PCM_S32) {
+            if (channels == 1) DAM_STFT_GENERIC(int32_t, 1, false);
+            else DAM_STFT_GENERIC(int32_t, 2, false);
         } else {
             if (channels == 1) DAM_STFT_GENERIC(double, 1, false);
             else if (planar) DAM_STFT_GENERIC(double, 2, true);
@@ -489,6 +538,12 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
         if (channels == 1) DAM_STFT_LAUNCH(float, 1, false);
         else if (planar) DAM_STFT_LAUNCH(float, 2, true);
         else DAM_STFT_LAUNCH(float, 2, false);
+    } else if (pcm_dtype == DAM_PCM_S16) {
+        if (channels == 1) DAM_STFT_LAUNCH(int16_t, 1, false);
+        else DAM_STFT_LAUNCH(int16_t, 2, false);
+    } else if (pcm_dtype == DAM_PCM_S32) {
+        if (channels == 1) DAM_STFT_LAUNCH(int32_t, 1, false);
+        else DAM_STFT_LAUNCH(int32_t, 2, false);
     } else {
         if (channels == 1) DAM_STFT_LAUNCH(double, 1, false);
         else if (planar) DAM_STFT_LAUNCH(double, 2, true);

@@ -26,7 +26,7 @@ import torch
 from torch.utils import data
 
 from .. import features, staging
-from .dataset_utils import read_wav, wav_num_frames
+from .dataset_utils import native_dtype, read_wav, read_wav_native, wav_header, wav_num_frames
 
 
 class MultitrackAudioDataset(data.Dataset):
@@ -43,7 +43,11 @@ class MultitrackAudioDataset(data.Dataset):
         self._device = torch.device(device) if device is not None else torch.device('cuda')
         self._verbose = verbose
         self._arrays = _arrays
-        self._aug_seed = seed if seed else 0          # device-side augmentation draws are keyed by (seed, item, track)
+        # device-side augmentation draws are keyed by (seed, item, how often the item was read before, track): every access
+        # is a fresh draw, as the reference's np.random.uniform per access (data/dataset.py:164-168), and a run is
+        # reproducible given the seed; without a seed the base is random, like numpy's unseeded global state
+        self._aug_seed = seed if seed else int.from_bytes(os.urandom(8), 'little') >> 2
+        self._aug_reads, self._aug_epoch = {}, 0
         if _arrays is not None and not songlist:
             songlist = list(_arrays.keys())
         if not songlist:
@@ -54,6 +58,23 @@ class MultitrackAudioDataset(data.Dataset):
             random.seed(seed)
         random.shuffle(songlist)
         self._len, self.song_durations = self._calculate_dataset_length()
+
+    _AUG_READ_SHIFT = 40       # read counter folded into the item field of the draw's key (items < 2^40, reads < 4096)
+
+    def set_epoch(self, epoch: int):
+        """The next read of every item takes augmentation draw number `epoch` (resuming a run: set_epoch(k) before pass k
+        reproduces that pass's gains).  Without it the counter simply advances with every read of an item."""
+        self._aug_reads, self._aug_epoch = {}, int(epoch)
+
+    def _aug_keys(self, items):
+        """Global item indices -> the item keys of THIS access' draws (features.augment_gains(items=)); advances the
+        items' read counters."""
+        keys = []
+        for i in items:
+            k = self._aug_reads.get(i, self._aug_epoch)
+            self._aug_reads[i] = k + 1
+            keys.append(int(i) + ((k % 4096) << self._AUG_READ_SHIFT))
+        return keys
 
     @classmethod
     def from_arrays(cls, songs: dict, **kwargs):
@@ -118,9 +139,27 @@ class MultitrackAudioDataset(data.Dataset):
         return np.mean(audio, axis=1)
 
     def _read_chunk(self, song_name, track_name, lo, hi):
+        """One track's chunk as the front-end wants it: the file's own integer samples where the kernel reads them (16 / 24 /
+        32-bit PCM -> int16 / int32, dataset_utils.read_wav_native: no host conversion), in-memory arrays as they are."""
         if self._arrays is not None:
             return np.asarray(self._arrays[song_name][track_name][lo:hi])
-        return read_wav(self._get_track_path(song_name, track_name), lo, hi)[0]
+        return read_wav_native(self._get_track_path(song_name, track_name), lo, hi)[0]
+
+    @staticmethod
+    def _common_pcm(chunks):
+        """Tracks of one item stacked into ONE front-end input: their common dtype if they share one, else float64 in
+        [-1, 1) (what soundfile.read yields at data/dataset.py:194)."""
+        kinds = {c.dtype for c in chunks}
+        if len(kinds) == 1 and chunks[0].dtype in (np.int16, np.int32, np.float32, np.float64):
+            return np.stack(chunks)
+        out = []
+        for c in chunks:
+            if c.dtype == np.int16:
+                c = c.astype(np.float64) / 32768.0
+            elif c.dtype == np.int32:
+                c = c.astype(np.float64) / 2147483648.0
+            out.append(c.astype(np.float64))
+        return np.stack(out)
 
     def _process_on_the_fly(self, song_i: int, chunk_i: int, index: int = None) -> tuple:
         """data/dataset.py:185-210: all S+1 tracks of the chunk go through ONE front-end launch."""
@@ -128,22 +167,41 @@ class MultitrackAudioDataset(data.Dataset):
         lo, hi = chunk_i * self._chunk_length * self._sr, (chunk_i + 1) * self._chunk_length * self._sr
         chunks = [self._read_chunk(song_name, t, lo, hi) for t in self._tracklist]
         chunks = [c[:, None] if c.ndim == 1 else c for c in chunks]
-        pcm = torch.from_numpy(np.stack(chunks)).to(self._device)          # [S+1, n, channels]
+        pcm = torch.from_numpy(self._common_pcm(chunks)).to(self._device)          # [S+1, n, channels]
         gain = None
         if self._augment:        # one draw per track, the mix included (data/dataset.py:198-199): drawn on the device,
-            # reproducibly, keyed by (dataset seed, global item index, track) instead of numpy's global state
+            # reproducibly, keyed by (dataset seed, global item index, read count, track) instead of numpy's global state
             item = index if index is not None else sum(int(d / self._chunk_length) for d in self.song_durations[:song_i]) + chunk_i
-            gain = features.augment_gains(self._aug_seed, len(chunks), first_item=item, n_items=1, device=self._device)[0]
+            gain = features.augment_gains(self._aug_seed, len(chunks), items=self._aug_keys([item]), device=self._device)[0]
         feats = features.stft_logmag(pcm, 2048, 1024, gain=gain, normalize=self._normalize)
         return feats[:-1], feats[-1]
 
     # ---- batched ingest: decode threads -> page-locked staging -> copy stream -> one front-end launch per batch
+    def staging_format(self):
+        """(numpy dtype, channels) of the page-locked staging buffers of iter_batches: the files' own sample type when every
+        track of every song shares it (16-bit MedleyDB / MUSDB18-HQ stems travel as int16: half the PCIe bytes of float32
+        and no conversion on the host), else float32."""
+        if self._arrays is not None:
+            a = np.asarray(self._arrays[self.songlist[0]][self._tracklist[0]])
+            return np.dtype(np.float32), (1 if a.ndim == 1 else a.shape[1])
+        kinds, chans = set(), set()
+        for song in self.songlist:
+            for t in self._tracklist:
+                h = wav_header(self._get_track_path(song, t))
+                kinds.add(native_dtype(h))
+                chans.add(h['channels'])
+        if len(chans) != 1:
+            raise ValueError('iter_batches needs one channel count over all tracks (found %s)' % sorted(chans))
+        kind = kinds.pop() if len(kinds) == 1 else None
+        return (np.dtype(np.float32) if kind is None else kind), chans.pop()
+
     def iter_batches(self, batch_size, indices=None, workers=8, drop_last=False):
         """Yields (train_features [B,S,1025,T], gt_features [B,1025,T]) float32 CUDA tensors for consecutive groups of
         `batch_size` items of `indices` (default: every item, in order) -- what ``DataLoader(self, batch_size)`` yields,
-        with the reads of data/dataset.py:192-196 done by `workers` threads into page-locked memory, the upload of batch
-        k+1 overlapped with the consumer's work on batch k, and the augmentation gains (data/dataset.py:198-199) drawn
-        on the device per (seed, item, track)."""
+        with the reads of data/dataset.py:192-196 done by `workers` threads straight into page-locked memory (integer PCM
+        stays integer: staging_format), the decode of batch k+1 running in the background and its upload on a copy stream
+        while the consumer works on batch k (also while it waits in ``loss.item()``), and the augmentation gains
+        (data/dataset.py:198-199) drawn on the device per (seed, item, read count, track)."""
         from concurrent.futures import ThreadPoolExecutor
         idx = list(range(len(self))) if indices is None else [int(i) for i in indices]
         groups = [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]
@@ -152,52 +210,60 @@ class MultitrackAudioDataset(data.Dataset):
         if not groups:
             return
         K, n = len(self._tracklist), self._chunk_length * self._sr
-        first = self._read_chunk_f32(self.songlist[self._calculate_song_index(idx[0])[0]], self._tracklist[0], 0, 1)
-        ch = first.shape[1]
-        host = [torch.empty((batch_size, K, n, ch), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-        dev = [torch.empty((batch_size, K, n, ch), dtype=torch.float32, device=self._device) for _ in range(2)]
+        kind, ch = self.staging_format()
+        tdt = torch.from_numpy(np.empty(0, dtype=kind)).dtype
+        host = [torch.empty((batch_size, K, n, ch), dtype=tdt, pin_memory=True) for _ in range(2)]
+        dev = [torch.empty((batch_size, K, n, ch), dtype=tdt, device=self._device) for _ in range(2)]
         uploaded = [torch.cuda.Event(), torch.cuda.Event()]
         consumed = [torch.cuda.Event(), torch.cuda.Event()]
         copy_stream = torch.cuda.Stream(device=self._device)
 
-        def decode(slot, group):
+        def decode(pool, slot, group):
+            """Starts the reads of one batch into host[slot]; returns the futures."""
             view = host[slot].numpy()
 
             def one(job):
                 b, k, item = job
                 song_i, chunk_i = self._calculate_song_index(item)
-                a = self._read_chunk_f32(self.songlist[song_i], self._tracklist[k], chunk_i * n, (chunk_i + 1) * n)
-                view[b, k] = a
-            list(pool.map(one, [(b, k, item) for b, item in enumerate(group) for k in range(K)]))
+                self._read_chunk_into(view[b, k], self.songlist[song_i], self._tracklist[k], chunk_i * n, (chunk_i + 1) * n)
+            return [pool.submit(one, (b, k, item)) for b, item in enumerate(group) for k in range(K)]
 
         with ThreadPoolExecutor(max_workers=workers) as pool:
-            cur = torch.cuda.current_stream(self._device)
-            staging._wait(uploaded[0])
-            decode(0, groups[0])
+            pending = decode(pool, 0, groups[0])
             for j, group in enumerate(groups):
                 slot, B = j % 2, len(group)
+                for f in pending:
+                    f.result()                                         # this batch is in host[slot] (raises a reader's error)
                 with torch.cuda.stream(copy_stream):
                     copy_stream.wait_event(consumed[slot])            # the launch that read dev[slot] two batches ago
                     dev[slot][:B].copy_(host[slot][:B], non_blocking=True)
                     uploaded[slot].record(copy_stream)
-                if j + 1 < len(groups):                                # decode the next batch while this one travels
-                    staging._wait(uploaded[1 - slot])                  # its previous upload has left the host buffer
-                    decode(1 - slot, groups[j + 1])
+                if j + 1 < len(groups):                                # the next batch is decoded in the background while
+                    staging._wait(uploaded[1 - slot])                  # this one travels and is consumed (host[1-slot] is
+                    pending = decode(pool, 1 - slot, groups[j + 1])    # free once its previous upload has left it)
                 cur = torch.cuda.current_stream(self._device)
                 cur.wait_event(uploaded[slot])
                 gain = None
                 if self._augment:
-                    gain = features.augment_gains(self._aug_seed, K, items=group, device=self._device)
+                    gain = features.augment_gains(self._aug_seed, K, items=self._aug_keys(group), device=self._device)
                 x, gt = features.stft_logmag_clips(dev[slot][:B], 2048, 1024, gain=gain, normalize=self._normalize)
                 consumed[slot].record(cur)
                 yield x, gt
 
-    def _read_chunk_f32(self, song_name, track_name, lo, hi):
+    def batch_loader(self, batch_size, indices=None, workers=8, drop_last=False):
+        """iter_batches as a re-iterable loader with ``len()`` -- what ModelTrainer.fit / the notebooks' loops expect of a
+        DataLoader (one pass per ``for`` loop)."""
+        return _BatchLoader(self, batch_size, indices, workers, drop_last)
+
+    def _read_chunk_into(self, out, song_name, track_name, lo, hi):
+        """One track's chunk into a [n, channels] view of a staging buffer (dtype: staging_format)."""
         if self._arrays is not None:
-            a = np.asarray(self._arrays[song_name][track_name][lo:hi], dtype=np.float32)
+            a = np.asarray(self._arrays[song_name][track_name][lo:hi])
+            out[...] = a[:, None] if a.ndim == 1 else a
+        elif out.dtype == np.float32:
+            out[...] = read_wav(self._get_track_path(song_name, track_name), lo, hi, dtype=np.float32)[0]
         else:
-            a = read_wav(self._get_track_path(song_name, track_name), lo, hi, dtype=np.float32)[0]
-        return a[:, None] if a.ndim == 1 else a
+            read_wav_native(self._get_track_path(song_name, track_name), lo, hi, out=out)
 
     # ---- pre-computed feature cache (data/dataset.py:213-268).  The reference's writer emits
     #      {song}_FEATURES/{i}_train_{len}s[_norm].npy / {i}_gt_{len}s[_norm].npy while its reader looks for
@@ -274,3 +340,15 @@ class MultitrackAudioDataset(data.Dataset):
                     track = read_wav(self._get_track_path(song_name, track_name))[0]
                 loudness[track_name].append(meter.integrated_loudness(track))
         return {track_name: mean(loudness[track_name]) for track_name in loudness}
+
+
+class _BatchLoader:
+    def __init__(self, dataset, batch_size, indices, workers, drop_last):
+        self.dataset, self.batch_size, self.indices, self.workers, self.drop_last = dataset, batch_size, indices, workers, drop_last
+
+    def __len__(self):
+        n = len(self.dataset) if self.indices is None else len(self.indices)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        return self.dataset.iter_batches(self.batch_size, self.indices, self.workers, self.drop_last)

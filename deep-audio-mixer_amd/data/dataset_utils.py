@@ -120,6 +120,53 @@ def read_wav(path, start=0, stop=None, dtype=np.float64):
     return _decode(raw, h, np.dtype(dtype).type).reshape(-1, h['channels']), h['rate']
 
 
+def read_wav_native(path, start=0, stop=None, out=None):
+    """Partial read WITHOUT conversion, for the device front-end (features.stft_logmag on int16 / int32 tensors scales by
+    1/2^(bits-1) itself, exactly as soundfile does): 16-bit PCM -> int16 [frames, channels]; 32-bit PCM -> int32; 24-bit PCM
+    -> int32 left-justified (value << 8, so the same 1/2^31 scale applies); float32 files -> float32; anything else (8-bit,
+    float64) -> float32 through read_wav.  out: optional preallocated array of the right dtype and shape (e.g. a view of a
+    page-locked staging buffer) -- 16 / 32-bit samples are then read from the file straight into it.
+    Returns (array, sample rate)."""
+    h = wav_header(path)
+    n = h['frames']
+    stop = n if stop is None else min(stop, n)
+    start = min(max(start, 0), stop)
+    width, ch = (h['bits'] + 7) // 8, h['channels']
+    kind = native_dtype(h)
+    if kind is None:
+        a, rate = read_wav(path, start, stop, dtype=np.float32)
+        if out is not None:
+            out[...] = a
+            return out, rate
+        return a, rate
+    with open(path, 'rb') as fh:
+        fh.seek(h['data_offset'] + start * h['frame_bytes'])
+        if width != 3:
+            if out is not None and out.dtype == kind and out.shape == (stop - start, ch) and out.flags.c_contiguous:
+                got = fh.readinto(memoryview(out).cast('B'))
+                if got != out.nbytes:
+                    raise ValueError('%s: short read' % path)
+                return out, h['rate']
+            a = np.frombuffer(fh.read((stop - start) * h['frame_bytes']), dtype=kind).reshape(-1, ch)
+        else:
+            b = np.frombuffer(fh.read((stop - start) * h['frame_bytes']), dtype=np.uint8).reshape(-1, 3)
+            a = np.zeros((b.shape[0], 4), dtype=np.uint8)
+            a[:, 1:] = b                                       # little endian: byte 0 of the int32 stays zero = value << 8
+            a = a.view('<i4').reshape(-1, ch)
+    if out is not None:
+        out[...] = a
+        return out, h['rate']
+    return a, h['rate']
+
+
+def native_dtype(h):
+    """numpy dtype read_wav_native yields for a parsed header (None: converted to float32 on the host)."""
+    width = (h['bits'] + 7) // 8
+    if h['tag'] == _WAVE_FORMAT_IEEE_FLOAT:
+        return np.dtype('<f4') if width == 4 else None
+    return {2: np.dtype('<i2'), 3: np.dtype('<i4'), 4: np.dtype('<i4')}.get(width)
+
+
 def wav_num_frames(path):
     h = wav_header(path)
     return h['frames'], h['rate']

@@ -82,6 +82,10 @@ class GradBucket:
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
+        if any(hasattr(p, '_dam_grad') for p in self.params):
+            raise RuntimeError('these parameters have gradient slots bound (optim.Adam.bind_grad_slots / engine.TrainStep): '
+                               'their .grad stays None, a GradBucket over them would all-reduce zeros -- unbind first '
+                               '(TrainStep.close()) or use optim.Adam\'s own buckets')
         self.group = group
         n = sum(p.numel() for p in self.params)
         p0 = self.params[0]

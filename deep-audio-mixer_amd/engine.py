@@ -30,25 +30,38 @@ from . import distributed, features, ops
 
 
 class TrainStep:
-    def __init__(self, model, optimizer, n_stems, n_samples, channels=2, batch=8, n_fft=2048, hop=1024,
-                 use_graph=True, device=None, overlap=True):
+    def __init__(self, model, optimizer, n_stems, n_samples=None, channels=2, batch=8, n_fft=2048, hop=1024,
+                 use_graph=True, device=None, overlap=True, feature_shape=None, pcm_dtype=torch.float32):
+        """feature_shape=(F, T): the step starts from FEATURES instead of PCM (what a DataLoader over the reference's
+        Dataset yields, model_trainer.py:31-33): no front-end launch in the step, `load_features(x, gt)` fills the static
+        inputs.  pcm_dtype: float32, or int16 / int32 for integer PCM read by the front-end as decoded from the file
+        (DAM_PCM_S16 / DAM_PCM_S32, include/dam_hip.h)."""
         self.model, self.opt = model, optimizer
         self.device = device or next(model.parameters()).device
         self.n_fft, self.hop, self.batch, self.n_stems = n_fft, hop, batch, n_stems
-        f, t = n_fft // 2 + 1, features.num_frames(n_samples, hop)
         dev = self.device
-        # stems and mix of a batch live in ONE buffer ([B, S+1, n, ch], mix last): the front-end is one launch
-        self.pcm = torch.zeros((batch, n_stems + 1, n_samples, channels), dtype=torch.float32, device=dev)
-        # the front-end reads the batch THROUGH this device word (DAM_PCM_INDIRECT): it points at self.pcm unless bind_clips()
-        # re-pointed it at another resident batch -- a graph replay then reads that batch in place, no copy
-        self.pcm_word = torch.full((1,), self.pcm.data_ptr(), dtype=torch.int64, device=dev)
-        self._bound = self.pcm
+        self.from_features = feature_shape is not None
+        if self.from_features:
+            f, t = feature_shape
+            self.pcm = self.pcm_word = self._bound = None
+        else:
+            f, t = n_fft // 2 + 1, features.num_frames(n_samples, hop)
+            # stems and mix of a batch live in ONE buffer ([B, S+1, n, ch], mix last): the front-end is one launch
+            self.pcm = torch.zeros((batch, n_stems + 1, n_samples, channels), dtype=pcm_dtype, device=dev)
+            # the front-end reads the batch THROUGH this device word (DAM_PCM_INDIRECT): it points at self.pcm unless
+            # bind_clips() re-pointed it at another resident batch -- a graph replay then reads that batch in place, no copy
+            self.pcm_word = torch.full((1,), self.pcm.data_ptr(), dtype=torch.int64, device=dev)
+            self._bound = self.pcm
         self.x = torch.empty((batch, n_stems, f, t), dtype=torch.float32, device=dev)
         self.gt = torch.empty((batch, f, t), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.use_graph = use_graph
         self._graphs = None
         self._steps_run = 0
+        # outputs of the last step's forward (masked [B,F,T], tuple of S gains [B,1]): tensors of the captured graph's pool,
+        # kept alive here, so after a replay they hold that step's values (read them before the next step)
+        self.masked = self.gains = None
+        self.measure_exposed, self._exposed = False, []
         self.frames_per_step = batch * n_stems * t          # BASELINE metric unit: stem-spectrogram frames
         self.staged = optimizer.world_size > 1 and overlap
         if self.staged:
@@ -58,8 +71,34 @@ class TrainStep:
                 raise ValueError('ddp_late_parameters() must be the tail of the optimizer\'s parameter list')
             optimizer.set_bucket_boundaries([late[0]])
         self._stage = None
-        # gradients go straight from the backward kernels into the flat buckets (no .grad tensors, no gather launch)
+        # gradients go straight from the backward kernels into the flat buckets (no .grad tensors, no gather launch).  The
+        # binding changes the MODEL (its layers then return no .grad): close() -- or leaving the `with` block -- undoes it
         optimizer.bind_grad_slots()
+        self._slots_checked = False
+
+    def close(self):
+        """Gives the model back to ordinary autograd: parameters get .grad tensors again (gradient accumulation, clipping,
+        another optimizer, torch.save(model)).  The captured graphs stay replayable -- they write the flat bucket directly."""
+        self.opt.unbind_grad_slots()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def _check_slots_written(self):
+        """Overwrite semantics: a bound parameter that backward does not reach would keep the PREVIOUS step's gradient
+        (already summed by the all-reduce).  Checked once, on the first eager step: the bucket is poisoned before backward
+        and every parameter's slice must have been rewritten."""
+        bad = [i for i, p in enumerate(self.opt._params)
+               if not bool(torch.isfinite(self.opt._grad[self.opt._offsets[i]:self.opt._offsets[i + 1]]).all())]
+        if bad:
+            self.close()
+            raise RuntimeError('TrainStep: backward wrote no gradient for parameter(s) %s of the optimizer -- bound gradient '
+                               'slots need every parameter to receive a gradient each step' % bad[:8])
+        self._slots_checked = True
 
     @property
     def stems(self):
@@ -71,12 +110,14 @@ class TrainStep:
 
     # -- pieces ---------------------------------------------------------------------------------
     def _front_end(self):
+        if self.from_features:
+            return
         features.stft_logmag_clips(self.pcm, self.n_fft, self.hop, out_stems=self.x, out_mix=self.gt, pcm_word=self.pcm_word)
 
     def _fwd_bwd(self):
         self._front_end()
         self.opt.zero_grad(set_to_none=True)
-        loss = self.model.forward_mse(self.x, self.gt)[0]
+        loss, self.masked, self.gains = self.model.forward_mse(self.x, self.gt)
         loss.backward()
         ops.side_stream_join(self.device)
         ops.wgrad_flush(self.device)                # every weight gradient's slab reduction, one launch
@@ -88,7 +129,7 @@ class TrainStep:
         self._front_end()
         self.opt.zero_grad(set_to_none=True)
         tap = []
-        loss = self.model.forward_mse(self.x, self.gt, tap=tap)[0]
+        loss, self.masked, self.gains = self.model.forward_mse(self.x, self.gt, tap=tap)
         grads, dmid = distributed.backward_late(loss, self.opt.bucket_params(1), tap[0])
         ops.side_stream_join(self.device)
         ops.wgrad_flush(self.device)                # bucket 1 is complete
@@ -109,6 +150,14 @@ class TrainStep:
         self.opt.launch_update()
 
     def _eager(self):
+        first = not self._slots_checked and not torch.cuda.is_current_stream_capturing()
+        if first:
+            self.opt._grad.fill_(float('nan'))
+        self._eager_body()
+        if first:
+            self._check_slots_written()
+
+    def _eager_body(self):
         if self.staged:
             self._stage1()
             w1 = self.opt.all_reduce_grads(1, async_op=True)
@@ -135,6 +184,12 @@ class TrainStep:
         self.pcm[:, self.n_stems].copy_(mix, non_blocking=True)
         self._point_at(self.pcm)
 
+    def load_features(self, x, gt):
+        """feature_shape mode: copies one batch of features (x [B,S,F,T], gt [B,F,T]; device or page-locked host memory)
+        into the static inputs of the step."""
+        self.x.copy_(x, non_blocking=True)
+        self.gt.copy_(gt, non_blocking=True)
+
     def load_clips(self, clips):
         """Copies one batch of whole clips [B, S+1, n, ch] (mix last; device or page-locked host memory) into the
         static input: one contiguous copy."""
@@ -146,9 +201,9 @@ class TrainStep:
         ([B, S+1, n, ch] float32, contiguous, mix last) in place -- only the front-end's 8-byte address word changes.
         The caller keeps `clips` alive and unmodified until those steps have run (a reference is held here until the
         next load/bind)."""
-        if clips.device != self.pcm.device or clips.dtype != torch.float32 or tuple(clips.shape) != tuple(self.pcm.shape) \
+        if clips.device != self.pcm.device or clips.dtype != self.pcm.dtype or tuple(clips.shape) != tuple(self.pcm.shape) \
                 or not clips.is_contiguous():
-            raise ValueError('bind_clips: a contiguous float32 %s tensor on %s' % (tuple(self.pcm.shape), self.pcm.device))
+            raise ValueError('bind_clips: a contiguous %s %s tensor on %s' % (self.pcm.dtype, tuple(self.pcm.shape), self.pcm.device))
         self._point_at(clips)
 
     def capture(self, warmup=3):
@@ -187,6 +242,16 @@ class TrainStep:
             self._graphs = (ga,)
         return self
 
+    def exposed_wait_ms(self):
+        """Mean device time per step the all-reduces were NOT hidden behind backward (measure_exposed; N-rank staged steps);
+        None when nothing was measured.  Synchronises."""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize(self.device)
+        ms = sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
+        self._exposed = []
+        return ms
+
     def __call__(self):
         """Runs one step on the data currently in the static buffers; returns the (device) loss tensor."""
         self.opt.sync_hyper()
@@ -204,8 +269,14 @@ class TrainStep:
             w1 = self.opt.all_reduce_grads(1, async_op=True)      # RCCL's stream: runs beside graph A2
             g[1].replay()
             w0 = self.opt.all_reduce_grads(0, async_op=True)
+            if self.measure_exposed:      # device time from the end of backward to both buckets being there
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             w1.wait()
             w0.wait()
+            if self.measure_exposed:
+                e1.record()
+                self._exposed.append((e0, e1))
             g[2].replay()
         self._steps_run += 1
         ops.params_changed()        # parameters / running statistics moved (a graph replay runs none of the Python above)

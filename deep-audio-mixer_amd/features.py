@@ -13,6 +13,16 @@ from . import _lib
 
 AMIN = 1e-5      # data/dataset.py:154
 _tables = {}
+# include/dam_hip.h dam_pcm_dtype.  int16 / int32: integer PCM as the WAV file holds it, scaled by 1/2^15 / 1/2^31 inside the
+# kernel exactly as soundfile.read scales it (24-bit files arrive left-justified in int32, dataset_utils.read_wav_native)
+PCM_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int16: 2, torch.int32: 3}
+
+
+def _pcm_code(pcm, planar=False):
+    code = PCM_DTYPES.get(pcm.dtype)
+    if code is None or (planar and code >= 2):
+        raise TypeError('pcm must be float32 or float64%s' % ('' if planar else ', or int16 / int32 integer PCM'))
+    return code
 
 
 def _get_tables(device, n_fft):
@@ -34,15 +44,15 @@ def num_frames(n_samples, hop):
 
 
 def stft_logmag(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out=None):
-    """pcm: CUDA tensor [n_tracks, n_samples, channels] or [n_tracks, n_samples], float32 or
-    float64, channels in {1, 2} interleaved.  Returns float32 [n_tracks, n_fft/2+1, T] in dB."""
+    """pcm: CUDA tensor [n_tracks, n_samples, channels] or [n_tracks, n_samples], float32 / float64 in [-1, 1) or int16 /
+    int32 integer PCM (scaled by 1/2^15 / 1/2^31 in the kernel), channels in {1, 2} interleaved.
+    Returns float32 [n_tracks, n_fft/2+1, T] in dB."""
     _lib.require_cuda(pcm, gain, out)
     if pcm.dim() == 2:
         pcm = pcm.unsqueeze(-1)
     if pcm.dim() != 3:
         raise ValueError('pcm must be [tracks, samples(, channels)]')
-    if pcm.dtype not in (torch.float32, torch.float64):
-        raise TypeError('pcm must be float32 or float64')
+    code = _pcm_code(pcm)
     pcm = pcm.contiguous()
     n_tracks, n, ch = pcm.shape
     t = num_frames(n, hop)
@@ -55,7 +65,7 @@ def stft_logmag(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out=None)
         gain = gain.to(device=pcm.device, dtype=torch.float32).contiguous()
         if gain.numel() != n_tracks:
             raise ValueError('gain must have one entry per track')
-    st = _lib.lib().dam_stft_logmag_f32(_lib.ptr(pcm), 0 if pcm.dtype == torch.float32 else 1, n_tracks, n, ch,
+    st = _lib.lib().dam_stft_logmag_f32(_lib.ptr(pcm), code, n_tracks, n, ch,
                                         n * ch, _lib.ptr(win), _lib.ptr(tw), _lib.ptr(gain), n_fft, hop,
                                         AMIN, 1 if normalize else 0, _lib.ptr(out), _lib.stream())
     _lib.check(st, 'dam_stft_logmag_f32')
@@ -68,8 +78,9 @@ def stft_logmag_song_chunks(pcm, n_chunks, chunk_samples, n_fft=2048, hop=1024, 
     the batch the chunk loop at inference_utils.py:111-123 builds one chunk at a time.  Reads the song in place
     (strided launch, no gather copy)."""
     _lib.require_cuda(pcm, out)
-    if pcm.dim() != 3 or pcm.dtype not in (torch.float32, torch.float64):
+    if pcm.dim() != 3:
         raise ValueError('pcm must be a float32/float64 [stems, channels, samples] tensor')
+    _pcm_code(pcm, planar=True)
     pcm = pcm.contiguous()
     S, ch, n = pcm.shape
     if n_chunks * chunk_samples > n:
@@ -98,8 +109,9 @@ def stft_logmag_clips(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out
     _lib.require_cuda(pcm, gain, out_stems, out_mix)
     if pcm.dim() == 3:
         pcm = pcm.unsqueeze(-1)
-    if pcm.dim() != 4 or pcm.dtype not in (torch.float32, torch.float64):
-        raise ValueError('pcm must be a float32/float64 [clips, tracks, samples(, channels)] tensor')
+    if pcm.dim() != 4:
+        raise ValueError('pcm must be a [clips, tracks, samples(, channels)] tensor')
+    code = _pcm_code(pcm)
     pcm = pcm.contiguous()
     B, K, n, ch = pcm.shape
     if K < 2:
@@ -123,7 +135,7 @@ def stft_logmag_clips(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out
         if pcm_word.dtype != torch.int64 or pcm_word.numel() != 1:
             raise ValueError('pcm_word: one int64 on the device')
         src, flag = _lib.ptr(pcm_word), 0x100
-    st = _lib.lib().dam_stft_logmag_strided_f32(src, (0 if pcm.dtype == torch.float32 else 1) | flag, B, K * n * ch, K,
+    st = _lib.lib().dam_stft_logmag_strided_f32(src, code | flag, B, K * n * ch, K,
                                                 n * ch, n, ch, ch, 1, _lib.ptr(win), _lib.ptr(tw), _lib.ptr(gain), n_fft,
                                                 hop, AMIN, 1 if normalize else 0, _lib.ptr(out_stems), _lib.ptr(out_mix), 1,
                                                 _lib.stream())

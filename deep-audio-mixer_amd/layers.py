@@ -211,21 +211,33 @@ class _UpstreamBn:
     """What the consumer of a relu(bn(c)) activation needs to take that BatchNorm's two backward sums in its own data-gradient
     epilogue (ops.conv2d_dgrad(bn_bwd=)), and the slot where it leaves them for the producer's backward.  Travels as an attribute
     of the activation tensor: ConvBnReluFn.forward attaches it, an identity BasicBlock that receives the tensor picks it up."""
-    __slots__ = ('c', 'mean', 'invstd', 'scale', 'shift', 'bits', 'partials', 'dx_ptr')
+    __slots__ = ('c', 'mean', 'invstd', 'scale', 'shift', 'bits', 'partials', 'dx_ptr', 'dx_version')
 
     def __init__(self, c, mean, invstd, scale, shift, bits=None):
         # ReLU mask of the activation: fma(c, scale, shift) > 0 (plain relu(bn(c))) or the sign bytes of relu(bn(c) + shortcut)
         self.c, self.mean, self.invstd, self.scale, self.shift, self.bits = c, mean, invstd, scale, shift, bits
-        self.partials, self.dx_ptr = None, None
+        self.partials, self.dx_ptr, self.dx_version = None, None, None
 
     def request(self):
         return (self.c, self.mean, self.invstd, self.scale, self.shift) + ((self.bits,) if self.bits is not None else ())
 
+    def offer(self, sums, dx):
+        """Consumer side: `sums` were taken over exactly the values `dx` holds now."""
+        self.partials, self.dx_ptr, self.dx_version = sums, dx.data_ptr(), dx._version
+
     def take(self, grad):
-        """The sums the consumer left, if they belong to this gradient tensor; the slot is cleared either way."""
-        sums = self.partials if self.partials is not None and self.dx_ptr == grad.data_ptr() else None
+        """The sums the consumer left, if they belong to this gradient tensor AS IT IS NOW: same storage and no in-place
+        write since (autograd accumulates a second consumer's gradient, or a hook's edit, in place into the first-arrived
+        buffer -- same address, bumped version counter: the sums are stale then and the separate pass runs).  The slot is
+        cleared either way."""
+        ok = self.partials is not None and self.dx_ptr == grad.data_ptr() and self.dx_version == grad._version
+        sums = self.partials if ok else None
         self.partials = None
+        if sums is not None:
+            _UpstreamBn.hits += 1
         return sums
+
+    hits = 0       # how often a producer's backward used sums left by its consumer (diagnostic; the tests read it)
 
 
 class ConvBnReluFn(torch.autograd.Function):
@@ -355,7 +367,7 @@ class BasicBlockFn(torch.autograd.Function):
         up = ctx.upstream
         if up is not None and ops.DGRAD_BN_SUMS and up.c.shape == x.shape:
             dx, sums = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out, res_mask_bits=bits, bn_bwd=up.request())
-            up.partials, up.dx_ptr = sums, dx.data_ptr()
+            up.offer(sums, dx)
         else:
             dx = blk.spec1.dgrad(dc1, w1, hw, res=dout, res_mask=out)      # + dout * (out > 0): identity shortcut
         return (dx,) + first + (None, None, None, None, None)

@@ -7,6 +7,14 @@ exist, "_1s_" is literal, the header prints ``num_epochs - 1``).
 What is different underneath:
   * with ``criterion = nn.MSELoss()`` (what every notebook passes) loss and gradient come from the model's fused
     ``forward_mse`` (one pass over the features); any other criterion is applied to ``masked`` as in the reference;
+  * the training loop body (model_trainer.py:30-37: zero_grad, forward, loss, backward, step) becomes ONE hipGraph replay
+    once it has proven static: model, criterion and optimizer are this package's own (``forward_mse`` + ``optim.Adam``)
+    and the batch shape has repeated -- the first ``EAGER_BATCHES`` batches run the eager autograd sequence, the next one
+    captures ``engine.TrainStep(feature_shape=...)`` (its warm-up step is rolled back, so no extra optimizer step is
+    taken) and from then on a batch is a copy into the static inputs + a replay; batches of another shape (a ragged last
+    batch) run eagerly.  The reference's per-batch ``loss.item()`` and prints stay.  ``graph=False`` keeps everything eager;
+  * loaders without ``__len__`` (generators such as ``MultitrackAudioDataset.iter_batches``) are accepted: the epoch mean
+    is taken over the batches seen;
   * like the reference, the trainer never switches the model between train and eval mode: validation runs
     under ``torch.no_grad()`` with whatever mode the caller left the model in;
   * under ``torch.distributed`` only rank 0 prints and saves.
@@ -25,13 +33,67 @@ def _rank0():
 
 
 class ModelTrainer:
-    def __init__(self, model, criterion, optimizer, device, model_name='scalar2d'):
+    EAGER_BATCHES = 2          # same-shape batches run eagerly before the step is captured
+
+    def __init__(self, model, criterion, optimizer, device, model_name='scalar2d', *, graph=True):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.device = device
         self.model_name = model_name
         self.weights_dir = './weights'
         fusable = type(criterion) is torch.nn.MSELoss and criterion.reduction == 'mean'
         self._fused = fusable and hasattr(model, 'forward_mse')
+        from .optim import Adam
+        self._graphable = bool(graph) and self._fused and isinstance(optimizer, Adam)
+        self._step = self._shape = None
+        self._seen = 0
+        self.graph_steps = self.eager_steps = 0       # diagnostic: how the training batches were run
+
+    # ---- the captured step
+    def _capture(self, feats, target):
+        """Builds and captures engine.TrainStep for this batch shape.  Capturing needs one eager warm-up step through the
+        slot-bound path (it sizes the workspaces the graph will bake in); that step is rolled back -- parameters, Adam
+        moments and step count, BatchNorm running buffers -- so the trajectory is exactly the eager loop's."""
+        from .engine import TrainStep
+        opt, model = self.optimizer, self.model
+        B, S, F, T = feats.shape
+        step = TrainStep(model, opt, S, batch=B, feature_shape=(F, T), use_graph=True, device=feats.device)
+        step.load_features(feats, target)
+        keep = [t.clone() for t in (opt._flat, opt._exp_avg, opt._exp_avg_sq, opt._step)]
+        bufs = [(b, b.clone()) for b in model.buffers()]
+        training = model.training
+        step.capture(warmup=1)
+        for dst, src in zip((opt._flat, opt._exp_avg, opt._exp_avg_sq, opt._step), keep):
+            dst.copy_(src)
+        for b, saved in bufs:
+            b.copy_(saved)
+        model.train(training)
+        return step
+
+    def _train_batch(self, batch):
+        feats, target = (t.to(self.device) for t in batch)
+        shape = (tuple(feats.shape), tuple(target.shape), feats.dtype, self.model.training)
+        if self._graphable and shape == self._shape and (self._step is not None or self._seen >= self.EAGER_BATCHES):
+            if self._step is None:
+                self._step = self._capture(feats, target)
+            else:
+                self._step.load_features(feats, target)
+            self.graph_steps += 1
+            return self._step()
+        if shape != self._shape and self._step is None:
+            self._shape, self._seen = shape, 0
+        self._seen += shape == self._shape
+        self.eager_steps += 1
+        self.optimizer.zero_grad()
+        loss = self._batch_loss((feats, target))
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def close(self):
+        """Drops the captured step and gives the model's parameters back to ordinary autograd (.grad tensors)."""
+        if self._step is not None:
+            self._step.close()
+            self._step = None
 
     # ---- one batch -> loss tensor (on the device)
     def _batch_loss(self, batch):
@@ -43,19 +105,15 @@ class ModelTrainer:
     def _run(self, loader, train):
         """Mean loss over the loader; one optimisation step per batch when ``train``."""
         total, quiet = 0.0, not _rank0()
+        n = len(loader) if hasattr(loader, '__len__') else None
+        step = 0
         for step, batch in enumerate(loader, start=1):
-            if train:
-                self.optimizer.zero_grad()
-                loss = self._batch_loss(batch)
-                loss.backward()
-                self.optimizer.step()
-            else:
-                loss = self._batch_loss(batch)
-            value = loss.item()
+            loss = self._train_batch(batch) if train else self._batch_loss(batch)
+            value = loss.item()               # the reference's per-batch host sync (model_trainer.py:41,43)
             if train and step % _LOG_EVERY == 0 and not quiet:
-                print('[%d/%4d] loss: %.3f' % (step, len(loader), value))
+                print('[%d/%4d] loss: %.3f' % (step, n, value) if n is not None else '[%d/   ?] loss: %.3f' % (step, value))
             total += value
-        return total / len(loader)
+        return total / (n if n is not None else step)
 
     def _train_epoch(self, train_loader):
         return self._run(train_loader, True)

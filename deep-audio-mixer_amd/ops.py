@@ -323,6 +323,16 @@ def _wgrad_queue(device):
     return q
 
 
+def wgrad_abandon(device=None):
+    """Drops reductions that were recorded but never flushed -- a backward pass that raised half-way leaves them behind,
+    and the next step's jobs would target the same gradients from the same flush launch.  Called at the start of every
+    step (optim.Adam.zero_grad, engine.TrainStep); a no-op in the normal case."""
+    for key, q in _wgrad_queues.items():
+        if q[1] and (device is None or key == (device.type, device.index)):
+            _lib.check(_lib.lib().dam_wgrad_queue_init(ctypes.addressof(q[0])), 'dam_wgrad_queue_init')
+            q[1] = 0
+
+
 def wgrad_flush(device=None):
     """Runs the slab reductions recorded by conv2d_wgrad(..., defer=True) in one launch on the current stream; the
     gradients are in their `out` buffers when that launch is done.  No-op when nothing is recorded."""

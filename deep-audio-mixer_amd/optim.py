@@ -132,6 +132,12 @@ class Adam(torch.optim.Optimizer):
                 del p._dam_grad
         self.slots_bound = False
 
+    def zero_grad(self, set_to_none=True):
+        """torch's zero_grad, plus: reductions a failed backward left recorded are dropped (ops.wgrad_abandon)."""
+        if self._flat.is_cuda:
+            ops.wgrad_abandon(self._flat.device)
+        return super().zero_grad(set_to_none=set_to_none)
+
     def gather_grads(self, bucket=None, grads=None):
         """One launch: every p.grad (or the given list of gradient tensors, bucket order) -> its slice of the flat
         buffer (missing grads count as zero).  bucket=None: all parameters."""

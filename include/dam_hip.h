@@ -35,7 +35,11 @@ typedef enum dam_status {
     DAM_ERR_WORKSPACE = -4       /* caller-provided workspace too small */
 } dam_status;
 
-typedef enum dam_pcm_dtype { DAM_PCM_F32 = 0, DAM_PCM_F64 = 1 } dam_pcm_dtype;
+/* Sample types the front-end reads.  DAM_PCM_S16 / DAM_PCM_S32: integer PCM exactly as the WAV file holds it (interleaved or
+ * mono), scaled by 1/2^15 / 1/2^31 as soundfile.read does (data/dataset.py:194) -- no host conversion, half the PCIe bytes
+ * for 16-bit files; results are bit-identical to DAM_PCM_F32 on host-converted samples.  24-bit files: the reader unpacks
+ * them to left-justified DAM_PCM_S32 (value << 8).  Strides are counted in samples of the given type. */
+typedef enum dam_pcm_dtype { DAM_PCM_F32 = 0, DAM_PCM_F64 = 1, DAM_PCM_S16 = 2, DAM_PCM_S32 = 3 } dam_pcm_dtype;
 /* OR-ed into pcm_dtype: `pcm` is a DEVICE word holding the address of the PCM (const void* const*), read when the kernel
  * starts.  A launch captured in a hipGraph then follows whichever resident batch the word points at -- the caller re-points
  * the word (8 bytes) instead of copying a batch into the graph's fixed input buffer.  Layout arguments describe the pointee. */
@@ -43,7 +47,10 @@ typedef enum dam_pcm_dtype { DAM_PCM_F32 = 0, DAM_PCM_F64 = 1 } dam_pcm_dtype;
 struct dam_bn_fin;      /* defined in the BatchNorm section */
 struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 
-/* Library / build identification ("gfx950"). */
+/* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
+ * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
+ * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
+#define DAM_ABI_VERSION 7
 const char* dam_arch(void);
 int dam_abi_version(void);
 

@@ -190,3 +190,28 @@ def train_step_ref(model, optimizer, x, gt):
     loss.backward()
     optimizer.step()
     return loss.detach(), gains
+
+
+# ---- ReLU decisions given from outside (per-block gradient parity, tests/test_blocks_gpu.py) --------------------------------
+# A float32 implementation and this float64 restatement disagree on relu'(v) wherever |v| is below the float32 rounding
+# error of v (a handful of the ~17 M activations of a full-size layer); ONE such element moves a weight gradient by ~1e-3 of
+# its norm.  For a deterministic gradient comparison the restatement therefore takes the 0/1 decisions as an argument -- the
+# test passes the device path's own decisions and asserts separately that they differ from sign(v) only where |v| is at
+# rounding level (so a wrong mask still fails).  With mask=None these functions are the plain reference arithmetic.
+def masked_relu(v, mask=None):
+    """relu(v) with the decisions `mask` (bool, same shape): v * mask.  Returns (result, v detached)."""
+    if mask is None:
+        mask = v.detach() > 0
+    return v * mask.to(v.dtype), v.detach()
+
+
+def stem_forward_masked(conv, bn, x, mask=None):
+    """models/model_resnet.py:97 -- relu(bn1(conv1(x))) -> (a, pre-activation)."""
+    return masked_relu(bn(conv(x)), mask)
+
+
+def block_forward_masked(block: RefBasicBlock, x, m1=None, m2=None):
+    """models/model_resnet.py:23-28 -> (out, pre-activation of the inner ReLU, pre-activation of the outer ReLU)."""
+    a1, v1 = masked_relu(block.bn1(block.conv1(x)), m1)
+    out, v2 = masked_relu(block.bn2(block.conv2(a1)) + block.shortcut(x), m2)
+    return out, v1, v2

@@ -27,7 +27,8 @@ def test_library_exports_header(dam_lib):
         assert len(_lib.SIGNATURES[name][1]) == nargs, name
     assert set(_lib.SIGNATURES) == set(decl)
     assert dam_lib.dam_arch() == b'gfx950'
-    assert dam_lib.dam_abi_version() >= 1
+    header = open(os.path.join(ROOT, 'include', 'dam_hip.h')).read()
+    assert dam_lib.dam_abi_version() == _lib.EXPECTED_ABI == int(re.search(r'#define DAM_ABI_VERSION (\d+)', header).group(1))
     assert dam_lib.dam_stft_twiddle_count(2048) == 2048
 
 
@@ -38,3 +39,12 @@ def test_product_fails_loudly_without_gpu():
         pytest.skip('GPU present')
     with pytest.raises(RuntimeError, match='GPU only'):
         features.stft_logmag(torch.zeros(1, 4096), hop=1024)
+
+
+def test_stale_library_is_refused(dam_lib, monkeypatch):
+    """A prebuilt libdam_hip.so of another ABI version must not be bound (arguments would be misread as pointers)."""
+    from deep_audio_mixer_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'EXPECTED_ABI', _lib.EXPECTED_ABI + 1)
+    with pytest.raises(RuntimeError, match='stale'):
+        _lib.lib()

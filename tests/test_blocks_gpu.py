@@ -1,0 +1,258 @@
+"""GPU: every residual block of the C3 training step (ResNet18, 8 stems, 1025x130 frames, BATCH 8 -- the shapes bench.py
+times) backward AND forward against the float64 oracle block, one block (or a short chain of blocks) at a time, with the
+gradients going where the captured step puts them (the optimizer's flat slots, deferred slab reductions).
+
+Deterministic by construction: a float32 path and the float64 oracle disagree on relu'(v) wherever |v| is below the float32
+rounding error of v -- a few of the ~17 M activations of a full-resolution layer, and one such element moves a weight
+gradient by ~1e-3 of its norm.  So the oracle takes the ReLU decisions of the device run (oracle/models_ref.py:
+block_forward_masked) and the test asserts, separately, that those decisions differ from the oracle's own only where the
+oracle's pre-activation is at rounding level (< 2e-5 on BatchNorm outputs of order 1): a wrong mask fails there, a wrong tap /
+halo / stride / sum fails the 2e-5-of-norm comparison of every output: dx, dW, dgamma, dbeta of every convolution and BatchNorm.
+
+Chains: stem -> layer1.0 -> layer1.1 (the BatchNorm-backward sums handed upstream through `_UpstreamBn` by the identity
+blocks' data gradients, EPI 2 / 3 of the strip kernel) and layer2.1 -> layer3.0 (the 4256-record fallback of the 257x33 stage).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models_ref
+
+pytestmark = pytest.mark.gpu
+B = 8
+TOL = 2e-5          # of the tensor's norm
+FLIP_LEVEL = 2e-5   # |oracle pre-activation| where the device's ReLU decision may differ
+
+
+@pytest.fixture(scope='module')
+def dam(dam_lib):
+    import deep_audio_mixer_amd  # noqa: F401
+    from deep_audio_mixer_amd import layers, ops
+    torch.set_num_threads(16)
+    return layers, ops
+
+
+def _randomize(module, gen):
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+            elif isinstance(m, torch.nn.Conv2d):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (2.0 / (m.weight[0].numel())) ** 0.5)
+    return module
+
+
+def _bind_slots(params):
+    """What optim.Adam.bind_grad_slots does for the captured step: every parameter's gradient is written in place."""
+    n = sum(p.numel() for p in params)
+    flat = torch.full((n,), float('nan'), dtype=torch.float32, device='cuda')
+    off = 0
+    for p in params:
+        p._dam_grad = flat[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    return flat
+
+
+def _a1_mask(ops, out):
+    """ReLU decisions of the never-materialised a1 = relu(bn1(c1)) of the block that produced `out`: the same fused affine
+    expression the consumers evaluate while loading c1 (bn_apply is that expression written out)."""
+    saved = out.grad_fn.saved_tensors
+    c1, sc1, sh1 = saved[5], saved[12], saved[13]
+    return (ops.bn_apply(c1, sc1, sh1, relu=True) > 0).permute(0, 3, 1, 2).cpu()
+
+
+def _nchw(t):
+    return t.detach().permute(0, 3, 1, 2).double().cpu()
+
+
+def _check_masks(name, pre, mask):
+    """The device's decisions may differ from sign(oracle pre-activation) only at rounding level."""
+    diff = mask != (pre > 0)
+    n = int(diff.sum())
+    worst = float(pre[diff].abs().max()) if n else 0.0
+    assert worst < FLIP_LEVEL, '%s: ReLU decision differs at |v| = %.3g' % (name, worst)
+    return n
+
+
+def _rel(got, want):
+    return float((got.double().cpu() - want).norm() / (want.norm() + 1e-300))
+
+
+def _compare_grads(pairs, report):
+    bad = []
+    for name, got, want in pairs:
+        e = _rel(got, want)
+        report.append((name, e))
+        if not e <= TOL:
+            bad.append((name, e))
+    return bad
+
+
+def _block_pairs(prefix, blk, ref, slotted):
+    out = []
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert p.shape == q.shape
+        g = p._dam_grad if slotted else p.grad
+        out.append((prefix + n, g, q.grad))
+    return out
+
+
+BLOCKS = [  # name, cin, cout, stride, input H, W   
+    ('layer1', 16, 16, 1, 1025, 130), ('layer2.0', 16, 32, 2, 1025, 130), ('layer2.1', 32, 32, 1, 513, 65),
+    ('layer3.0', 32, 64, 2, 513, 65), ('layer3.1', 64, 64, 1, 257, 33), ('layer4.0', 64, 96, 2, 257, 33),
+    ('layer4.1', 96, 96, 1, 129, 17), ('layer5.0', 96, 128, 2, 129, 17), ('layer5.1', 128, 128, 1, 65, 9),
+    ('layer6.0', 128, 256, 2, 65, 9), ('layer6.1', 256, 256, 1, 33, 5)]
+
+
+@pytest.mark.parametrize('name,cin,cout,stride,H,W', BLOCKS, ids=[b[0] for b in BLOCKS])
+@pytest.mark.parametrize('slotted', [False, True], ids=['grad', 'slots'])
+def test_basic_block_c3_batch8(dam, name, cin, cout, stride, H, W, slotted):
+    layers, ops = dam
+    gen = torch.Generator().manual_seed(7 + [b[0] for b in BLOCKS].index(name))
+    blk = _randomize(layers.BasicBlock(cin, cout, stride), gen)
+    ref = models_ref.RefBasicBlock(cin, cout, stride).double().train()
+    ref.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+    blk = blk.cuda().train()
+    x = torch.relu(torch.randn((B, H, W, cin), generator=gen))           # NHWC, like the activation of the block in front
+    dout_shape = (B, (H - 1) // stride + 1, (W - 1) // stride + 1, cout)
+    dout = torch.randn(dout_shape, generator=gen)
+    params = list(blk.parameters())
+    if slotted:
+        _bind_slots(params)
+    xc = x.cuda().requires_grad_(True)
+    out = blk(xc)
+    m1, m2 = _a1_mask(ops, out), (out > 0).permute(0, 3, 1, 2).cpu()
+    out.backward(dout.cuda())
+    ops.wgrad_flush()
+    torch.cuda.synchronize()
+    # oracle, float64, the device's ReLU decisions
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    out_r, v1, v2 = models_ref.block_forward_masked(ref, xr, m1, m2)
+    flips = _check_masks(name + ' inner', v1, m1) + _check_masks(name + ' outer', v2, m2)
+    out_r.backward(dout.permute(0, 3, 1, 2).double())
+    report = []
+    e_out = _rel(_nchw(out), out_r.detach())
+    assert e_out <= TOL, ('forward', e_out)
+    bad = _compare_grads([('dx', _nchw(xc.grad), xr.grad)] + _block_pairs('', blk, ref, slotted), report)
+    print('%s B=%d: forward %.1e, %d rounding-level ReLU decisions taken from the device; worst gradient %s'
+          % (name, B, e_out, flips, max(report, key=lambda r: r[1])))
+    np.testing.assert_allclose(blk.bn2.running_var.cpu().numpy(), ref.bn2.running_var.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(blk.bn1.running_mean.cpu().numpy(), ref.bn1.running_mean.numpy(), rtol=1e-5, atol=1e-7)
+    assert not bad, bad
+
+
+def test_chain_stem_layer1_upstream_sums(dam):
+    """stem -> layer1.0 -> layer1.1 at 8 x 8 x 1025 x 130 with bound gradient slots: both identity blocks hand the BatchNorm-
+    backward sums of the activation in front of them upstream (layers._UpstreamBn)."""
+    layers, ops = dam
+    from _inputs import model_input
+    gen = torch.Generator().manual_seed(11)
+    S, H, W = 8, 1025, 130
+    conv, bn = torch.nn.Conv2d(S, 16, 3, 1, 1, bias=False), torch.nn.BatchNorm2d(16)
+    stem = _randomize(torch.nn.Sequential(conv, bn), gen)
+    blks = [_randomize(layers.BasicBlock(16, 16, 1), gen) for _ in range(2)]
+    ref_stem = torch.nn.Sequential(torch.nn.Conv2d(S, 16, 3, 1, 1, bias=False), torch.nn.BatchNorm2d(16)).double().train()
+    ref_stem.load_state_dict({k: v.double() for k, v in stem.state_dict().items()})
+    refs = []
+    for b in blks:
+        r = models_ref.RefBasicBlock(16, 16, 1).double().train()
+        r.load_state_dict({k: v.double() for k, v in b.state_dict().items()})
+        refs.append(r)
+    stem, blks = stem.cuda().train(), [b.cuda().train() for b in blks]
+    spec = layers.ConvSpec(S, 16, 3, 1, 1, in_nchw=True)
+    params = list(stem.parameters()) + [p for b in blks for p in b.parameters()]
+    _bind_slots(params)
+    x = torch.from_numpy(model_input(B, S, H, W, seed=5)[0])              # dB-valued features, NCHW
+    dout = torch.randn((B, H, W, 16), generator=gen)
+    a0 = layers.ConvBnReluFn.apply(x.cuda(), stem[0].weight, None, stem[1].weight, stem[1].bias, spec, stem[1], True)
+    o1 = blks[0](a0)
+    o2 = blks[1](o1)
+    assert ops.DGRAD_BN_SUMS and getattr(a0, '_dam_upstream', None) is not None and getattr(o1, '_dam_upstream', None) is not None
+    sign = lambda t: (t > 0).permute(0, 3, 1, 2).cpu()
+    masks = [sign(a0), _a1_mask(ops, o1), sign(o1), _a1_mask(ops, o2), sign(o2)]
+    up0, up1 = a0._dam_upstream, o1._dam_upstream
+    hits = layers._UpstreamBn.hits
+    o2.backward(dout.cuda())
+    ops.wgrad_flush()
+    torch.cuda.synchronize()
+    assert up0.partials is None and up1.partials is None
+    assert layers._UpstreamBn.hits == hits + 2                            # both hand-offs were used by the producers' backward
+    xr = x.double()
+    a0r, v0 = models_ref.stem_forward_masked(ref_stem[0], ref_stem[1], xr, masks[0])
+    o1r, v1, v2 = models_ref.block_forward_masked(refs[0], a0r, masks[1], masks[2])
+    o2r, v3, v4 = models_ref.block_forward_masked(refs[1], o1r, masks[3], masks[4])
+    flips = sum(_check_masks('chain %d' % i, v, m) for i, (v, m) in enumerate(zip((v0, v1, v2, v3, v4), masks)))
+    o2r.backward(dout.permute(0, 3, 1, 2).double())
+    e_out = _rel(_nchw(o2), o2r.detach())
+    assert e_out <= TOL, ('forward', e_out)
+    report = []
+    pairs = [('stem.' + n, p._dam_grad, q.grad) for (n, p), (_, q) in zip(stem.named_parameters(), ref_stem.named_parameters())]
+    for i in range(2):
+        pairs += _block_pairs('layer1.%d.' % i, blks[i], refs[i], True)
+    bad = _compare_grads(pairs, report)
+    print('stem -> layer1.0 -> layer1.1: forward %.1e, %d device ReLU decisions; worst %s' % (e_out, flips, max(report, key=lambda r: r[1])))
+    assert not bad, bad
+
+
+def test_chain_layer2_1_layer3_0(dam):
+    """layer2.1 (identity, 32 ch on 513x65) -> layer3.0 (32 -> 64, stride 2 -> 257x33: the stage whose 4256 statistics records
+    exceed the epilogue tables and keep the separate pass), slots bound, input gradient included."""
+    layers, ops = dam
+    gen = torch.Generator().manual_seed(12)
+    blks = [_randomize(layers.BasicBlock(32, 32, 1), gen), _randomize(layers.BasicBlock(32, 64, 2), gen)]
+    refs = [models_ref.RefBasicBlock(32, 32, 1).double().train(), models_ref.RefBasicBlock(32, 64, 2).double().train()]
+    for b, r in zip(blks, refs):
+        r.load_state_dict({k: v.double() for k, v in b.state_dict().items()})
+    blks = [b.cuda().train() for b in blks]
+    _bind_slots([p for b in blks for p in b.parameters()])
+    x = torch.relu(torch.randn((B, 513, 65, 32), generator=gen))
+    dout = torch.randn((B, 257, 33, 64), generator=gen)
+    xc = x.cuda().requires_grad_(True)
+    o1 = blks[0](xc)
+    o2 = blks[1](o1)
+    masks = [_a1_mask(ops, o1), (o1 > 0).permute(0, 3, 1, 2).cpu(), _a1_mask(ops, o2), (o2 > 0).permute(0, 3, 1, 2).cpu()]
+    o2.backward(dout.cuda())
+    ops.wgrad_flush()
+    torch.cuda.synchronize()
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    o1r, v1, v2 = models_ref.block_forward_masked(refs[0], xr, masks[0], masks[1])
+    o2r, v3, v4 = models_ref.block_forward_masked(refs[1], o1r, masks[2], masks[3])
+    flips = sum(_check_masks('chain %d' % i, v, m) for i, (v, m) in enumerate(zip((v1, v2, v3, v4), masks)))
+    o2r.backward(dout.permute(0, 3, 1, 2).double())
+    e_out = _rel(_nchw(o2), o2r.detach())
+    assert e_out <= TOL, ('forward', e_out)
+    report = []
+    pairs = [('dx', _nchw(xc.grad), xr.grad)]
+    for i, nm in enumerate(('layer2.1.', 'layer3.0.')):
+        pairs += _block_pairs(nm, blks[i], refs[i], True)
+    bad = _compare_grads(pairs, report)
+    print('layer2.1 -> layer3.0: forward %.1e, %d device ReLU decisions; worst %s' % (e_out, flips, max(report, key=lambda r: r[1])))
+    assert not bad, bad
+
+
+def test_upstream_sums_are_dropped_when_the_activation_has_a_second_consumer(dam, monkeypatch):
+    """The stem output feeds layer1.0 AND an auxiliary tap: autograd accumulates the tap's gradient in place into the buffer
+    layer1.0's data gradient returned (same address, bumped version) -- the sums left beside that buffer are stale and must
+    not be used.  Gradients then equal the path that never takes the sums (DAM_NO_DGRAD_SUMS)."""
+    layers, ops = dam
+    from _inputs import model_input
+    S, H, W, b = 4, 257, 40, 2
+    x = torch.from_numpy(model_input(b, S, H, W, seed=3)[0]).cuda()
+    tap_w = torch.randn((b, H, W, 16), generator=torch.Generator().manual_seed(5)).cuda()
+    dout = torch.randn((b, H, W, 16), generator=torch.Generator().manual_seed(6)).cuda()
+    spec = layers.ConvSpec(S, 16, 3, 1, 1, in_nchw=True)
+    results = []
+    for sums_on in (True, False):
+        monkeypatch.setattr(ops, 'DGRAD_BN_SUMS', sums_on)
+        gen = torch.Generator().manual_seed(21)
+        stem = _randomize(torch.nn.Sequential(torch.nn.Conv2d(S, 16, 3, 1, 1, bias=False), torch.nn.BatchNorm2d(16)), gen).cuda().train()
+        blk = _randomize(layers.BasicBlock(16, 16, 1), gen).cuda().train()
+        hits = layers._UpstreamBn.hits
+        a0 = layers.ConvBnReluFn.apply(x, stem[0].weight, None, stem[1].weight, stem[1].bias, spec, stem[1], True)
+        loss = (blk(a0) * dout).sum() + (a0 * tap_w).sum()
+        loss.backward()
+        assert layers._UpstreamBn.hits == hits          # never used: stale by construction (or switched off)
+        results.append([p.grad.clone() for p in list(stem.parameters()) + list(blk.parameters())])
+    for a, c in zip(*results):
+        assert float((a - c).norm()) <= 1e-6 * float(c.norm()) + 1e-12

@@ -278,3 +278,29 @@ def test_bench_refuses_to_run_fewer_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='1'),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'WORLD_SIZE' in r.stderr
+
+
+def test_bench_counts_gpus_from_sysfs_without_a_gpu_runtime(tmp_path, monkeypatch):
+    """bench.visible_gpu_count(): KFD topology nodes with SIMDs whose render node is accessible, narrowed by
+    HIP_VISIBLE_DEVICES -- no torch.cuda / HIP call in the parent of an N-rank run."""
+    import builtins
+    import glob as globmod
+    import bench
+    nodes = tmp_path / 'nodes'
+    props = {0: 'cpu_cores_count 64\nsimd_count 0\ndrm_render_minor -1\n',
+             1: 'cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor 128\n',
+             2: 'cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor 129\n',
+             3: 'cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor 130\n'}
+    for i, txt in props.items():
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / 'properties').write_text(txt)
+    real_glob, real_exists, real_access, real_open = globmod.glob, os.path.exists, os.access, builtins.open
+    monkeypatch.setattr(globmod, 'glob', lambda pat: real_glob(str(nodes / '*' / 'properties')) if 'kfd' in pat else real_glob(pat))
+    visible = {'/dev/dri/renderD128', '/dev/dri/renderD129'}            # the third GPU belongs to another container
+    monkeypatch.setattr(os.path, 'exists', lambda q: q in visible or (not str(q).startswith('/dev/dri') and real_exists(q)))
+    monkeypatch.setattr(os, 'access', lambda q, m: q in visible or (not str(q).startswith('/dev/dri') and real_access(q, m)))
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '1')
+    assert bench.visible_gpu_count() == 1

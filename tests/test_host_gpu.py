@@ -398,3 +398,67 @@ def test_feature_cache_roundtrip(dam, tmp_path):
     off = (aug - cached[1][0]).flatten(1)
     assert torch.allclose(off, off[:, :1].expand_as(off), atol=1e-4)          # one dB offset per stem (:170-179)
     assert off[:, 0].abs().max() <= 20 * np.log10(1.4) + 1e-3
+
+
+def test_trainer_captured_step_equals_eager_loop(dam, tmp_path, monkeypatch, capsys):
+    """ModelTrainer.fit runs the loop body as one hipGraph replay from the third same-shape batch on: same
+    loss list as the all-eager loop, ragged last batch and a second epoch included; loaders without __len__ are accepted."""
+    from deep_audio_mixer_amd.model_trainer import ModelTrainer
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    monkeypatch.chdir(tmp_path)
+    os.mkdir('weights')
+    shape = (2, 1025, 17)
+    batches = [tuple(torch.from_numpy(a) for a in model_input(3, *shape, seed=40 + k)) for k in range(6)]
+    batches.append(tuple(torch.from_numpy(a) for a in model_input(2, *shape, seed=50)))        # ragged last batch
+    val = batches[:1]
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(4)
+        model = ResNet18(n_stems=2, input_shape=shape[1:]).cuda().train()
+        opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr = ModelTrainer(model, torch.nn.MSELoss(), opt, torch.device('cuda'), model_name='g', graph=graph)
+        per_batch = []
+        real = tr._train_batch
+        tr._train_batch = lambda b, real=real, acc=per_batch: acc.append(real(b).item()) or torch.tensor(acc[-1])
+        tl, vl = tr.fit(batches, val, 0, 2)
+        assert (tr.graph_steps, tr.eager_steps) == ((10, 4) if graph else (0, 14))     # 2 eager + 4 graph + ragged, then 6 + ragged
+        runs.append((per_batch, tl, vl, model.state_dict()['bn1.running_mean'].clone()))
+        if graph:      # a generator loader (what MultitrackAudioDataset.iter_batches is), epoch mean over the batches seen
+            t2, _ = tr.fit((b for b in batches[:3]), val, 2, 1)
+            assert len(t2) == 1 and np.isfinite(t2[0])
+            tr.close()
+            assert not hasattr(next(model.parameters()), '_dam_grad')
+    np.testing.assert_allclose(runs[1][0], runs[0][0], rtol=2e-5)
+    np.testing.assert_allclose(runs[1][1], runs[0][1], rtol=2e-5)
+    np.testing.assert_allclose(runs[1][2], runs[0][2], rtol=2e-5)
+    assert torch.allclose(runs[1][3], runs[0][3], rtol=1e-5, atol=1e-6)
+    assert runs[0][0][-1] < runs[0][0][0]
+    capsys.readouterr()
+
+
+def test_bench_two_rank_spawn_path_gloo_rehearsal(dam):
+    """`python bench.py --gpus 2` as a fresh process: the parent counts GPUs from sysfs, starts two ranks itself
+    (torch.distributed.run), the ranks run the staged step (graphs A1 / A2 / B, two async buckets) and rank 0 prints ONE line.
+    gloo carries the buckets because this box has one GPU (DAM_DIST_BACKEND=gloo lets two ranks share it); with RCCL the same
+    code path runs one rank per GPU.  Not a scaling number -- the line's shape and the staged schedule are what is checked."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(DAM_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-roofline', '--no-host-stream', '--repeat', '1'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out['config']
+    assert out['n_gpus'] == 2 and cfg['world_size'] == 2 and cfg['grad_buckets'] == 2 and cfg['allreduce_overlap'] is True
+    assert cfg['dist_backend'] == 'gloo' and cfg['global_batch'] == 16 and cfg['sync_per_step'] is False
+    assert np.isfinite(cfg['final_loss']) and out['value'] > 0 and out['steps'] == 3
+    pr = out['per_rank']
+    assert len(pr['ms_per_step']) == 2 and pr['ms_per_step_min'] <= pr['ms_per_step_max']
+    assert all(w is not None and w >= 0 for w in pr['exposed_allreduce_wait_ms'])
+    assert out['repeat']['regions'] == 1

@@ -98,9 +98,90 @@ def test_iter_batches_equals_items(dam, tmp_path):
     assert torch.equal(sub[0][0][0], items[6][0]) and torch.equal(sub[0][0][1], items[1][0])
     # augmentation: per-item device draws, identical through both paths and across runs
     a = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr, seed=11, augment_data=True)
-    xa = torch.cat([b[0] for b in a.iter_batches(4)])
+    a2 = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr, seed=11, augment_data=True)
+    xa = torch.cat([b[0] for b in a.iter_batches(4)])           # first read of every item
     for i in (0, 5):
-        assert torch.equal(xa[i], a[i][0])
+        assert torch.equal(xa[i], a2[i][0])                      # ... equals the other path's first read, same seed
     off = (xa[2] - items[2][0]).flatten(1)
     want = [20 * np.log10(features_ref.augment_gain_ref(11, 2, k)) for k in range(4)]
     assert torch.allclose(off.median(dim=1).values.cpu(), torch.tensor(want, dtype=torch.float32), atol=2e-3)
+    # every access is a fresh draw (data/dataset.py:164-168 draws np.random.uniform per access): the second pass differs
+    # from the first, through either path, and (seed, pass) reproduces it
+    xb = torch.cat([b[0] for b in a.iter_batches(4)])
+    assert not torch.equal(xb[2], xa[2])
+    off2 = (xb[2] - items[2][0]).flatten(1)
+    want2 = [20 * np.log10(features_ref.augment_gain_ref(11, 2 + (1 << 40), k)) for k in range(4)]
+    assert torch.allclose(off2.median(dim=1).values.cpu(), torch.tensor(want2, dtype=torch.float32), atol=2e-3)
+    assert torch.equal(a2[5][0], xb[5])                          # a2's second read of item 5
+    a2.set_epoch(1)
+    assert torch.equal(a2[2][0], xb[2]) and not torch.equal(a2[2][0], xb[2])     # pass 1 again, then pass 2
+    # unseeded datasets do not share a base
+    u1 = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr, augment_data=True)
+    u2 = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr, augment_data=True)
+    assert not torch.equal(u1[0][0], u2[0][0])
+
+
+@pytest.mark.parametrize('n_fft,hop', [(2048, 1024), (2048, 512), (1024, 256)])
+def test_integer_pcm_is_read_as_the_file_holds_it(dam, n_fft, hop):
+    """DAM_PCM_S16 / DAM_PCM_S32 (include/dam_hip.h): the kernel scales integer samples by 1/2^(bits-1) as soundfile.read does
+    (data/dataset.py:194) -- bit for bit the float32 kernel on host-converted samples, and the oracle on the float64 ones."""
+    from deep_audio_mixer_amd import features
+    from _inputs import feature_error
+    rng = np.random.default_rng(6)
+    n = 3 * 16000 + 17
+    for ch in (2, 1):
+        s16 = rng.integers(-20000, 20000, (3, n, ch), dtype=np.int16)
+        s16[0, :5] = [[-32768] * ch, [32767] * ch, [0] * ch, [1] * ch, [-1] * ch]
+        as_f32 = (s16.astype(np.float32) / np.float32(32768.0))
+        a = features.stft_logmag(torch.from_numpy(s16).cuda(), n_fft, hop)
+        b = features.stft_logmag(torch.from_numpy(as_f32).cuda(), n_fft, hop)
+        assert torch.equal(a, b)
+        want = features_ref.compute_features((s16[1].astype(np.float64) / 32768.0).mean(1), n_fft, hop)
+        rel, db = feature_error(a[1].cpu().numpy(), want)
+        assert rel <= 2e-6 and db <= 2e-3
+        # 24-bit samples left-justified in int32 (what read_wav_native yields for 24-bit files), and full 32-bit ones
+        s24 = rng.integers(-(1 << 22), 1 << 22, (2, n, ch)).astype(np.int32) << 8
+        s32 = rng.integers(-(1 << 30), 1 << 30, (2, n, ch)).astype(np.int32)
+        for s in (s24, s32):
+            f32 = (s.astype(np.float64) / 2147483648.0).astype(np.float32)          # read_wav(dtype=float32)
+            a = features.stft_logmag(torch.from_numpy(s).cuda(), n_fft, hop)
+            assert torch.equal(a, features.stft_logmag(torch.from_numpy(f32).cuda(), n_fft, hop))
+            want = features_ref.compute_features((s[0].astype(np.float64) / 2147483648.0).mean(1), n_fft, hop)
+            rel, db = feature_error(a[0].cpu().numpy(), want)
+            assert rel <= 2e-6 and db <= 2e-3
+    # a whole batch of clips through the strided entry (stems + mix in one launch), with augmentation gains
+    clips = rng.integers(-9000, 9000, (2, 3, 16000 * 2, 2), dtype=np.int16)
+    gain = torch.tensor([[0.7, 1.3, 1.0], [1.1, 0.9, 0.6]], device='cuda')
+    xa, ga = features.stft_logmag_clips(torch.from_numpy(clips).cuda(), n_fft, hop, gain=gain)
+    xb, gb = features.stft_logmag_clips(torch.from_numpy(clips.astype(np.float32) / np.float32(32768.0)).cuda(), n_fft, hop, gain=gain)
+    assert torch.equal(xa, xb) and torch.equal(ga, gb)
+    with pytest.raises(TypeError):
+        features.stft_logmag(torch.zeros((1, 4096, 2), dtype=torch.int64, device='cuda'))
+
+
+def test_read_wav_native_all_sample_formats(dam, tmp_path):
+    """dataset_utils.read_wav_native: partial reads without conversion; scaled by 2^-(bits-1) they are read_wav's values."""
+    import struct
+    from deep_audio_mixer_amd.data.dataset_utils import read_wav, read_wav_native
+    rng = np.random.default_rng(9)
+    n, ch, sr = 5000, 2, 22050
+
+    def write(path, tag, bits, payload):
+        fmt = struct.pack('<HHIIHH', tag, ch, sr, sr * ch * bits // 8, ch * bits // 8, bits)
+        with open(path, 'wb') as fh:
+            fh.write(b'RIFF' + struct.pack('<I', 36 + len(payload)) + b'WAVE' + b'fmt ' + struct.pack('<I', 16) + fmt +
+                     b'data' + struct.pack('<I', len(payload)) + payload)
+    v16 = rng.integers(-32768, 32767, (n, ch)).astype('<i2')
+    v24 = rng.integers(-(1 << 23), 1 << 23, (n, ch)).astype('<i4')
+    v32 = rng.integers(-(1 << 31), 1 << 31, (n, ch)).astype('<i4')
+    vf = rng.uniform(-1, 1, (n, ch)).astype('<f4')
+    b24 = v24.astype('<i4').view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+    for name, tag, bits, payload, kind, scale in (('a16', 1, 16, v16.tobytes(), np.int16, 32768.0), ('a24', 1, 24, b24, np.int32, 2147483648.0),
+                                                  ('a32', 1, 32, v32.tobytes(), np.int32, 2147483648.0), ('af', 3, 32, vf.tobytes(), np.float32, 1.0)):
+        p = str(tmp_path / (name + '.wav'))
+        write(p, tag, bits, payload)
+        a, rate = read_wav_native(p, 100, 4100)
+        assert a.dtype == kind and a.shape == (4000, ch) and rate == sr
+        np.testing.assert_array_equal(a.astype(np.float64) / scale, read_wav(p, 100, 4100)[0])
+        out = np.empty((4000, ch), dtype=kind)
+        assert read_wav_native(p, 100, 4100, out=out)[0] is out and np.array_equal(out, a)
