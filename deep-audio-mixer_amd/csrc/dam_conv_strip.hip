@@ -21,6 +21,7 @@
 //     border slots (zero padding) are zeroed once, only in-tensor pixels are ever written;
 //   * optional epilogue: per-channel BatchNorm partial statistics (n, mean, M2), one record per workgroup, merged by
 //     bn_stats_finalize -- removes the statistics pass over the conv output.
+#include <algorithm>
 #include "dam_common.h"
 #include "dam_conv_geo.h"
 #include "dam_bn_fin.h"
@@ -36,8 +37,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifdef DAM_STAMPS
 #define DAM_STAMP(slot)                                                                                   \
     do {                                                                                                  \
-        if (lane == 0 && (wave == 0 || wave == 8) && stamp_i < 30)                                        \
-            reinterpret_cast<unsigned long long*>(stats)[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 + (wave == 8)) * 32 + \
+        if (lane == 0 && (wave == 0 || wave == NCW) && stamp_i < 30)                                        \
+            reinterpret_cast<unsigned long long*>(stats)[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 + (wave == NCW)) * 32 + \
                                                          (stamp_i++)] = __builtin_amdgcn_s_memtime() | ((unsigned long long)(slot) << 56); \
     } while (0)
 #else
@@ -59,6 +60,7 @@ struct RowLoad {           // everything the row loader needs, by value (no clos
     const float* ximg;
     int H, W, C, s, c0, PWs, PWin, PWT, nchunks, RB, CHB, NR, ring_off, ppr, gpp;
     float inv_ppr, inv_gpp;
+    int m_ppr, m_gpp;      // floor(65536 / d) + 1: q / d == (q * m) >> 16 for q < 65536 / d (piece indices are a few hundred)
 };
 
 // Requests pieces first + part + nparts*u (u < STRIP_PU) of input rows [lo, hi] into registers: unconditional loads from
@@ -71,8 +73,9 @@ __device__ __forceinline__ void rows_issue(const RowLoad& r, int lo, int hi, int
         const int q = first + part + nparts * u;
         const bool used = q < total;
         const int qc = used ? q : total - 1;
-        const int row = fdiv(qc, r.ppr, r.inv_ppr), rem = qc - row * r.ppr;
-        const int cc = fdiv(rem, r.gpp, r.inv_gpp), gi = rem - cc * r.gpp;
+        // qc is wave-uniform (first, part, nparts are): integer magic division stays on the scalar ALU
+        const int row = (qc * r.m_ppr) >> 16, rem = qc - row * r.ppr;
+        const int cc = (rem * r.m_gpp) >> 16, gi = rem - cc * r.gpp;
         const int ih = lo + row;
         const int L = gi * 64 + lane, slot = L >> 2, quad = L & 3;
         int pw = slot;
@@ -118,8 +121,18 @@ __device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&
 // operand.  2: the launch carries the identity shortcut (residual operand, its ReLU mask as sign BYTES in `res_mask`) and the
 // sums are those of the BatchNorm UPSTREAM of the block input (its x is a third prefetched operand).  3: as 2, the upstream ReLU
 // mask comes as sign bytes as well (bwd.mask_bits: the upstream layer is relu(bn(x) + shortcut), a residual block's bn2)
-template <int MB, int NB, int NCH, bool T33, bool LW, int EPI>
-__global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
+// SO: 0 = the ping-pong form above (two compute groups alternate MFMA and write-out slots).  > 0 = SELF-OVERLAPPED form (T33
+// only, 8 waves): ONE compute group; every compute wave writes tile s-1 out, computes the geometry of tile s+1 and requests the
+// residual operands of tile s INSIDE its own MFMA stream of tile s.  The ablation ladder (profiles/r03_strip_ladder.txt) showed
+// why: a wave that streams MFMAs leaves the other waves of its SIMD no vector issue slots, so the ping-pong partner's write-out
+// ran AFTER the stream, not beside it (slot = 4.6 k cycles of MFMAs + 1.0-1.9 k of tail; the MFMA-only build still needed the
+// yield nops' 7 us); one wave's own stream, on the other hand, has 24 of every 32 MFMA cycles free for 4-cycle instructions
+// (MI355X_MICROARCH.md, vector-instruction issue cost).  The slot body is branch-free (one scheduling region per item, fillers
+// pinned between the MFMAs with sched_group_barrier), so what the write-out does is compile time: with EPI == 0, SO = 1 raw
+// store, 2 raw + BatchNorm partial statistics, 3 + bias, max(., floor) [folded inference convolution], 4 as 3 + residual,
+// 5 + residual * (mask > 0); with EPI >= 1 the sums epilogues as above (SO = 1).
+template <int MB, int NB, int NCH, bool T33, bool LW, int EPI, int SO>
+__global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
                                                          const float* __restrict__ res_mask, float* __restrict__ stats,
@@ -130,6 +143,8 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: role tests and loader arithmetic on the scalar ALU
     const int j = lane & 15, kq = lane >> 4;
     constexpr int MW = 16 * MB, TM = 4 * MW;
+    constexpr int NT = SO ? 512 : STRIP_THREADS;       // threads; compute waves; role index of the loader waves
+    constexpr int NCW = SO ? 4 : 8, LGRP = SO ? 1 : 2;
     const int img = blockIdx.z, nb0 = blockIdx.y * NB;
     const int HoWo = g.Ho * g.Wo;
     const int t_begin = blockIdx.x * sg.tpw;
@@ -177,83 +192,42 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     rl.ximg = ximg; rl.H = g.H; rl.W = g.W; rl.C = g.C; rl.s = g.s; rl.c0 = g.c0; rl.PWs = g.PWs; rl.PWin = g.PWin; rl.PWT = g.PWT;
     rl.nchunks = g.nchunks; rl.RB = RB; rl.CHB = CHB; rl.NR = sg.NR; rl.ring_off = sg.ring_off;
     rl.ppr = pieces_per_row; rl.gpp = groups_per_plane; rl.inv_ppr = inv_ppr; rl.inv_gpp = inv_gpp;
+    rl.m_ppr = (int)(65536.0f * inv_ppr) + 1; rl.m_gpp = (int)(65536.0f * inv_gpp) + 1;
 
     const int grp = wave >> 2, cw = wave & 3;          // role: 0/1 = compute group A/B, 2 = loader; wave index inside the role
     const int n_tiles = t_end - t_begin;
     const int n_slots = (n_tiles + 2) & ~1;            // tile s is computed in slot s and written out in slot s+1; padded to even
-    // Prologue: the rows of the first tile are requested first (every wave, into registers), the ring is zeroed and the
-    // weights copied while they are in flight, then the rows are written.
+    // ---- row loader: per-lane constants, register sets and the request / commit macros (used by the loader waves' slot loop
+    //      and, in the self-overlapped form, by every wave for the workgroup's first tile)
     int lo0, hi0;
     tile_rows(t_begin, lo0, hi0);
-    const int total0 = (hi0 - lo0 + 1) * pieces_per_row;
-    rows_issue(rl, lo0, hi0, 0, wave, STRIP_THREADS / 64, lane, lv, ldst, laff);
-    // zero the whole ring once: border slots stay zero for the lifetime of the workgroup
-    for (int e = tid * 16; e < CHB * g.nchunks; e += STRIP_THREADS * 16)
-        *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-    // thin layers: the packed weights of this N tile are small; keep them in LDS so that the MFMA loop never waits on L2
-    const int w_base = CHB * g.nchunks;       // always address LDS as smem + integer offset (a derived pointer variable
-                                              // degrades to flat_load, which is slower and also counts on vmcnt)
-    {   // canonical order [a*3+b][chunk][nb][lane] whatever the layer's tap numbering: operand offsets become immediates
-        const int n4 = 9 * g.nchunks * NB * 64;
-        for (int e = tid; e < n4; e += STRIP_THREADS) {
-            const int ln = e & 63, nb = (e >> 6) % NB, tc = (e >> 6) / NB;
-            const int ct = tc / g.nchunks, cc = tc - ct * g.nchunks, a = ct / 3, b = ct - a * 3;
-            if (a < g.nA && b < g.nB) {
-                const int tap = g.wt_base + a * g.wt_sa + b * g.wt_sb;
-                *reinterpret_cast<float4*>(smem + w_base + e * 16) =
-                    Wp[((size_t)(tap * g.nchunks + cc) * g.NBtot + nb0 + nb) * 64 + ln];
-            }
-        }
-    }
-    __syncthreads();
-    DAM_STAMP(2);
-    rows_commit<NCH>(smem, lv, ldst, laff, has_aff, scq, shq, relu_in);
-    for (int base = (STRIP_THREADS / 64) * STRIP_PU; base < total0; base += (STRIP_THREADS / 64) * STRIP_PU) {
-        rows_issue(rl, lo0, hi0, base, wave, STRIP_THREADS / 64, lane, lv, ldst, laff);
-        rows_commit<NCH>(smem, lv, ldst, laff, has_aff, scq, shq, relu_in);
-    }
-    __syncthreads();
-    DAM_STAMP(3);
-
-    if (grp == 2) {
-        // ================= loader waves: their own slot loop (same number of barriers as the compute waves) =============
-        // Slot s writes the rows tile s+1 adds (requested two slots earlier: HBM latency under this load is ~4 us, a full
-        // slot) and requests those of tile s+3.  Two register sets alternate; tile k uses set k & 1.
-        //
-        // A wave that streams MFMAs owns the SIMD's vector issue port (tools/mfma_valu_mix.hip: a co-resident wave's VALU
-        // instructions make no progress at all until the MFMA stream pauses, whatever s_setprio says), so every VALU
-        // instruction of a loader is paid for in MFMA time.  The loader therefore works in whole (row, chunk) planes:
-        // everything that depends on the plane is wave-uniform and lives on the scalar ALU, everything that depends on the
-        // lane (column pattern of piece gi: byte offset inside a row, which lanes are real columns) is computed once, and
-        // a piece costs no VALU instruction at all: buffer_load with scalar base + per-lane offset, ds_write with the
-        // piece's column mask in EXEC and an immediate offset.
-        constexpr int KP = NCH == 1 ? 1 : (LW ? 2 : 3);           // planes per loader wave per tile
-        constexpr int GPP = NCH == 1 ? (LW ? 14 : 9) : (LW ? 7 : 5);   // 1 KB pieces per plane (host: groups_per_plane <= GPP)
-        int loffb[GPP];
-        unsigned long long cmask[GPP];
+    constexpr int KP = NCH == 1 ? 1 : (LW ? 2 : 3);           // planes per loader wave per tile
+    constexpr int GPP = NCH == 1 ? (LW ? 14 : 9) : (LW ? 7 : 5);   // 1 KB pieces per plane (host: groups_per_plane <= GPP)
+    int loffb[GPP];
+    unsigned long long cmask[GPP];
 #pragma unroll
-        for (int gi = 0; gi < GPP; ++gi) {
-            const int L = gi * 64 + lane, slot = L >> 2, quad = L & 3;
-            int pw = slot;
-            if (g.s != 1) pw = slot < g.PWs ? 2 * slot : 2 * (slot - g.PWs) + 1;
-            const int iw = pw + g.c0;
-            const bool ok = gi < groups_per_plane && slot < g.PWT && pw < g.PWin && iw >= 0 && iw < g.W;
-            const int iwc = iw < 0 ? 0 : (iw >= g.W ? g.W - 1 : iw);
-            loffb[gi] = (iwc * g.C + quad * 4) * 4;
-            cmask[gi] = __ballot(ok);
-        }
-        // buffer addressing: scalar resource (this image) + scalar plane offset + per-lane column offset, no VALU
-        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, g.H * g.W * g.C * 4, 0x00020000);
-        const int lane16 = lane * 16;
-        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
-        v4f lvA[KP][GPP], lvB[KP][GPP];
-        int dstA[KP], dstB[KP];                          // scalar: ring byte offset of the plane | 1 << 30 if the row is
-        int ccA[KP], ccB[KP];                            // outside the tensor (zeros are written), -1 = nothing to write; chunk
+    for (int gi = 0; gi < GPP; ++gi) {
+        const int L = gi * 64 + lane, slot = L >> 2, quad = L & 3;
+        int pw = slot;
+        if (g.s != 1) pw = slot < g.PWs ? 2 * slot : 2 * (slot - g.PWs) + 1;
+        const int iw = pw + g.c0;
+        const bool ok = gi < groups_per_plane && slot < g.PWT && pw < g.PWin && iw >= 0 && iw < g.W;
+        const int iwc = iw < 0 ? 0 : (iw >= g.W ? g.W - 1 : iw);
+        loffb[gi] = (iwc * g.C + quad * 4) * 4;
+        cmask[gi] = __ballot(ok);
+    }
+    // buffer addressing: scalar resource (this image) + scalar plane offset + per-lane column offset, no VALU
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, g.H * g.W * g.C * 4, 0x00020000);
+    const int lane16 = lane * 16;
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    v4f lvA[KP][GPP], lvB[KP][GPP];
+    int dstA[KP], dstB[KP];                          // scalar: ring byte offset of the plane | 1 << 30 if the row is
+    int ccA[KP], ccB[KP];                            // outside the tensor (zeros are written), -1 = nothing to write; chunk
 #pragma unroll
-        for (int k = 0; k < KP; ++k) { dstA[k] = -1; dstB[k] = -1; ccA[k] = 0; ccB[k] = 0; }
-        const int chs = NCH == 1 ? 0 : 1;
-        int loaded_hi;
-        { int lo; tile_rows(t_begin, lo, loaded_hi); }
+    for (int k = 0; k < KP; ++k) { dstA[k] = -1; dstB[k] = -1; ccA[k] = 0; ccB[k] = 0; }
+    const int chs = NCH == 1 ? 0 : 1;
+    int loaded_hi;
+    { int lo; tile_rows(t_begin, lo, loaded_hi); }
 #define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_)                                                                                \
     do {                                                                                                                   \
         int first_ = 0, planes_ = 0;                                                                                       \
@@ -278,9 +252,10 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #define DAM_STRIP_WRITE(ADDR_, DATA_, GI_)                                                                                 \
     asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
                  : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024) : "memory")
-#define DAM_STRIP_COMMIT(LV_, DST_, CC_)                                                                                   \
+#define DAM_STRIP_COMMIT(LV_, DST_, CC_) DAM_STRIP_COMMIT_N(KP, LV_, DST_, CC_)
+#define DAM_STRIP_COMMIT_N(KPX_, LV_, DST_, CC_)                                                                           \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
+        _Pragma("unroll") for (int k = 0; k < (KPX_); ++k) {                                                                   \
             if (DST_[k] >= 0) {                                                                                            \
                 const int va_ = lane16 + (DST_[k] & 0x3fffffff);                                                           \
                 if (!(DST_[k] >> 30)) {                                                                                    \
@@ -305,6 +280,121 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 #undef DAM_STRIP_REQUEST
 #define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_) do { } while (0)
 #endif
+    // SO prologue: the rows of the workgroup's FIRST tile as whole planes too, spread over all NT / 64 waves (plane = wave + k * NT/64)
+    constexpr int KP0 = NCH == 1 ? 1 : 2;
+#define DAM_STRIP_REQUEST0(LV_, DST_, CC_)                                                                                 \
+    do {                                                                                                                   \
+        const int planes_ = (hi0 - lo0 + 1) << chs;                                                                        \
+        _Pragma("unroll") for (int k = 0; k < KP0; ++k) {                                                                  \
+            const int pl_ = wave + (NT / 64) * k;                                                                          \
+            const bool used_ = pl_ < planes_;                                                                              \
+            const int cc_ = pl_ & (NCH - 1), ih_ = lo0 + (pl_ >> chs);                                                     \
+            const bool rowok_ = used_ && ih_ >= 0 && ih_ < g.H;                                                            \
+            const int soff_ = ((rowok_ ? ih_ : 0) * g.W * g.C + (used_ ? cc_ : 0) * 16) * 4;                               \
+            _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                             \
+                LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[gi], soff_, 0));   \
+            DST_[k] = used_ ? ((cc_ * CHB + ((ih_ + sg.ring_off) & (sg.NR - 1)) * RB) | (rowok_ ? 0 : 1 << 30)) : -1;     \
+            CC_[k] = cc_;                                                                                                  \
+        }                                                                                                                  \
+    } while (0)
+
+    // Prologue: the rows of the first tile are requested first (every wave, into registers), the ring is zeroed and the
+    // weights copied while they are in flight, then the rows are written.
+    const int total0 = (hi0 - lo0 + 1) * pieces_per_row;
+    // thin layers: the packed weights of this N tile are small; keep them in LDS so that the MFMA loop never waits on L2
+    const int w_base = CHB * g.nchunks;       // always address LDS as smem + integer offset (a derived pointer variable
+                                              // degrades to flat_load, which is slower and also counts on vmcnt)
+    // canonical order [a*3+b][chunk][nb][lane] whatever the layer's tap numbering: operand offsets become immediates.
+    // All of a thread's weight loads are requested FIRST (clamped addresses, no load inside a conditional), then the rows of
+    // the first tile, then the ring is zeroed while both are in flight: one memory latency for the prologue, not three.
+    constexpr int WPT = (9 * NCH * NB * 64 + NT - 1) / NT;
+    const int n4 = 9 * g.nchunks * NB * 64;
+    float4 wreg[WPT];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int e = tid + u * NT, ec = e < n4 ? e : n4 - 1;
+        const int ln = ec & 63, nb = (ec >> 6) % NB, tc = (ec >> 6) / NB;
+        const int ct = tc / g.nchunks, cc = tc - ct * g.nchunks, a = ct / 3, b = ct - a * 3;
+        const bool tap_ok = a < g.nA && b < g.nB;
+        const int tap = tap_ok ? g.wt_base + a * g.wt_sa + b * g.wt_sb : g.wt_base;
+        wreg[u] = Wp[((size_t)(tap * g.nchunks + cc) * g.NBtot + nb0 + nb) * 64 + ln];
+        if (!tap_ok) wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    DAM_STAMP(9);
+    v4f lv0[SO ? KP0 : 1][SO ? GPP : 1];
+    int dst0[KP0], cc0[KP0];
+    if constexpr (SO != 0) {
+        // rows of the first tile: whole planes over all waves (the per-piece path above costs 3.4-5 k cycles of address
+        // arithmetic per wave).  The loader waves request tiles 1 and 2 at the top of their slot loop, as before: issuing those
+        // requests here too (measured: first barrier wait 3.4 k -> 0.4 k cycles) gave wrong rows on the first launches of a
+        // kernel in tools/strip_so_debug.py -- not understood, not kept; with the loader constants computed up here the wait
+        // is 1.3 k anyway
+        DAM_STRIP_REQUEST0(lv0, dst0, cc0);
+    } else {
+        rows_issue(rl, lo0, hi0, 0, wave, NT / 64, lane, lv, ldst, laff);
+    }
+    DAM_STAMP(10);
+    // zero the whole ring once: border slots stay zero for the lifetime of the workgroup
+    for (int e = tid * 16; e < CHB * g.nchunks; e += NT * 16)
+        *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    DAM_STAMP(11);
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int e = tid + u * NT;
+        if (e < n4) *reinterpret_cast<float4*>(smem + w_base + e * 16) = wreg[u];
+    }
+    DAM_STAMP(12);
+    __syncthreads();
+    DAM_STAMP(2);
+    if constexpr (SO != 0) {
+        DAM_STRIP_COMMIT_N(KP0, lv0, dst0, cc0);
+    } else {
+        rows_commit<NCH>(smem, lv, ldst, laff, has_aff, scq, shq, relu_in);
+        for (int base = (NT / 64) * STRIP_PU; base < total0; base += (NT / 64) * STRIP_PU) {
+            rows_issue(rl, lo0, hi0, base, wave, NT / 64, lane, lv, ldst, laff);
+            rows_commit<NCH>(smem, lv, ldst, laff, has_aff, scq, shq, relu_in);
+        }
+    }
+    // SO: per-tile geometry tables.  A compute wave's scalar pixel decode (magic division, ring-row masks, multiplies: ~90
+    // dependent scalar instructions per tile) sits in its own in-order stream in front of its MFMAs -- measured 800 of a 6.0 k
+    // cycle slot.  The loader wave paired with compute wave cw does that arithmetic instead, all (pixel block, field) pairs at
+    // once in its lanes (~25 vector instructions per tile), and leaves 8 ints per pixel block in LDS: {scalar part of the output
+    // offset, lanes-on-this-row threshold, three operand row bases for lanes on the block's first output row, three for lanes
+    // wrapped to the next}; the compute wave reads them as two broadcast ds_read_b128.  Double-buffered by tile parity.
+    const int tab_base = CHB * g.nchunks + 9 * g.nchunks * NB * 1024;
+#define SO_TABLE(T_)                                                                                                      \
+    do {                                                                                                                  \
+        if (lane < 8 * MB) {                                                                                              \
+            const int mbt_ = lane >> 3, f_ = lane & 7;                                                                    \
+            const int pm_ = (t_begin + (T_)) * TM + (wave & 3) * MW + mbt_ * 16;                                          \
+            const int oh_ = (int)__umulhi((unsigned)pm_, sg.wo_magic), ow_ = pm_ - oh_ * g.Wo;                            \
+            const bool k1_ = f_ >= 5;                                                                                     \
+            const int a_ = k1_ ? f_ - 5 : f_ - 2;                                                                         \
+            const int rr_ = oh_ * g.s + sg.ring_off + g.off_h + a_ * g.step_h + (k1_ ? g.s : 0);                          \
+            const int kv_ = (rr_ & (sg.NR - 1)) * RB + (ow_ + g.off_w - g.c0 - (k1_ ? g.Wo : 0)) * 64;                    \
+            const int so_ = oh_ * (g.os * g.OWt * g.N * 4) + ow_ * (g.os * g.N * 4);                                      \
+            const int val_ = f_ == 0 ? so_ : (f_ == 1 ? g.Wo - ow_ : kv_);                                                \
+            *reinterpret_cast<int*>(smem + tab_base + ((((wave & 3) * 2 + ((T_) & 1)) * MB * 8 + lane) << 2)) = val_;     \
+        }                                                                                                                 \
+    } while (0)
+    if constexpr (SO != 0) {
+        if (grp == LGRP) { SO_TABLE(0); SO_TABLE(1); }
+    }
+    __syncthreads();
+    DAM_STAMP(3);
+
+    if (grp == LGRP) {
+        // ================= loader waves: their own slot loop (same number of barriers as the compute waves) =============
+        // Slot s writes the rows tile s+1 adds (requested two slots earlier: HBM latency under this load is ~4 us, a full
+        // slot) and requests those of tile s+3.  Two register sets alternate; tile k uses set k & 1.
+        //
+        // A wave that streams MFMAs owns the SIMD's vector issue port (tools/mfma_valu_mix.hip: a co-resident wave's VALU
+        // instructions make no progress at all until the MFMA stream pauses, whatever s_setprio says), so every VALU
+        // instruction of a loader is paid for in MFMA time.  The loader therefore works in whole (row, chunk) planes:
+        // everything that depends on the plane is wave-uniform and lives on the scalar ALU, everything that depends on the
+        // lane (column pattern of piece gi: byte offset inside a row, which lanes are real columns) is computed once, and
+        // a piece costs no VALU instruction at all: buffer_load with scalar base + per-lane offset, ds_write with the
+        // piece's column mask in EXEC and an immediate offset.
         DAM_STRIP_REQUEST(1, lvB, dstB, ccB);
         DAM_STRIP_REQUEST(2, lvA, dstA, ccA);
         // slots come in pairs (n_slots is even) so that no load sits inside a conditional: the compiler then knows that the
@@ -312,16 +402,20 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         for (int s = 0; s < n_slots; s += 2) {
             DAM_STRIP_COMMIT(lvB, dstB, ccB);       // tile s+1
             DAM_STRIP_REQUEST(s + 3, lvB, dstB, ccB);
+            if constexpr (SO != 0) SO_TABLE(s + 2);  // read by the compute waves in slot s+1
             DAM_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             DAM_STRIP_COMMIT(lvA, dstA, ccA);       // tile s+2
             DAM_STRIP_REQUEST(s + 4, lvA, dstA, ccA);
+            if constexpr (SO != 0) SO_TABLE(s + 3);
             DAM_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 #undef DAM_STRIP_REQUEST
+#undef DAM_STRIP_REQUEST0
 #undef DAM_STRIP_WRITE
 #undef DAM_STRIP_COMMIT
+#undef DAM_STRIP_COMMIT_N
     }
 
     // BatchNorm partial statistics of this wave's outputs: shifted sums per lane (channels 4*kq..+3 of block nb), kept as
@@ -415,7 +509,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
     int mskb_pf[EPI >= 2 ? MB : 1][EPI >= 2 ? NB : 1], upb_pf[EPI == 3 ? MB : 1][EPI == 3 ? NB : 1];
     static_assert(EPI < 2 || RES_PF, "the residual + sums epilogue is built on the prefetch path");
 
-    for (int s = 0; grp < 2 && s < n_slots; ++s) {
+    for (int s = 0; SO == 0 && grp < 2 && s < n_slots; ++s) {
         if (false) {
         } else if (grp == (s & 1)) {
             // ---------------- MFMA slot of this group: tile s ----------------
@@ -603,6 +697,9 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                             }
                         }
                         if (relu_out) v = __builtin_elementwise_max(v, (v4f){0.f, 0.f, 0.f, 0.f});
+#ifdef DAM_DIAG_NO_STORE     // timing experiments only: the write-out's VALU work without its stores
+                        if (g.B == 12345)
+#endif
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), yrsrc, voff + nb * 64, 0, 0);
                         if constexpr (EPI >= 2) {       // v is the gradient reaching relu(bn(x) [+ ..]) of the block input: its two sums
                             const v4f xq = x_pf[mb][nb];
@@ -621,7 +718,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                             st_s2[nb][0] = __builtin_elementwise_fma(dz.xy, xh.xy, st_s2[nb][0]);
                             st_s2[nb][1] = __builtin_elementwise_fma(dz.zw, xh.zw, st_s2[nb][1]);
                         }
-#ifndef DAM_STAMPS
+#if !defined(DAM_STAMPS) && !defined(DAM_DIAG_NO_STATS)
                         if (stats && !epi_bwd) {
                             if (!st_have) { st_nk[nb][0] = -v.xy; st_nk[nb][1] = -v.zw; }
                             const v2f d0 = v.xy + st_nk[nb][0], d1 = v.zw + st_nk[nb][1];
@@ -636,9 +733,11 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                 st_have = true;
             }
             }
+#ifndef DAM_DIAG_NO_GEOM
             if constexpr (T33) {
                 if (s + 1 < n_tiles) DAM_STRIP_GEOM(s + 1);        // this group's next MFMA slot
             }
+#endif
             DAM_STAMP(6);
         }
         // slot boundary: the loaders' rows are in LDS (their ds_writes waited on the loads), the MFMA group's LDS reads
@@ -647,6 +746,267 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         DAM_STAMP(7);
     }
 
+    // =========================== self-overlapped compute waves (SO != 0; see the template comment) ===========================
+    if constexpr (SO != 0) {
+        static_assert(T33, "the self-overlapped form is built on the compile-time 3x3 item grid");
+        if (grp == 0) {
+            constexpr bool ST = EPI == 0 && SO == 2, BIAS = EPI == 0 && (SO == 3 || SO == 4), RADD = EPI == 0 && SO == 4,
+                           RMSK = EPI == 0 && SO == 5, NEED_R = EPI != 0 || RADD || RMSK;
+            constexpr int NI = 9 * NCH;
+#ifdef DAM_DIAG_SO_FROZEN          // timing experiments only: the fillers see tile 1 in every slot -- their scalar pixel decode
+            constexpr bool SO_FROZEN = true;      // becomes loop invariant (results are wrong)
+#else
+            constexpr bool SO_FROZEN = false;
+#endif
+#ifdef DAM_DIAG_SO_NO_STATS_UNIT   // timing experiments only: no statistics arithmetic in the write-out units
+            constexpr bool SO_NOSTU = true;
+#else
+            constexpr bool SO_NOSTU = false;
+#endif
+#ifdef DAM_DIAG_SO_NOFILL          // timing experiments only: the bare MFMA + operand-read stream (results are wrong)
+            constexpr bool SO_NOFILL = true;
+#else
+            constexpr bool SO_NOFILL = false;
+#endif
+            static_assert(NI >= 2 * MB + 1, "one filler per item: MB write-out units, MB geometry units, the operand prefetch");
+            v4f accX[2][MB][NB];            // [parity of the tile]: produced in one slot, written out inside the next
+            int voffX[2][MB];               // lane part of the output byte offset of pixel block mb (row wrap folded in)
+            int baseX[2][3][MB];            // LDS operand row bases
+            v4f rpf[NEED_R ? MB : 1][NEED_R ? NB : 1], mpf[RMSK ? MB : 1][RMSK ? NB : 1], xpf[EPI >= 2 ? MB : 1][EPI >= 2 ? NB : 1];
+            int mbpf[EPI >= 2 ? MB : 1][EPI >= 2 ? NB : 1], ubpf[EPI == 3 ? MB : 1][EPI == 3 ? NB : 1];
+            const float floor_out = relu_out ? 0.f : -3.0e38f;
+            const int lane_oD = lane_o + oD;
+            float4 wa[2][NB], xv[2][MB];
+
+            // geometry of pixel block MBI_ of tile T_ (parity P_) from the loader's table: SO_TABREAD requests the 8 ints (two
+            // broadcast reads, placed a few items ahead of their use), SO_GEOM turns them into per-lane offsets: one compare and
+            // eight select / add instructions, no scalar arithmetic
+            v4i tq[MB][2];
+#define SO_TABREAD(PAR_, MBI_)                                                                                            \
+    do {                                                                                                                  \
+        const int ta_ = tab_base + ((cw * 2 + (PAR_)) * MB + (MBI_)) * 32;                                                \
+        tq[MBI_][0] = *reinterpret_cast<const v4i*>(smem + ta_);                                                          \
+        tq[MBI_][1] = *reinterpret_cast<const v4i*>(smem + ta_ + 16);                                                     \
+    } while (0)
+#define SO_GEOM(P_, MBI_)                                                                                                 \
+    do {                                                                                                                  \
+        const v4i qa_ = tq[MBI_][0], qb_ = tq[MBI_][1];                                                                   \
+        const bool nx_ = j >= qa_.y;                                                                                      \
+        voffX[P_][MBI_] = (nx_ ? lane_oD : lane_o) + qa_.x;                                                               \
+        baseX[P_][0][MBI_] = lane_x + (nx_ ? qb_.y : qa_.z);                                                              \
+        baseX[P_][1][MBI_] = lane_x + (nx_ ? qb_.z : qa_.w);                                                              \
+        baseX[P_][2][MBI_] = lane_x + (nx_ ? qb_.w : qb_.x);                                                              \
+    } while (0)
+#define SO_LOAD(P_, I_, BUF_)                                                                                             \
+    do {                                                                                                                  \
+        constexpr int a_ = (I_) / (3 * NCH), b_ = ((I_) / NCH) % 3, cc_ = (I_) % NCH;                                     \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                 \
+            wa[BUF_][nb] = *reinterpret_cast<const float4*>(smem + w_lane + ((((a_ * 3 + b_) * NCH + cc_) * NB + nb) * 1024)); \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                 \
+            xv[BUF_][mb] = *reinterpret_cast<const float4*>(smem + (cc_ ? baseX[P_][a_][mb] + CHB : baseX[P_][a_][mb]) + b_ * 64); \
+    } while (0)
+#ifdef DAM_DIAG_NO_MFMA        // timing experiments only (results are wrong)
+#define SO_MFMA(P_, I_, BUF_) do { if ((I_) == 0) { _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) accX[P_][mb][nb] = __builtin_bit_cast(v4f, wa[BUF_][nb]) + __builtin_bit_cast(v4f, xv[BUF_][mb]); } } while (0)
+#else
+#define SO_MFMA(P_, I_, BUF_)                                                                                             \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                     \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                             \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                         \
+                    accX[P_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(                                              \
+                        reinterpret_cast<const float*>(&wa[BUF_][nb])[r], reinterpret_cast<const float*>(&xv[BUF_][mb])[r], \
+                        ((I_) == 0 && r == 0) ? (v4f){0.f, 0.f, 0.f, 0.f} : accX[P_][mb][nb], 0, 0, 0);                   \
+    } while (0)
+#endif
+            // operands of the write-out of tile T_ (residual / mask / the BatchNorm's x), requested a slot ahead
+#define SO_PREFETCH(P_)                                                                                                   \
+    do {                                                                                                                  \
+        if constexpr (NEED_R) {                                                                                           \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                           \
+                const int vo_ = voffX[P_][mb];                                                                            \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {   /* pixels past the image fail the range check: 0 */  \
+                    rpf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vo_ + nb * 64, 0, 0)); \
+                    if constexpr (RMSK)                                                                                   \
+                        mpf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, vo_ + nb * 64, 0, 0)); \
+                    if constexpr (EPI >= 2) {                                                                             \
+                        mbpf[mb][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(bbrsrc, (vo_ >> 4) + nb * 4, 0, 0);       \
+                        xpf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(x2rsrc, vo_ + nb * 64, 0, 0)); \
+                    }                                                                                                     \
+                    if constexpr (EPI == 3)                                                                               \
+                        ubpf[mb][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(ubrsrc, (vo_ >> 4) + nb * 4, 0, 0);       \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
+            // write-out of pixel block MBI_ of tile T_ (parity Q_).  PRED_: per-lane validity (the image's last tile only)
+#define SO_UNIT(Q_, T_, MBI_, PRED_)                                                                                      \
+    do {                                                                                                                  \
+        /* the WHOLE byte offset is a vector register, soffset = 0.  (With a register in the store's soffset field the */     \
+        /* compiler assumes the 128-bit data may be overwritten at once and places no wait state; on gfx950 the next VALU */  \
+        /* write to those registers then reached the store: stale components in single lanes.) */                            \
+        const int vo_ = voffX[Q_][MBI_];                                                                                  \
+        if (!(PRED_) || j < HoWo - ((t_begin + (T_)) * TM + cw * MW + (MBI_) * 16)) {                                     \
+            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                           \
+                v4f v = accX[Q_][MBI_][nb];                                                                               \
+                if constexpr (BIAS) {                                                                                     \
+                    v += bias4[nb];                                                                                       \
+                    if constexpr (RADD) v += rpf[MBI_][nb];                                                               \
+                    v.x = fmaxf(v.x, floor_out); v.y = fmaxf(v.y, floor_out); v.z = fmaxf(v.z, floor_out); v.w = fmaxf(v.w, floor_out); \
+                }                                                                                                         \
+                if constexpr (RMSK) {                                                                                     \
+                    const v4f rv = rpf[MBI_][nb], mv = mpf[MBI_][nb];                                                     \
+                    v.x += mv.x > 0.f ? rv.x : 0.f; v.y += mv.y > 0.f ? rv.y : 0.f;                                       \
+                    v.z += mv.z > 0.f ? rv.z : 0.f; v.w += mv.w > 0.f ? rv.w : 0.f;                                       \
+                }                                                                                                         \
+                if constexpr (EPI >= 2) {       /* identity shortcut: + res where the block output was positive */       \
+                    const v4f rv = rpf[MBI_][nb];                                                                         \
+                    const int b8 = mbpf[MBI_][nb];                                                                        \
+                    v.x += (b8 & 1) ? rv.x : 0.f; v.y += (b8 & 2) ? rv.y : 0.f;                                           \
+                    v.z += (b8 & 4) ? rv.z : 0.f; v.w += (b8 & 8) ? rv.w : 0.f;                                           \
+                }                                                                                                         \
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), yrsrc, vo_ + nb * 64, 0, 0);           \
+                if constexpr (EPI != 0) {       /* v reaches relu(bn(x) [+ ..]): the BatchNorm's two backward sums */     \
+                    const v4f xq = EPI == 1 ? rpf[MBI_][nb] : xpf[MBI_][nb];                                              \
+                    const v4f xh = __builtin_elementwise_fma(xq, bw_k1[nb], bw_k2[nb]);                                   \
+                    v4f dz;                                                                                               \
+                    if constexpr (EPI == 3) {                                                                             \
+                        const int ub = ubpf[MBI_][nb];                                                                    \
+                        dz.x = (ub & 1) ? v.x : 0.f; dz.y = (ub & 2) ? v.y : 0.f;                                         \
+                        dz.z = (ub & 4) ? v.z : 0.f; dz.w = (ub & 8) ? v.w : 0.f;                                         \
+                    } else {                                                                                              \
+                        const v4f m = __builtin_elementwise_fma(xq, bw_ms[nb], bw_mh[nb]);                                \
+                        dz.x = m.x > 0.f ? v.x : 0.f; dz.y = m.y > 0.f ? v.y : 0.f;                                       \
+                        dz.z = m.z > 0.f ? v.z : 0.f; dz.w = m.w > 0.f ? v.w : 0.f;                                       \
+                    }                                                                                                     \
+                    st_s1[nb][0] += dz.xy; st_s1[nb][1] += dz.zw;                                                         \
+                    st_s2[nb][0] = __builtin_elementwise_fma(dz.xy, xh.xy, st_s2[nb][0]);                                 \
+                    st_s2[nb][1] = __builtin_elementwise_fma(dz.zw, xh.zw, st_s2[nb][1]);                                 \
+                }                                                                                                         \
+                if constexpr (ST && !SO_NOSTU) {                                                                          \
+                    const v2f d0 = v.xy + st_nk[nb][0], d1 = v.zw + st_nk[nb][1];                                         \
+                    st_s1[nb][0] += d0; st_s1[nb][1] += d1;                                                               \
+                    st_s2[nb][0] = __builtin_elementwise_fma(d0, d0, st_s2[nb][0]);                                       \
+                    st_s2[nb][1] = __builtin_elementwise_fma(d1, d1, st_s2[nb][1]);                                       \
+                }                                                                                                         \
+            }                                                                                                             \
+            if constexpr (ST) ++st_n;                                                                                     \
+        }                                                                                                                 \
+    } while (0)
+            // the filler of item I_ in the slot that computes tile S_ (parity P_): write-out units of tile S_-1 first, then the
+            // geometry of tile S_+1 (into the parity tile S_-1 is leaving), then the operand prefetch of tile S_
+#define SO_FILL(P_, S_, I_, WO_)                                                                                          \
+    do {                                                                                                                  \
+        /* the tile index through an opaque volatile copy: the scalar pixel decode below must stay in THIS item's region */  \
+        /* (free-floating, the instruction selector lines all of a slot's decodes up in front of the slot's first MFMA) */ \
+        int sa_ = SO_FROZEN ? 1 : (S_);                                                                                   \
+        if constexpr (!SO_FROZEN) asm volatile("" : "+s"(sa_));                                                           \
+        if constexpr (SO_NOFILL) { }                                                                                      \
+        else if constexpr ((I_) < MB) {                                                                                   \
+            if constexpr (WO_) SO_UNIT(1 - (P_), sa_ - 1, ((I_) < MB ? (I_) : 0), 0);                                     \
+            SO_TABREAD(1 - (P_), ((I_) < MB ? (I_) : 0));                      /* tile S_+1 */                            \
+        } else if constexpr ((I_) < 2 * MB) SO_GEOM(1 - (P_), ((I_) < 2 * MB && (I_) >= MB ? (I_) - MB : 0));             \
+        else if constexpr ((I_) == 2 * MB) SO_PREFETCH(P_);                                                               \
+    } while (0)
+            // one MFMA gap = 32 cycles of which the MFMA holds the issue port for 8: room for ~5 four-cycle instructions
+#ifndef DAM_SO_PAT_VALU
+#define DAM_SO_PAT_VALU 3
+#endif
+#ifndef DAM_SO_PAT_SALU
+#define DAM_SO_PAT_SALU 2
+#endif
+#ifdef DAM_SO_NOPATTERN
+#define SO_PATTERN() do { } while (0)
+#else
+#define SO_PATTERN()                                                                                                      \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4 * MB * NB; ++q_) {                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x002, DAM_SO_PAT_VALU, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x004, DAM_SO_PAT_SALU, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);                                                            \
+        }                                                                                                                 \
+    } while (0)
+#endif
+#define SO_ITEM(P_, S_, I_, WO_)                                                                                          \
+    do {                                                                                                                  \
+        if constexpr ((I_) + 1 < NI) SO_LOAD(P_, ((I_) + 1 < NI ? (I_) + 1 : 0), ((I_) + 1) & 1);                         \
+        SO_MFMA(P_, I_, (I_) & 1);                                                                                        \
+        if constexpr ((I_) != 0) SO_FILL(P_, S_, I_, WO_);                                                                \
+        SO_PATTERN();                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+    } while (0)
+#define SO_SLOT(P_, S_, WO_)                                                                                              \
+    do {                                                                                                                  \
+        /* the first operands are requested, then the first filler runs while they travel (its pixel block's last MFMA */  \
+        /* was issued >= 3 MFMAs = 96 cycles before the barrier: past the 40-cycle MFMA -> VALU distance) */               \
+        SO_LOAD(P_, 0, 0);                                                                                                \
+        SO_FILL(P_, S_, 0, WO_);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        SO_ITEM(P_, S_, 0, WO_); SO_ITEM(P_, S_, 1, WO_); SO_ITEM(P_, S_, 2, WO_); SO_ITEM(P_, S_, 3, WO_); SO_ITEM(P_, S_, 4, WO_); \
+        SO_ITEM(P_, S_, 5, WO_); SO_ITEM(P_, S_, 6, WO_); SO_ITEM(P_, S_, 7, WO_); SO_ITEM(P_, S_, 8, WO_);               \
+        if constexpr (NCH == 2) {                                                                                         \
+            SO_ITEM(P_, S_, 9, WO_); SO_ITEM(P_, S_, 10, WO_); SO_ITEM(P_, S_, 11, WO_); SO_ITEM(P_, S_, 12, WO_); SO_ITEM(P_, S_, 13, WO_); \
+            SO_ITEM(P_, S_, 14, WO_); SO_ITEM(P_, S_, 15, WO_); SO_ITEM(P_, S_, 16, WO_); SO_ITEM(P_, S_, 17, WO_);       \
+        }                                                                                                                 \
+        DAM_STAMP(5);                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                   \
+        DAM_STAMP(7);                                                                                                     \
+    } while (0)
+            // the last tile of the strip: nothing left to overlap with; per-lane validity (the image's last tile may be ragged)
+#define SO_LAST(Q_, T_)                                                                                                   \
+    do {                                                                                                                  \
+        /* The accumulators were written by the MFMAs just in front of the barrier.  A VALU read of an MFMA result has no */ \
+        /* hardware interlock; the compiler pads such pairs with s_nop, but not across the barrier's inline asm (seen on */   \
+        /* hardware: the last-written register of a block stale in one lane column).  16x16x4 f32: 40 cycles to the result. */ \
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                                                \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                               \
+            if (HoWo - ((t_begin + (T_)) * TM + cw * MW + mb * 16) > 0) SO_UNIT(Q_, T_, mb, 1);                           \
+        }                                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                   \
+        DAM_STAMP(7);                                                                                                     \
+    } while (0)
+
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) { SO_TABREAD(0, mb); SO_GEOM(0, mb); }
+            // slot 0: tile 0 alone (the fillers: geometry of tile 1, operands of tile 0's write-out)
+            SO_SLOT(0, 0, 0);
+            if constexpr (ST) {       // statistics shift = the wave's first outputs (any value near the data would do)
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA result -> VALU read behind inline asm: see SO_LAST
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) { st_nk[nb][0] = -accX[0][0][nb].xy; st_nk[nb][1] = -accX[0][0][nb].zw; }
+            }
+            int s = 1;
+            for (; s + 1 < n_tiles; s += 2) {
+                SO_SLOT(1, s, 1);
+                SO_SLOT(0, s + 1, 1);
+            }
+            if (s < n_tiles) {
+                SO_SLOT(1, s, 1);
+                ++s;
+            }
+            // s == n_tiles: the last tile's write-out, then the padding slots of the loaders' paired loop
+            if ((n_tiles - 1) & 1) SO_LAST(1, n_tiles - 1);
+            else SO_LAST(0, n_tiles - 1);
+            for (++s; s < n_slots; ++s) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                DAM_STAMP(7);
+            }
+#undef SO_GEOM
+#undef SO_TABREAD
+#undef SO_LOAD
+#undef SO_MFMA
+#undef SO_PREFETCH
+#undef SO_UNIT
+#undef SO_FILL
+#undef SO_PATTERN
+#undef SO_ITEM
+#undef SO_SLOT
+#undef SO_LAST
+        }
+    }
+
+#undef SO_TABLE
 #undef DAM_STRIP_GEOM
 #ifdef DAM_STAMPS
     DAM_STAMP(8);
@@ -663,7 +1023,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                 float a = st_s1[nb][r >> 1][r & 1], b = st_s2[nb][r >> 1][r & 1];
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-                if (j == 0 && wave < 8) {
+                if (j == 0 && wave < NCW) {
                     float* o = sm + ((wave * NB * 16) + nb * 16 + kq * 4 + r) * 2;
                     o[0] = a; o[1] = b;
                 }
@@ -671,7 +1031,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         __syncthreads();
         if (tid < NB * 16) {
             float a = 0.f, b = 0.f;
-            for (int w = 0; w < 8; ++w) { a += sm[((w * NB * 16) + tid) * 2]; b += sm[((w * NB * 16) + tid) * 2 + 1]; }
+            for (int w = 0; w < NCW; ++w) { a += sm[((w * NB * 16) + tid) * 2]; b += sm[((w * NB * 16) + tid) * 2 + 1]; }
             const int ch = nb0 * 16 + tid;
             if (ch < g.N) {
                 const size_t part = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
@@ -681,7 +1041,11 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         }
         return;
     }
+#ifdef DAM_DIAG_SO_NO_STATS_EPI    // timing experiments only: no merge of the statistics at the end
+    if (stats && g.B == 12345) {
+#else
     if (stats) {
+#endif
         // (n, mean, M2) per lane -> Chan merge over the 16 pixel lanes, then over the 4 compute waves through LDS
         float* sm = reinterpret_cast<float*>(smem);        // ring no longer needed: [8 compute waves][NB*16 ch][3]
 #pragma unroll
@@ -704,7 +1068,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
                     }
                     n = nn;
                 }
-                if (j == 0 && wave < 8) {
+                if (j == 0 && wave < NCW) {
                     float* o = sm + ((wave * NB * 16) + nb * 16 + kq * 4 + r) * 3;
                     o[0] = n; o[1] = mean; o[2] = m2;
                 }
@@ -712,7 +1076,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
         __syncthreads();
         if (tid < NB * 16) {
             float n = 0.f, mean = 0.f, m2 = 0.f;
-            for (int w = 0; w < 8; ++w) {
+            for (int w = 0; w < NCW; ++w) {
                 const float* o = sm + ((w * NB * 16) + tid) * 3;
                 const float nb_ = o[0];
                 if (nb_ == 0.f) continue;
@@ -732,7 +1096,7 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
             unsigned* ticket = reinterpret_cast<unsigned*>(smem + 16 * 1024);
             const unsigned total = gridDim.x * gridDim.z;       // statistics launches have gridDim.y == 1 (host check)
             if (block_arrive_last(fin.counter, total, ticket))
-                bn_stats_finalize_block(stats, (int)total, g.N, fin, reinterpret_cast<double*>(smem + 32 * 1024), tid, STRIP_THREADS);
+                bn_stats_finalize_block(stats, (int)total, g.N, fin, reinterpret_cast<double*>(smem + 32 * 1024), tid, NT);
         }
     }
 }
@@ -740,21 +1104,21 @@ __global__ __launch_bounds__(STRIP_THREADS) void conv_strip_kernel(const ConvGeo
 }  // namespace
 
 // Returns DAM_OK if launched, DAM_ERR_UNSUPPORTED if the layer does not fit this variant (caller falls back).
-template <int MB, int NB, int NCH, bool T33, bool LW = false, int EPI = 0>
+template <int MB, int NB, int NCH, bool T33, bool LW = false, int EPI = 0, int SO = 0>
 static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, const float* Wp, const float* bias, float* Y,
                         const float* res, const float* res_mask, float* stats, const float* in_scale, const float* in_shift,
                         const BnFinArgs& fin, const BnBwdEpi& bwd, hipStream_t st) {
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH, T33, LW, EPI>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH, T33, LW, EPI, SO>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return DAM_ERR_LAUNCH;
             raised = true;
         }
     }
     dim3 grid((unsigned)sg.strips, (unsigned)cdiv(g.N / 16, NB), (unsigned)g.B);
-    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33, LW, EPI>), grid, dim3(STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
+    hipLaunchKernelGGL((conv_strip_kernel<MB, NB, NCH, T33, LW, EPI, SO>), grid, dim3(SO ? 512 : STRIP_THREADS), lds, st, g, sg, X, reinterpret_cast<const float4*>(Wp), bias,
                        Y, res, res_mask, stats, in_scale, in_shift, fin, bwd);
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -829,6 +1193,36 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     // 3x3 taps, stride 1, unit column step: compile-time item grid with immediate operand offsets
     const bool t33 = g.nA == 3 && g.nB == 3 && g.s == 1 && g.step_w == 1;
 #define DAM_STRIP_ARGS g, sg, lds, X, Wp, bias, Y, (bwd.x && !res ? bwd.x : res), (bwd.x && res ? reinterpret_cast<const float*>(bwd.res_bits) : res_mask), stats, in_scale, in_shift, fin, bwd, st
+    // Self-overlapped form (template comment of the kernel) for the 3x3 / stride-1 shapes of the 16- and 32-channel stages at
+    // ordinary row widths; DAM_STRIP_PINGPONG=1 keeps the ping-pong form (A/B switch).  The write-out variant is compile time.
+    static const bool pingpong = getenv("DAM_STRIP_PINGPONG") != nullptr;
+    const int rows_out_so = std::min(g.Ho, (64 * MB + g.Wo - 2) / g.Wo + 1), rows_tile_so = (rows_out_so - 1) * g.s + sg.RH;
+    if (t33 && !wide && !pingpong && !fin.counter && rows_tile_so * g.nchunks <= 8 * (g.nchunks == 1 ? 1 : 2) &&
+        ((g.nchunks == 1 && MB == 4 && NB == 1) || (g.nchunks == 2 && MB == 2 && NB == 2))) {
+        const bool c16 = g.nchunks == 1;
+        lds += 1024;                        // geometry tables: 4 compute waves x 2 tile parities x 8 ints x <= 4 pixel blocks
+#define DAM_SO_CASE(E_, S_)                                                                                              \
+    return c16 ? launch_strip<4, 1, 1, true, false, E_, S_>(DAM_STRIP_ARGS) : launch_strip<2, 2, 2, true, false, E_, S_>(DAM_STRIP_ARGS)
+        if (bwd.x && res) {
+            if (c16) {
+                if (bwd.mask_bits) return launch_strip<4, 1, 1, true, false, 3, 1>(DAM_STRIP_ARGS);
+                return launch_strip<4, 1, 1, true, false, 2, 1>(DAM_STRIP_ARGS);
+            }
+        } else if (bwd.x) {
+            DAM_SO_CASE(1, 1);
+        } else if (stats) {
+            if (!bias && !res && !g.relu_out) DAM_SO_CASE(0, 2);
+        } else if (res && res_mask) {
+            if (!bias && !g.relu_out) DAM_SO_CASE(0, 5);
+        } else if (res) {
+            DAM_SO_CASE(0, 4);
+        } else if (bias || g.relu_out) {
+            DAM_SO_CASE(0, 3);
+        } else {
+            DAM_SO_CASE(0, 1);
+        }
+#undef DAM_SO_CASE
+    }
     if (bwd.x && res) { // residual + upstream sums: the 16-channel full-resolution data gradient only (stem <- first block)
         if (!t33 || g.nchunks != 1 || MB != 4 || NB != 1) return DAM_ERR_UNSUPPORTED;
         if (bwd.mask_bits)

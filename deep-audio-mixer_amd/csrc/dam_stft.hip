@@ -101,6 +101,11 @@ __device__ __forceinline__ int64_t reflect(int64_t p, int64_t n) {
 __device__ __forceinline__ float to_db(float m, float amin, float floor_db) {
     return m <= amin ? floor_db : 20.0f * log10f(m);
 }
+// The same from the POWER p = |X|^2: 20*log10(sqrt(p)) = 10*log10(p) -- no square root (a correctly rounded sqrtf is a dozen
+// instructions, seventeen times per lane and frame); v_log_f32 is good to 1 ulp of log2(p), i.e. < 1e-5 dB over the whole range.
+__device__ __forceinline__ float power_to_db(float p, float amin2, float floor_db) {
+    return p <= amin2 ? floor_db : 3.01029995663981195f * __log2f(p);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The 2048-point kernel, built for OCCUPANCY.  (Round 1's version kept every lane-invariant table and a prefetched frame in
@@ -141,8 +146,18 @@ __global__ __launch_bounds__(TF2* WAVE, 4) void stft2048_kernel(
     __syncthreads();
     float* P = planes + wave * PLANE;
     const int n_main = n_inner - n_tail;
+    const float amin2 = amin * amin;
 
-    for (int tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
+    // Tile walk, XCD-aware: workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2.  Each XCD takes
+    // one CONTIGUOUS eighth of the tiles and its workgroups walk it side by side, so the tiles that share an output cache line
+    // (four consecutive 8-frame tiles of a track: 32-byte pieces of one 128-byte line) and the PCM of overlapping frames meet in
+    // ONE L2 at about the same time: partial lines are merged there instead of going out as masked writes, the second read of
+    // every sample hits.  (With the plain stride walk, neighbours sat on different XCDs: WRITE_SIZE 1.7 x the output bytes.)
+    const int n_xcd = (gridDim.x & 7) == 0 ? 8 : 1;
+    const int per_xcd = (n_tiles + n_xcd - 1) / n_xcd, wg_per_xcd = gridDim.x / n_xcd;
+    const int tile_lo = (blockIdx.x % n_xcd) * per_xcd;
+    for (int v = blockIdx.x / n_xcd; v < per_xcd && tile_lo + v < n_tiles; v += wg_per_xcd) {
+        const int tile_i = tile_lo + v;
         const int64_t track = tile_i / tiles_per_track;
         const int t0 = (tile_i - (int)track * tiles_per_track) * TF2;
         const int t = t0 + wave;
@@ -309,12 +324,12 @@ __global__ __launch_bounds__(TF2* WAVE, 4) void stft2048_kernel(
 #ifdef DAM_STFT_DIAG_NO_LOG
                     db[4 * i + d] = xa.x * xa.x + xa.y * xa.y;
 #else
-                    db[4 * i + d] = to_db(sqrtf(xa.x * xa.x + xa.y * xa.y), amin, floor_db);
+                    db[4 * i + d] = power_to_db(xa.x * xa.x + xa.y * xa.y, amin2, floor_db);
 #endif
                     mx = fmaxf(mx, fabsf(db[4 * i + d]));
                     if (i == 0 && d == 0 && lane == 0) {          // k = 0: Nyquist bin X[1024] = e - tt
                         const float2 xb = csub(e, tt);
-                        nyq = to_db(sqrtf(xb.x * xb.x + xb.y * xb.y), amin, floor_db);
+                        nyq = power_to_db(xb.x * xb.x + xb.y * xb.y, amin2, floor_db);
                     }
                 }
             }
@@ -468,7 +483,10 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     if (n_tail < 0 || n_tail >= n_inner || (n_tail > 0 && !out_tail)) return DAM_ERR_BAD_ARG;
     if (n_samples <= n_fft / 2) return DAM_ERR_BAD_ARG;   // reflect padding needs N > n_fft/2 (torch.stft raises too)
     if (channels != 1 && channels != 2) return DAM_ERR_UNSUPPORTED;
-    const bool fast = n_fft == NFFT && !(hop & 1);         // the tuned 2048-point kernel; else any power of two 64..4096
+    bool fast = n_fft == NFFT && !(hop & 1);               // the tuned 2048-point kernel; else any power of two 64..4096
+    // 16-bit mono tracks at an odd sample stride start on odd 2-byte boundaries: the tuned kernel's 4-byte point loads would
+    // be misaligned, the generic kernel reads sample by sample
+    if ((pcm_dtype & ~DAM_PCM_INDIRECT) == DAM_PCM_S16 && channels == 1 && ((outer_stride | inner_stride) & 1)) fast = false;
     if (!fast && (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))) return DAM_ERR_UNSUPPORTED;
     const int indirect = (pcm_dtype & DAM_PCM_INDIRECT) ? 1 : 0;
     pcm_dtype &= ~DAM_PCM_INDIRECT;
@@ -491,7 +509,6 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     if (integer && planar) return DAM_ERR_UNSUPPORTED;     // integer PCM is what a WAV decoder hands over: interleaved
     // the 2-byte kernels fetch a complex point (two frames) with one aligned 4- / 8-byte load
     if (pcm_dtype == DAM_PCM_S16 && !indirect && ((uintptr_t)pcm & 3)) return DAM_ERR_BAD_ARG;
-    if (pcm_dtype == DAM_PCM_S16 && ((outer_stride | inner_stride) & 1) && channels == 1) return DAM_ERR_UNSUPPORTED;
     const int n_frames = (int)(1 + n_samples / hop);
     dim3 grid, block;
     hipStream_t s = (hipStream_t)stream;

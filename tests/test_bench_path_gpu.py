@@ -97,7 +97,7 @@ def test_c3_captured_step_matches_oracle(dam_lib):
         gmax = max(p.grad.norm().item() for p in ref.parameters())
         worst = 0.0
         for name, p in ref.named_parameters():
-            e = (named[name] - p.grad).norm().item() / (p.grad.norm().item() + 1e-5 * gmax)
+            e = (named[name].reshape(p.grad.shape) - p.grad).norm().item() / (p.grad.norm().item() + 1e-5 * gmax)
             worst = max(worst, e)
             assert e <= 2e-2, (k, name, e)
         # Adam(+L2) of the captured step == torch.optim.Adam's rule applied to the step's OWN gradient, in float64

@@ -423,7 +423,7 @@ def test_trainer_captured_step_equals_eager_loop(dam, tmp_path, monkeypatch, cap
         tr._train_batch = lambda b, real=real, acc=per_batch: acc.append(real(b).item()) or torch.tensor(acc[-1])
         tl, vl = tr.fit(batches, val, 0, 2)
         assert (tr.graph_steps, tr.eager_steps) == ((10, 4) if graph else (0, 14))     # 2 eager + 4 graph + ragged, then 6 + ragged
-        runs.append((per_batch, tl, vl, model.state_dict()['bn1.running_mean'].clone()))
+        runs.append((list(per_batch), tl, vl, model.state_dict()['bn1.running_mean'].clone()))
         if graph:      # a generator loader (what MultitrackAudioDataset.iter_batches is), epoch mean over the batches seen
             t2, _ = tr.fit((b for b in batches[:3]), val, 2, 1)
             assert len(t2) == 1 and np.isfinite(t2[0])

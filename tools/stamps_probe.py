@@ -20,7 +20,7 @@ y, parts = ops.conv2d_fwd(x, wp, C, 3, 3, 1, 1, 1, bn_partial=buf)
 torch.cuda.synchronize()
 st = buf.view(torch.int64).cpu().numpy().astype(np.uint64).reshape(-1, 2, 32)
 nwg = int((st[:, 0, 0] != 0).sum())
-names = {1: 'start', 2: 'zeroed', 3: 'first-load', 4: 'issued', 5: 'mfma', 6: 'bar+commit', 7: 'epi+bar', 8: 'end'}
+names = {1: 'start', 2: 'sync1', 3: 'sync2', 4: 'issued', 5: 'mfma', 6: 'bar+commit', 7: 'epi+bar', 8: 'end', 9: 'w-req', 10: 'rows-req', 11: 'zeroed', 12: 'w-lds'}
 t0all = None
 for wg in (0, min(200, nwg - 1)):
     for role, rn in ((0, 'wave0'), (1, 'wave8 (loader)')):
