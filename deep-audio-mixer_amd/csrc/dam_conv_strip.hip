@@ -324,12 +324,14 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     v4f lv0[SO ? KP0 : 1][SO ? GPP : 1];
     int dst0[KP0], cc0[KP0];
     if constexpr (SO != 0) {
-        // rows of the first tile: whole planes over all waves (the per-piece path above costs 3.4-5 k cycles of address
-        // arithmetic per wave).  The loader waves request tiles 1 and 2 at the top of their slot loop, as before: issuing those
-        // requests here too (measured: first barrier wait 3.4 k -> 0.4 k cycles) gave wrong rows on the first launches of a
-        // kernel in tools/strip_so_debug.py -- not understood, not kept; with the loader constants computed up here the wait
-        // is 1.3 k anyway
+        // rows of the first tile: whole planes over all waves (the per-piece path of the ping-pong form costs 3.4-5 k cycles
+        // of address arithmetic per wave); the loader waves' requests for tiles 1 and 2 follow at once, so that tile 1's rows
+        // are there long before slot 0 ends (requested after the prologue, the first barrier waited 1.3-3.4 k cycles for them)
         DAM_STRIP_REQUEST0(lv0, dst0, cc0);
+        if (grp == LGRP) {
+            DAM_STRIP_REQUEST(1, lvB, dstB, ccB);
+            DAM_STRIP_REQUEST(2, lvA, dstA, ccA);
+        }
     } else {
         rows_issue(rl, lo0, hi0, 0, wave, NT / 64, lane, lv, ldst, laff);
     }
@@ -360,7 +362,10 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     // cycle slot.  The loader wave paired with compute wave cw does that arithmetic instead, all (pixel block, field) pairs at
     // once in its lanes (~25 vector instructions per tile), and leaves 8 ints per pixel block in LDS: {scalar part of the output
     // offset, lanes-on-this-row threshold, three operand row bases for lanes on the block's first output row, three for lanes
-    // wrapped to the next}; the compute wave reads them as two broadcast ds_read_b128.  Double-buffered by tile parity.
+    // wrapped to the next}; the compute wave reads them as two broadcast ds_read_b128.  FOUR buffers (tile & 3): the loaders
+    // write tile s+2 during slot s while the compute waves read tile s+1 -- and tile 0 BEFORE slot 0, beside the loaders' first
+    // write (with two buffers that write landed in tile 0's entries: a late compute wave, e.g. on a cold instruction cache,
+    // read tile 2's geometry for its first tile -- single pixel blocks wrong on first launches).
     const int tab_base = CHB * g.nchunks + 9 * g.nchunks * NB * 1024;
 #define SO_TABLE(T_)                                                                                                      \
     do {                                                                                                                  \
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             const int kv_ = (rr_ & (sg.NR - 1)) * RB + (ow_ + g.off_w - g.c0 - (k1_ ? g.Wo : 0)) * 64;                    \
             const int so_ = oh_ * (g.os * g.OWt * g.N * 4) + ow_ * (g.os * g.N * 4);                                      \
             const int val_ = f_ == 0 ? so_ : (f_ == 1 ? g.Wo - ow_ : kv_);                                                \
-            *reinterpret_cast<int*>(smem + tab_base + ((((wave & 3) * 2 + ((T_) & 1)) * MB * 8 + lane) << 2)) = val_;     \
+            *reinterpret_cast<int*>(smem + tab_base + ((((wave & 3) * 4 + ((T_) & 3)) * MB * 8 + lane) << 2)) = val_;     \
         }                                                                                                                 \
     } while (0)
     if constexpr (SO != 0) {
@@ -395,8 +400,10 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
         // lane (column pattern of piece gi: byte offset inside a row, which lanes are real columns) is computed once, and
         // a piece costs no VALU instruction at all: buffer_load with scalar base + per-lane offset, ds_write with the
         // piece's column mask in EXEC and an immediate offset.
-        DAM_STRIP_REQUEST(1, lvB, dstB, ccB);
-        DAM_STRIP_REQUEST(2, lvA, dstA, ccA);
+        if constexpr (SO == 0) {
+            DAM_STRIP_REQUEST(1, lvB, dstB, ccB);
+            DAM_STRIP_REQUEST(2, lvA, dstA, ccA);
+        }
         // slots come in pairs (n_slots is even) so that no load sits inside a conditional: the compiler then knows that the
         // set being written is the older of the two in flight and waits with vmcnt(pieces of the other set), not vmcnt(0)
         for (int s = 0; s < n_slots; s += 2) {
@@ -782,9 +789,9 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             // broadcast reads, placed a few items ahead of their use), SO_GEOM turns them into per-lane offsets: one compare and
             // eight select / add instructions, no scalar arithmetic
             v4i tq[MB][2];
-#define SO_TABREAD(PAR_, MBI_)                                                                                            \
+#define SO_TABREAD(T_, MBI_)                                                                                              \
     do {                                                                                                                  \
-        const int ta_ = tab_base + ((cw * 2 + (PAR_)) * MB + (MBI_)) * 32;                                                \
+        const int ta_ = tab_base + ((cw * 4 + ((T_) & 3)) * MB + (MBI_)) * 32;                                            \
         tq[MBI_][0] = *reinterpret_cast<const v4i*>(smem + ta_);                                                          \
         tq[MBI_][1] = *reinterpret_cast<const v4i*>(smem + ta_ + 16);                                                     \
     } while (0)
@@ -903,7 +910,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
         if constexpr (SO_NOFILL) { }                                                                                      \
         else if constexpr ((I_) < MB) {                                                                                   \
             if constexpr (WO_) SO_UNIT(1 - (P_), sa_ - 1, ((I_) < MB ? (I_) : 0), 0);                                     \
-            SO_TABREAD(1 - (P_), ((I_) < MB ? (I_) : 0));                      /* tile S_+1 */                            \
+            SO_TABREAD(sa_ + 1, ((I_) < MB ? (I_) : 0));                                                                  \
         } else if constexpr ((I_) < 2 * MB) SO_GEOM(1 - (P_), ((I_) < 2 * MB && (I_) >= MB ? (I_) - MB : 0));             \
         else if constexpr ((I_) == 2 * MB) SO_PREFETCH(P_);                                                               \
     } while (0)
@@ -1200,7 +1207,7 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     if (t33 && !wide && !pingpong && !fin.counter && rows_tile_so * g.nchunks <= 8 * (g.nchunks == 1 ? 1 : 2) &&
         ((g.nchunks == 1 && MB == 4 && NB == 1) || (g.nchunks == 2 && MB == 2 && NB == 2))) {
         const bool c16 = g.nchunks == 1;
-        lds += 1024;                        // geometry tables: 4 compute waves x 2 tile parities x 8 ints x <= 4 pixel blocks
+        lds += 2048;                        // geometry tables: 4 compute waves x 4 buffers x 8 ints x <= 4 pixel blocks
 #define DAM_SO_CASE(E_, S_)                                                                                              \
     return c16 ? launch_strip<4, 1, 1, true, false, E_, S_>(DAM_STRIP_ARGS) : launch_strip<2, 2, 2, true, false, E_, S_>(DAM_STRIP_ARGS)
         if (bwd.x && res) {

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 import torch
 
+from _inputs import feature_error
 from oracle import features_ref, models_ref
 
 pytestmark = pytest.mark.gpu
@@ -63,6 +64,7 @@ def test_c3_captured_step_matches_oracle(dam_lib):
 
     torch.set_num_threads(16)
     ref = models_ref.RefResNet18(n_stems=S, input_shape=(bench.N_FFT // 2 + 1, 1 + n // hop)).double().train()
+    ref32 = models_ref.RefResNet18(n_stems=S, input_shape=(bench.N_FFT // 2 + 1, 1 + n // hop)).train()
     host = clips.cpu().numpy()
     rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
     losses = []
@@ -82,24 +84,51 @@ def test_c3_captured_step_matches_oracle(dam_lib):
         items = [features_ref.clip_features(host[k * Bsz + b], bench.N_FFT, hop, np.float32) for b in range(Bsz)]
         x = torch.from_numpy(np.stack([i[0] for i in items])).double()
         gt = torch.from_numpy(np.stack([i[1] for i in items])).double()
-        ref.zero_grad()
-        masked_r, gains_r = ref(x)
-        loss_r = torch.nn.functional.mse_loss(masked_r, gt)
-        loss_r.backward()
+        with torch.no_grad():
+            masked_r, gains_r = ref(x)
+            loss_r = torch.nn.functional.mse_loss(masked_r, gt)
+        rs = {k_: v.clone() for k_, v in ref.state_dict().items()}      # running statistics after the numpy-feature forward
         e_loss = abs(loss - loss_r.item()) / loss_r.item()
         e_gain = rel(gains, torch.cat(gains_r, 1).detach().numpy())
         e_mask = rel(masked, masked_r.detach()[:, ::41, ::7].numpy())
         # north_star: gains within 1e-4 relative of the reference CPU path; loss 2e-4 (as the golden model tests)
         assert e_loss <= 2e-4 and e_gain <= 1e-4 and e_mask <= 1e-4, (k, e_loss, e_gain, e_mask)
-        # gradients of the whole model (float32 ReLU decision flips move a tensor by 2-5e-3: whole-model tolerance as in
-        # test_models_gpu.py; the per-block tests hold 2e-5)
+        # The front-end itself against the numpy oracle, in the measure the feature tests use (linear magnitude relative to the
+        # frame peak; dB only away from spectral nulls, where rounding is amplified without bound)
+        x_dev = step.x.cpu().numpy()
+        for b_, s_ in ((0, 0), (3, 5), (7, 7)):
+            rel_lin, db = feature_error(x_dev[b_, s_], items[b_][0][s_])
+            assert rel_lin <= 2e-6 and db <= 2e-3, (k, b_, s_, rel_lin, db)
+        # Gradients of the whole model: the oracle is fed the DEVICE's features here.  Five of the 8.5 M bins of a batch sit in
+        # spectral nulls and differ by up to 0.1 dB between any two float32 STFTs; loss and gains do not care (checked above
+        # from the numpy features) but an ill-conditioned gradient can: in the state after the first update the reference's own
+        # conv_head1 gradient moves by 11 % (its bias gradient by a factor 2.3) when those five bins change
+        # (tools/head_grad_debug.py) -- with the same features the device agrees to 7e-6 on every head tensor.  In the trunk
+        # every float32 ReLU decision flip moves the tensors upstream of it by 2-5e-3, in ANY float32 implementation, so the
+        # yardstick is the CPU oracle in float32 from the same state and features: a tensor passes at 3 x that oracle's own
+        # distance to float64 (floor 2e-2).  The tight, deterministic gradient checks are per block
+        # (tests/test_blocks_gpu.py: 2e-5 on every gradient of every block at these shapes)
+        xd, gtd = step.x.cpu(), step.gt.cpu()
+        ref.load_state_dict(before)
+        ref.zero_grad()
+        masked_d, _ = ref(xd.double())
+        torch.nn.functional.mse_loss(masked_d, gtd.double()).backward()
+        ref32.load_state_dict({k_: (v.float() if v.is_floating_point() else v) for k_, v in before.items()})
+        ref32.zero_grad()
+        masked32, _ = ref32(xd)
+        torch.nn.functional.mse_loss(masked32, gtd).backward()
+        g32 = {n_: p_.grad.double() for n_, p_ in ref32.named_parameters()}
         named = _ref_named_flat(model, g_dev, opt)
         gmax = max(p.grad.norm().item() for p in ref.parameters())
-        worst = 0.0
+        errs = []
         for name, p in ref.named_parameters():
-            e = (named[name].reshape(p.grad.shape) - p.grad).norm().item() / (p.grad.norm().item() + 1e-5 * gmax)
-            worst = max(worst, e)
-            assert e <= 2e-2, (k, name, e)
+            scale = p.grad.norm().item() + 1e-5 * gmax
+            e = (named[name].reshape(p.grad.shape) - p.grad).norm().item() / scale
+            e32 = (g32[name] - p.grad).norm().item() / scale
+            errs.append((e / max(3 * e32, 2e-2), name, e, e32))
+        errs.sort(reverse=True)
+        worst = max(e_[2] for e_ in errs)
+        assert errs[0][0] <= 1.0, (k, [(n_, 'hip %.2e' % a, 'cpu-f32 %.2e' % b) for _, n_, a, b in errs[:6]])
         # Adam(+L2) of the captured step == torch.optim.Adam's rule applied to the step's OWN gradient, in float64
         t = k + 1
         g = g_dev + wd * p0
@@ -110,7 +139,6 @@ def test_c3_captured_step_matches_oracle(dam_lib):
         assert (opt._exp_avg.double().cpu() - m1).abs().max().item() <= 1e-6 * m1.abs().max().item()
         assert (opt._exp_avg_sq.double().cpu() - v1).abs().max().item() <= 1e-6 * v1.abs().max().item()
         # BatchNorm running statistics: the oracle's forward updated its buffers from the same starting values
-        rs = ref.state_dict()
         for key in ('bn1.running_mean', 'bn1.running_var', 'layer1.1.bn2.running_var', 'layer3.0.bn2.running_mean',
                     'layer3.0.shortcut.1.running_var', 'layer6.1.bn2.running_var'):
             np.testing.assert_allclose(after[key].numpy(), rs[key].numpy(), rtol=2e-5, atol=1e-6, err_msg='%d %s' % (k, key))
