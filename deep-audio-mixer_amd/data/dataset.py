@@ -218,29 +218,37 @@ class MultitrackAudioDataset(data.Dataset):
         consumed = [torch.cuda.Event(), torch.cuda.Event()]
         copy_stream = torch.cuda.Stream(device=self._device)
 
-        def decode(pool, slot, group):
-            """Starts the reads of one batch into host[slot]; returns the futures."""
-            view = host[slot].numpy()
+        def stage(pool, slot, group):
+            """Starts the reads of one batch into host[slot] and, behind them, its upload into dev[slot] on the copy stream
+            (enqueued by a pool thread the moment the last read is done -- not when the consumer comes back for the batch:
+            the transfer then runs beside the consumer's work on the previous batch).  Returns the upload job's future."""
+            view, B = host[slot].numpy(), len(group)
 
             def one(job):
                 b, k, item = job
                 song_i, chunk_i = self._calculate_song_index(item)
                 self._read_chunk_into(view[b, k], self.songlist[song_i], self._tracklist[k], chunk_i * n, (chunk_i + 1) * n)
-            return [pool.submit(one, (b, k, item)) for b, item in enumerate(group) for k in range(K)]
+            reads = [pool.submit(one, (b, k, item)) for b, item in enumerate(group) for k in range(K)]
 
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            pending = decode(pool, 0, groups[0])
-            for j, group in enumerate(groups):
-                slot, B = j % 2, len(group)
-                for f in pending:
-                    f.result()                                         # this batch is in host[slot] (raises a reader's error)
-                with torch.cuda.stream(copy_stream):
+            def upload():
+                for f in reads:
+                    f.result()                                         # raises a reader's error in the consumer
+                with torch.cuda.device(self._device), torch.cuda.stream(copy_stream):
                     copy_stream.wait_event(consumed[slot])            # the launch that read dev[slot] two batches ago
                     dev[slot][:B].copy_(host[slot][:B], non_blocking=True)
                     uploaded[slot].record(copy_stream)
-                if j + 1 < len(groups):                                # the next batch is decoded in the background while
-                    staging._wait(uploaded[1 - slot])                  # this one travels and is consumed (host[1-slot] is
-                    pending = decode(pool, 1 - slot, groups[j + 1])    # free once its previous upload has left it)
+            return pool.submit(upload)                                 # FIFO pool: every read has a thread before this waits
+
+        with ThreadPoolExecutor(max_workers=max(2, workers)) as pool:
+            pending = stage(pool, 0, groups[0])
+            for j, group in enumerate(groups):
+                slot, B = j % 2, len(group)
+                pending.result()                                       # batch j is decoded and its upload is enqueued
+                if j + 1 < len(groups):
+                    # host[1 - slot] is free once ITS previous upload (batch j - 1) has left it: by now long done; a blocking
+                    # wait, not a poll (a polling main thread holds the GIL the reader threads need to start their reads)
+                    uploaded[1 - slot].synchronize()
+                    pending = stage(pool, 1 - slot, groups[j + 1])
                 cur = torch.cuda.current_stream(self._device)
                 cur.wait_event(uploaded[slot])
                 gain = None
