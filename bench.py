@@ -520,8 +520,9 @@ def _setup_single(device_index=0):
     return torch.device('cuda', device_index)
 
 
-def _synthetic_songs(cfg, n_songs, chunks_per_song, seed=1234):
-    """In-memory songs of SURVEY 8(d)'s synthetic clips: {song: {track: float32 [n, 2]}}, S stems + 'mix'."""
+def _synthetic_songs(cfg, n_songs, chunks_per_song, seed=1234, pcm16=False):
+    """In-memory songs of SURVEY 8(d)'s synthetic clips: {song: {track: float32 [n, 2]}}, S stems + 'mix'; pcm16: the same
+    signals quantised to 16-bit PCM (what MedleyDB / MUSDB18-HQ stems are), int16 [n, 2]."""
     import numpy as np
     S, n = cfg['n_stems'], cfg['sr'] * cfg['seconds']
     rng = np.random.default_rng(seed)
@@ -530,7 +531,10 @@ def _synthetic_songs(cfg, n_songs, chunks_per_song, seed=1234):
     songs = {}
     for j in range(n_songs):
         stems = [(0.1 * rng.standard_normal((chunks_per_song * n, CHANNELS))).astype(np.float32) for _ in range(S)]
-        songs['song%02d' % j] = dict(zip(tracklist, stems + [sum(gi * st for gi, st in zip(g, stems))]))
+        tracks = stems + [sum(gi * st for gi, st in zip(g, stems))]
+        if pcm16:
+            tracks = [np.clip(np.rint(t * 32768.0), -32768, 32767).astype(np.int16) for t in tracks]
+        songs['song%02d' % j] = dict(zip(tracklist, tracks))
     return songs, tracklist
 
 
@@ -547,8 +551,8 @@ def run_via_trainer(name, cfg, args):
     from deep_audio_mixer_amd.model_trainer import ModelTrainer
     from deep_audio_mixer_amd.optim import Adam
     S, B = cfg['n_stems'], cfg['batch']
-    n_songs, chunks = 6, 16                                      # 96 clips = 12 batches of 8 per epoch (0.9 GB of float32 PCM)
-    songs, tracklist = _synthetic_songs(cfg, n_songs, chunks)
+    n_songs, chunks = 8, 48                                      # 384 clips = 48 batches of 8 per epoch (1.8 GB of 16-bit PCM)
+    songs, tracklist = _synthetic_songs(cfg, n_songs, chunks, pcm16=not args.float_pcm)
     ds = MultitrackAudioDataset.from_arrays(songs, chunk_length=cfg['seconds'], sr=cfg['sr'], tracklist=tracklist, seed=1)
     train = ds.batch_loader(B, drop_last=True, workers=args.workers)
     val = ds.batch_loader(B, indices=list(range(B)), workers=args.workers)
@@ -588,8 +592,10 @@ def run_via_trainer(name, cfg, args):
         'metric': 'stem-spectrogram-frames/sec (train, via ModelTrainer.fit)', 'value': frames * steps / train_s,
         'unit': 'stem-spectrogram-frames/s', 'n_gpus': 1, 'steps': steps, 'ms_per_step': 1e3 * train_s / steps,
         'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic', 'diagnostic': True,
-        'config': {'workload': cfg['workload'] + ' -- through ModelTrainer.fit(Dataset.batch_loader(8)) from in-memory songs',
-                   'sync_per_step': True, 'decode_threads': args.workers, 'graph_steps': trainer.graph_steps,
+        'config': {'workload': cfg['workload'] + ' -- through ModelTrainer.fit(Dataset.batch_loader(8)) from in-memory songs (%s)' % ('float32' if args.float_pcm else '16-bit PCM'),
+                   'sync_per_step': 'every batch\'s loss is read on the host and logged, one batch late (ModelTrainer._run)',
+                   'decode_threads': args.workers, 'pcm': 'float32' if args.float_pcm else 'int16 (16-bit PCM)',
+                   'graph_steps': trainer.graph_steps,
                    'eager_steps': trainer.eager_steps, 'epochs_timed': n_epochs, 'batches_per_epoch': len(train),
                    'ms_per_step_incl_validation_and_checkpoint': 1e3 * fit_s / steps, 'final_train_loss': tl[-1]}}), flush=True)
 
@@ -750,6 +756,7 @@ def main():
     ap.add_argument('--ingest', action='store_true',
                     help='diagnostic line: frames/s of WAV files -> decode threads -> pinned -> H2D -> STFT (iter_batches)')
     ap.add_argument('--workers', type=int, default=8, help='--ingest / --via-trainer: decode threads')
+    ap.add_argument('--float-pcm', action='store_true', help='--via-trainer: float32 in-memory songs instead of 16-bit PCM')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')

@@ -181,9 +181,13 @@ class MultitrackAudioDataset(data.Dataset):
         """(numpy dtype, channels) of the page-locked staging buffers of iter_batches: the files' own sample type when every
         track of every song shares it (16-bit MedleyDB / MUSDB18-HQ stems travel as int16: half the PCIe bytes of float32
         and no conversion on the host), else float32."""
-        if self._arrays is not None:
-            a = np.asarray(self._arrays[self.songlist[0]][self._tracklist[0]])
-            return np.dtype(np.float32), (1 if a.ndim == 1 else a.shape[1])
+        if self._arrays is not None:      # in-memory songs: their own sample type when all share one the kernel reads
+            arrs = [np.asarray(self._arrays[song][t]) for song in self.songlist for t in self._tracklist]
+            kinds = {a.dtype for a in arrs}
+            kind = kinds.pop() if len(kinds) == 1 else None
+            a = arrs[0]
+            ok = kind in (np.dtype(np.int16), np.dtype(np.int32), np.dtype(np.float32))
+            return (kind if ok else np.dtype(np.float32)), (1 if a.ndim == 1 else a.shape[1])
         kinds, chans = set(), set()
         for song in self.songlist:
             for t in self._tracklist:
@@ -199,8 +203,8 @@ class MultitrackAudioDataset(data.Dataset):
         """Yields (train_features [B,S,1025,T], gt_features [B,1025,T]) float32 CUDA tensors for consecutive groups of
         `batch_size` items of `indices` (default: every item, in order) -- what ``DataLoader(self, batch_size)`` yields,
         with the reads of data/dataset.py:192-196 done by `workers` threads straight into page-locked memory (integer PCM
-        stays integer: staging_format), the decode of batch k+1 running in the background and its upload on a copy stream
-        while the consumer works on batch k (also while it waits in ``loss.item()``), and the augmentation gains
+        stays integer: staging_format), three staging slots -- batch k in use, k+1 on the copy stream, k+2 being decoded in
+        the background (also while the consumer waits in ``loss.item()``) -- and the augmentation gains
         (data/dataset.py:198-199) drawn on the device per (seed, item, read count, track)."""
         from concurrent.futures import ThreadPoolExecutor
         idx = list(range(len(self))) if indices is None else [int(i) for i in indices]
@@ -212,51 +216,94 @@ class MultitrackAudioDataset(data.Dataset):
         K, n = len(self._tracklist), self._chunk_length * self._sr
         kind, ch = self.staging_format()
         tdt = torch.from_numpy(np.empty(0, dtype=kind)).dtype
-        host = [torch.empty((batch_size, K, n, ch), dtype=tdt, pin_memory=True) for _ in range(2)]
-        dev = [torch.empty((batch_size, K, n, ch), dtype=tdt, device=self._device) for _ in range(2)]
-        uploaded = [torch.cuda.Event(), torch.cuda.Event()]
-        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        NS = 3            # staging slots: batch j in use, j + 1 travelling, j + 2 being decoded
+        # page-locking 3 x 38-76 MB costs milliseconds: the staging buffers are kept on the dataset and reused by the next pass
+        # (one epoch = one iter_batches call; a pass that is still running keeps its own set)
+        key = (batch_size, K, n, ch, tdt, str(self._device))
+        cache = getattr(self, '_staging_cache', None)
+        if cache is not None and cache[0] == key and not cache[3].locked():
+            host, dev, busy = cache[1], cache[2], cache[3]
+        else:
+            import threading as _th
+            host = [torch.empty((batch_size, K, n, ch), dtype=tdt, pin_memory=True) for _ in range(NS)]
+            dev = [torch.empty((batch_size, K, n, ch), dtype=tdt, device=self._device) for _ in range(NS)]
+            busy = _th.Lock()
+            self._staging_cache = (key, host, dev, busy)
+        busy.acquire()
+        uploaded = [torch.cuda.Event() for _ in range(NS)]
         copy_stream = torch.cuda.Stream(device=self._device)
 
-        def stage(pool, slot, group):
-            """Starts the reads of one batch into host[slot] and, behind them, its upload into dev[slot] on the copy stream
-            (enqueued by a pool thread the moment the last read is done -- not when the consumer comes back for the batch:
-            the transfer then runs beside the consumer's work on the previous batch).  Returns the upload job's future."""
-            view, B = host[slot].numpy(), len(group)
+        import queue
+        import threading
+        ready, free, stop = queue.Queue(), threading.Semaphore(NS), threading.Event()
 
-            def one(job):
-                b, k, item = job
-                song_i, chunk_i = self._calculate_song_index(item)
-                self._read_chunk_into(view[b, k], self.songlist[song_i], self._tracklist[k], chunk_i * n, (chunk_i + 1) * n)
-            reads = [pool.submit(one, (b, k, item)) for b, item in enumerate(group) for k in range(K)]
+        def feeder(pool):
+            """Producer thread: for batch j = 0, 1, ... take a free staging slot, read the batch into host[slot] (pool
+            threads), enqueue its upload on the copy stream the moment the last read is done, hand (slot, group) over.
+            None of this is on the consumer's critical path: it runs while the consumer's step executes / syncs."""
+            from collections import deque
+            started = deque()                 # batches whose reads are running: (slot, group, futures)
+            try:
+                j = 0
+                while j < len(groups) or started:
+                    # start the reads of as many batches as there are free slots (block for a slot only when idle)
+                    while j < len(groups) and free.acquire(blocking=not started):
+                        if stop.is_set():
+                            return
+                        slot, group = j % NS, groups[j]
+                        uploaded[slot].synchronize()                    # the slot's previous upload has left host[slot]
+                        view = host[slot].numpy()
 
-            def upload():
-                for f in reads:
-                    f.result()                                         # raises a reader's error in the consumer
-                with torch.cuda.device(self._device), torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(consumed[slot])            # the launch that read dev[slot] two batches ago
-                    dev[slot][:B].copy_(host[slot][:B], non_blocking=True)
-                    uploaded[slot].record(copy_stream)
-            return pool.submit(upload)                                 # FIFO pool: every read has a thread before this waits
+                        def one(job, view=view):
+                            b, k, item = job
+                            song_i, chunk_i = self._calculate_song_index(item)
+                            self._read_chunk_into(view[b, k], self.songlist[song_i], self._tracklist[k], chunk_i * n, (chunk_i + 1) * n)
+                        started.append((slot, group, [pool.submit(one, (b, k, item)) for b, item in enumerate(group) for k in range(K)]))
+                        j += 1
+                    slot, group, reads = started.popleft()
+                    for f in reads:
+                        f.result()                                      # raises a reader's error (re-raised in the consumer)
+                    B = len(group)
+                    # upload AND front-end launch on the copy stream, from this thread: the features of batch j + 1 are
+                    # computed while the consumer's step on batch j runs -- nothing of it is left on the consumer's
+                    # critical path (with a per-step loss.item() the device idles for every host call in between)
+                    with torch.cuda.device(self._device), torch.cuda.stream(copy_stream):
+                        dev[slot][:B].copy_(host[slot][:B], non_blocking=True)      # (stream order: after the launch that
+                        uploaded[slot].record(copy_stream)                          # read dev[slot] NS batches ago)
+                        gain = None
+                        if self._augment:
+                            gain = features.augment_gains(self._aug_seed, K, items=self._aug_keys(group), device=self._device)
+                        x, gt = features.stft_logmag_clips(dev[slot][:B], 2048, 1024, gain=gain, normalize=self._normalize)
+                        done = torch.cuda.Event()
+                        done.record(copy_stream)
+                    ready.put((x, gt, done))
+                ready.put(None)
+            except BaseException as e:       # noqa: B036 -- handed to the consumer, which re-raises it
+                ready.put(e)
 
-        with ThreadPoolExecutor(max_workers=max(2, workers)) as pool:
-            pending = stage(pool, 0, groups[0])
-            for j, group in enumerate(groups):
-                slot, B = j % 2, len(group)
-                pending.result()                                       # batch j is decoded and its upload is enqueued
-                if j + 1 < len(groups):
-                    # host[1 - slot] is free once ITS previous upload (batch j - 1) has left it: by now long done; a blocking
-                    # wait, not a poll (a polling main thread holds the GIL the reader threads need to start their reads)
-                    uploaded[1 - slot].synchronize()
-                    pending = stage(pool, 1 - slot, groups[j + 1])
-                cur = torch.cuda.current_stream(self._device)
-                cur.wait_event(uploaded[slot])
-                gain = None
-                if self._augment:
-                    gain = features.augment_gains(self._aug_seed, K, items=self._aug_keys(group), device=self._device)
-                x, gt = features.stft_logmag_clips(dev[slot][:B], 2048, 1024, gain=gain, normalize=self._normalize)
-                consumed[slot].record(cur)
-                yield x, gt
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            th = threading.Thread(target=feeder, args=(pool,), daemon=True)
+            th.start()
+            try:
+                while True:
+                    item = ready.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    x, gt, done = item
+                    cur = torch.cuda.current_stream(self._device)
+                    cur.wait_event(done)
+                    x.record_stream(cur)            # allocated on the copy stream, used on the consumer's
+                    gt.record_stream(cur)
+                    free.release()                  # the staging slot is free: its PCM has been turned into features
+                    yield x, gt
+            finally:
+                stop.set()
+                free.release()          # a feeder waiting for a slot sees `stop` and leaves
+                th.join()
+                torch.cuda.current_stream(self._device).wait_stream(copy_stream)
+                busy.release()
 
     def batch_loader(self, batch_size, indices=None, workers=8, drop_last=False):
         """iter_batches as a re-iterable loader with ``len()`` -- what ModelTrainer.fit / the notebooks' loops expect of a

@@ -8,7 +8,8 @@ What is different underneath:
   * with ``criterion = nn.MSELoss()`` (what every notebook passes) loss and gradient come from the model's fused
     ``forward_mse`` (one pass over the features); any other criterion is applied to ``masked`` as in the reference;
   * the training loop body (model_trainer.py:30-37: zero_grad, forward, loss, backward, step) becomes ONE hipGraph replay
-    once it has proven static: model, criterion and optimizer are this package's own (``forward_mse`` + ``optim.Adam``)
+    once it has proven static (and the per-batch ``loss.item()`` is read one batch late, see ``_run``): model, criterion
+    and optimizer are this package's own (``forward_mse`` + ``optim.Adam``)
     and the batch shape has repeated -- the first ``EAGER_BATCHES`` batches run the eager autograd sequence, the next one
     captures ``engine.TrainStep(feature_shape=...)`` (its warm-up step is rolled back, so no extra optimizer step is
     taken) and from then on a batch is a copy into the static inputs + a replay; batches of another shape (a ragged last
@@ -103,16 +104,47 @@ class ModelTrainer:
         return self.criterion(self.model(feats)[0], target)
 
     def _run(self, loader, train):
-        """Mean loss over the loader; one optimisation step per batch when ``train``."""
+        """Mean loss over the loader; one optimisation step per batch when ``train``.
+
+        The reference reads ``loss.item()`` after every batch (model_trainer.py:41,43) -- a device synchronisation per step,
+        during which nothing is enqueued.  Every batch's loss is still read and logged here, in order, but ONE BATCH LATE:
+        the value of batch j travels to page-locked memory behind an event and is picked up after batch j + 1 has been
+        enqueued, so the host's work for the next batch (loader, copies, launch) runs beside the device's work on this one.
+        Same numbers, same lines on stdout, same returned mean; the host never runs more than one batch ahead."""
         total, quiet = 0.0, not _rank0()
         n = len(loader) if hasattr(loader, '__len__') else None
+        on_gpu = torch.device(self.device).type == 'cuda'
+        if on_gpu and getattr(self, '_loss_host', None) is None:
+            self._loss_host = torch.zeros(2, dtype=torch.float32, pin_memory=True)
+            self._loss_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        pending = []                                    # [(step index, slot)]: losses on their way to the host
+
+        def flush():
+            nonlocal total
+            k, slot = pending.pop(0)
+            self._loss_ev[slot].synchronize()
+            value = float(self._loss_host[slot])
+            if train and k % _LOG_EVERY == 0 and not quiet:
+                print('[%d/%4d] loss: %.3f' % (k, n, value) if n is not None else '[%d/   ?] loss: %.3f' % (k, value))
+            total += value
+
         step = 0
         for step, batch in enumerate(loader, start=1):
             loss = self._train_batch(batch) if train else self._batch_loss(batch)
-            value = loss.item()               # the reference's per-batch host sync (model_trainer.py:41,43)
-            if train and step % _LOG_EVERY == 0 and not quiet:
-                print('[%d/%4d] loss: %.3f' % (step, n, value) if n is not None else '[%d/   ?] loss: %.3f' % (step, value))
-            total += value
+            if not on_gpu or not loss.is_cuda:
+                value = loss.item()
+                if train and step % _LOG_EVERY == 0 and not quiet:
+                    print('[%d/%4d] loss: %.3f' % (step, n, value) if n is not None else '[%d/   ?] loss: %.3f' % (step, value))
+                total += value
+                continue
+            slot = step & 1
+            self._loss_host[slot:slot + 1].copy_(loss.detach().reshape(1), non_blocking=True)
+            self._loss_ev[slot].record()
+            pending.append((step, slot))
+            if len(pending) > 1:
+                flush()
+        while pending:
+            flush()
         return total / (n if n is not None else step)
 
     def _train_epoch(self, train_loader):
