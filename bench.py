@@ -214,17 +214,17 @@ def roofline_object(name, cfg, device, t_frames):
         train = name != 'C5'
         t = k['step_mix_s'] if train else k['fwd_s']
         tf = k['flops_per_launch'] / t / 1e12
-        kern = ('conv_strip_kernel<4,1,1,true> (ResNet layer1 3x3 conv 16->16, %dx1025x%d px: ' % (cfg['batch'], t_frames) +
+        kern = ('conv_strip_kernel<4,1,1,true,false,EPI,SO> (ResNet layer1 3x3 conv 16->16, %dx1025x%d px: ' % (cfg['batch'], t_frames) +
                 ('its 9 launches per step: 5 forward with statistics, 4 data gradients with the BatchNorm-backward / residual / '
                  'upstream-sum epilogues)' if train else 'forward launches of the eval-mode chunk batch)'))
         # traffic: measured in a SEPARATE rocprofv3 --pmc run (bench.py cannot read PMC counters of its own launches);
         # the figure below was taken at batch 8 on the forward launch of this kernel at the commit named in traffic_source
         obj = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_MFMA / 1e12, 'unit': 'TFLOP/s', 'frac': tf * 1e12 / PEAK_F32_MFMA,
                'traffic': 140.0e6 if cfg['batch'] == 8 else None,
-               'traffic_source': 'profiles/r02_pmc_layer1_layer3_stft.csv (tools/collect_profiles.sh r02 at the commit that '
-                                 'added it: FETCH_SIZE 36,689 KB x 2 for the gfx950 halving of wide coalesced reads + WRITE_SIZE '
-                                 '66,625 KB = 140.0 MB, forward launch, batch 8, 1.03 x the 136.4 MB algorithmic bytes); a '
-                                 'constant from that separate PMC run, not re-measured by this run',
+               'traffic_source': 'profiles/r03_pmc_final.csv (tools/collect_profiles.sh r03: FETCH_SIZE 36,663 KB x 2 for the gfx950 '
+                                 'halving of wide coalesced reads + WRITE_SIZE 66,625 KB = 140.0 MB, forward launch of the '
+                                 'self-overlapped kernel, batch 8, 1.03 x the 136.4 MB algorithmic bytes); a constant from that '
+                                 'separate PMC run, not re-measured by this run',
                'kernel': kern, 'avg_launch_s': t, 'flops_per_launch': k['flops_per_launch'],
                'forward_only': {'avg_launch_s': k['fwd_s'], 'achieved': k['flops_per_launch'] / k['fwd_s'] / 1e12,
                                 'frac': k['flops_per_launch'] / k['fwd_s'] / PEAK_F32_MFMA},

@@ -22,6 +22,7 @@
 //   * optional epilogue: per-channel BatchNorm partial statistics (n, mean, M2), one record per workgroup, merged by
 //     bn_stats_finalize -- removes the statistics pass over the conv output.
 #include <algorithm>
+#include <cstdint>
 #include "dam_common.h"
 #include "dam_conv_geo.h"
 #include "dam_bn_fin.h"
@@ -1182,12 +1183,22 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     }
     const int tm = 64 * MB;
     sg.tiles_m = (int)cdiv(npix, tm);
-    const int64_t total = (int64_t)sg.tiles_m * g.B * cdiv(nblk, NB);
-    // one resident round: <= 256 workgroups (one per CU) when strips of <= 64 tiles allow it
-    int tpw = (int)cdiv(total, 256);
-    if (tpw > 64) tpw = 64;
-    if (tpw > sg.tiles_m) tpw = sg.tiles_m;
-    if (tpw < 2 && sg.tiles_m >= 2) tpw = 2;                      // the two compute groups alternate tiles
+    // Strips per image by MAKESPAN: one workgroup per CU is resident (LDS), so a launch of w workgroups runs in ceil(w / 256)
+    // rounds of (tiles per workgroup + ~2 tiles' worth of prologue and drain).  The first rule (cdiv(total, 256) tiles per
+    // workgroup, at most 64) gave C5's batch of 59 chunks 295 and 531 workgroups -- a second and third round for a fraction of
+    // the chip: 512 and 384 us per launch where 236 workgroups of 66 tiles / 472 of 66 need 290 / 270.
+    int tpw = sg.tiles_m;
+    {
+        const int64_t per_image = cdiv(nblk, NB);
+        int64_t best = INT64_MAX;
+        for (int strips = 1; strips <= sg.tiles_m; ++strips) {
+            const int t = (int)cdiv(sg.tiles_m, strips);
+            if (t < 2 && sg.tiles_m >= 2) break;                      // the loaders' slot loop wants two tiles per workgroup
+            const int64_t wgs = (int64_t)cdiv(sg.tiles_m, t) * g.B * per_image;
+            const int64_t cost = cdiv(wgs, 256) * (t + 2);
+            if (cost < best) { best = cost; tpw = t; }
+        }
+    }
     sg.tpw = tpw;
     sg.strips = (int)cdiv(sg.tiles_m, tpw);
     if (g.Wo > 1024 || g.Wo < 16) return DAM_ERR_UNSUPPORTED;   // scalar pixel decode: 16 consecutive pixels span <= 2 output rows
