@@ -37,7 +37,8 @@ constexpr int PIPE_LT = 256;                    // loader threads: 4 waves, one 
                                                 // leaves its SIMD's other waves few issue slots: two loader waves on two SIMDs held
                                                 // back the two compute waves they shared with, and the barrier made all four wait)
 constexpr int PIPE_THREADS = 256 + PIPE_LT;
-// float4 items per loader thread and chunk = template parameter PU: 5 (a chunk of the patch <= 1280 items: every stride-1 stage,
+// float4 items per loader thread and chunk = template parameter PU: 3 (the K-split form of the small stages: every item a thread does
+// not have still costs its commit a slot of the SIMD it shares with a compute wave), 5 (a chunk of the patch <= 1280 items: every stride-1 stage,
 // also 64 pixels of 54-pixel rows at the reference's 216 frames) or 8 (<= 2048 items: the strided 3x3 convolutions at the head of
 // a down-sampling block, whose patch covers twice the rows and columns)
 constexpr int PIPE_BUF1 = 32768;                // LDS byte offset of the second chunk buffer: a compile-time constant, so the
@@ -55,13 +56,13 @@ constexpr int PIPE_BUF1 = 32768;                // LDS byte offset of the second
 #endif
 
 // Diagnostic build only (-DDAM_PIPE_STAMPS): the caller's workspace (`stamps`, otherwise unused here) receives s_memtime stamps of phase
-// boundaries, [workgroup][role: wave 0 / first loader wave][32] of (tag << 56 | time); read by tools/pipe_stamps_probe.py.
+// boundaries, [workgroup][role: wave 0 / first loader wave][64] of (tag << 56 | time); read by tools/pipe_stamps_probe.py.
 #ifdef DAM_PIPE_STAMPS
 #define DAM_PSTAMP(role, tag)                                                                                         \
     do {                                                                                                              \
-        if (lane == 0 && (wave == 0 || wave == 4) && stamp_n < 32) {                                                  \
+        if (lane == 0 && (wave == 0 || wave == 4) && stamp_n < 64) {                                                  \
             const unsigned long long t_ = __builtin_readcyclecounter();                                               \
-            stamp_p[(role) * 32 + stamp_n++] = ((unsigned long long)(tag) << 56) | (t_ & ((1ull << 56) - 1));         \
+            stamp_p[(role) * 64 + stamp_n++] = ((unsigned long long)(tag) << 56) | (t_ & ((1ull << 56) - 1));         \
         }                                                                                                             \
     } while (0)
 #else
@@ -72,13 +73,13 @@ struct PipeUnit {            // one work unit, decoded (wave uniform)
     int p0, img, nb0, oh_first;
 };
 
-template <int MB, int NB>
+template <int UPX, int NB>                    // UPX: output pixels of a unit
 __device__ __forceinline__ PipeUnit pipe_decode(const ConvGeo& g, int unit, int nby, float inv_wo) {
     PipeUnit u;
     const int r = unit / g.tiles_m, tm = unit - r * g.tiles_m;
     u.img = r / nby;
     u.nb0 = (r - u.img * nby) * NB;
-    u.p0 = tm * (64 * MB);
+    u.p0 = tm * UPX;
     u.oh_first = fast_div(u.p0, g.Wo, inv_wo);
     return u;
 }
@@ -87,7 +88,12 @@ __device__ __forceinline__ PipeUnit pipe_decode(const ConvGeo& g, int unit, int 
 // of the loader's 16 segments into registers (198 VGPRs, one workgroup per CU).
 // STATS: the launch also emits BatchNorm partial statistics (a separate instantiation: the epilogue code costs every launch
 // 1-2 us through register allocation even when it does not run).
-template <int MB, int NB, int PIPE_U, int STATS>   // STATS: 0 none, 1 forward statistics, 2 BatchNorm-backward sums (BnBwdEpi)
+// KS (1 or 2): K split over the compute waves.  The matrix pipe's atom is one wave's 16 x 16 block over the whole K; the 33 x 5 /
+// 65 x 9 stages have 1408 / 2368 of them for 1024 SIMDs, and with 64-pixel units the CUs that get two of the 384 units set the
+// launch.  KS = 2: a unit is 32 * MB pixels, a STAGE of the stream is TWO 16-channel chunks, waves 0 / 1 take the two pixel blocks
+// on the first chunk of every stage and waves 2 / 3 the same blocks on the second; waves 2 / 3 leave their accumulators in LDS in
+// front of the unit's last barrier and waves 0 / 1 add them and run the epilogue -- 768 / 1216 units, no extra barrier.
+template <int MB, int NB, int PIPE_U, int STATS, int KS>   // STATS: 0 none, 1 forward statistics, 2 BatchNorm-backward sums (BnBwdEpi)
 __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g, const int nunits, const float* __restrict__ X,
                                                                  const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                                  const float* __restrict__ in_scale,
@@ -99,14 +105,19 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int MW = 16 * MB;
+    constexpr int MT = 4 / KS;                  // pixel blocks (waves) of a unit
+    constexpr int UPX = MW * MT;                // output pixels of a unit
+    constexpr int QM = 4 * KS - 1;              // channel quads of a stage - 1
     const int HoWo = g.Ho * g.Wo;
     const float inv_wo = 1.0f / (float)g.Wo;
     const int chunk_bytes = g.PR * g.PWT * 64;
+    const int stage_bytes = chunk_bytes * KS;
+    const int nst = g.nchunks / KS;             // stages of a unit
     const int nby = g.N / 16 / NB;
     const int G = gridDim.x;
     const size_t img_floats = (size_t)g.H * g.W * g.C;
 #ifdef DAM_PIPE_STAMPS
-    unsigned long long* stamp_p = reinterpret_cast<unsigned long long*>(stamps) + (size_t)blockIdx.x * 64;
+    unsigned long long* stamp_p = reinterpret_cast<unsigned long long*>(stamps) + (size_t)blockIdx.x * 128;
     int stamp_n = 0;
 #endif
     DAM_PSTAMP(wave >> 2, 1);
@@ -121,9 +132,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         // is the padding.
         const int ltid = tid - 256;
         const int WC = g.W * g.C;
-        const int ipr = g.PWin * 4;                              // items per patch row
+        const int ipr = g.PWin * 4 * KS;                         // items per patch row
         const int total = g.PR * ipr;
-        const int tab_off = PIPE_BUF1 + chunk_bytes;             // scale / shift tables (2 * C floats, only with in_scale)
+        const int tab_off = PIPE_BUF1 + stage_bytes;             // scale / shift tables (2 * C floats, only with in_scale)
         const int dump_off = tab_off + (in_scale ? 2 * g.C * 4 : 0);    // 4 KB that absorb the writes of threads without an item
         int dst[PIPE_U], gcol[PIPE_U];
         {
@@ -133,9 +144,9 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
             for (int u = 0; u < PIPE_U; ++u) {
                 dst[u] = dump_off + ltid * 16; gcol[u] = INT_MIN;
                 if (ltid + PIPE_LT * u < total) {
-                    const int pw = rem >> 2, cq = rem & 3;
+                    const int pw = rem / (4 * KS), cq = rem & QM;        // cq >> 2: the chunk of the stage
                     const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
-                    dst[u] = ((pr * g.PWT + slot) * 16 + cq * 4) * 4;
+                    dst[u] = ((pr * g.PWT + slot) * 16 + (cq & 3) * 4) * 4 + (cq >> 2) * chunk_bytes;
                     const int iw = g.c0 + pw;
                     if (iw >= 0 && iw < g.W) gcol[u] = (pr * WC + iw * g.C + cq * 4) * 4;
                 }
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                 if (rem >= ipr) { rem -= ipr; ++pr; }
             }
         }
-        const int cq4 = (lane & 3) * 4;                          // an item's channel quad is its lane's (256 and ipr are multiples of 4)
+        const int cq4 = (lane & QM) * 4;                         // an item's channel quad is its lane's (256 and ipr are multiples of 4 * KS)
         // Two register sets hold two DIFFERENT chunks of the stream, so a chunk's loads are in flight for two compute periods
         // (one measured period is ~2.3 us at one workgroup per CU, about the latency of the load itself: with one chunk in
         // flight the loaders, not the MFMAs, set the pace).  A round = commit the older set, refill it from the head of the
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         // check: no memory traffic), so the wait in front of a commit is the compile-time vmcnt(PIPE_U), not 0.
         float4 v[2][PIPE_U];
         int unit = blockIdx.x;                                   // head of the stream: the next chunk to request
-        PipeUnit cur = pipe_decode<MB, NB>(g, unit, nby, inv_wo);
+        PipeUnit cur = pipe_decode<UPX, NB>(g, unit, nby, inv_wo);
         int icg = 0;
         int rowb = (cur.oh_first * g.s + g.r0) * WC * 4;         // byte offset of patch row 0 in the image (negative above it)
         const unsigned img_bytes = (unsigned)img_floats * 4u;
@@ -162,16 +173,16 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         bool s_live[2] = {false, false};
 #define DAM_PIPE_REFILL(S_)                                                                                                \
     do {                                                                                                                   \
-        const int sb_ = head ? rowb + icg * 64 : INT_MIN;                                                                  \
+        const int sb_ = head ? rowb + icg * (64 * KS) : INT_MIN;                                                                \
         _Pragma("unroll") for (int u = 0; u < PIPE_U; ++u)                                                                 \
             v[S_][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, gcol[u] + sb_, 0, 0));      \
         s_sb[S_] = sb_; s_cg[S_] = icg; s_live[S_] = head;                                                                 \
         if (head) {                                         /* advance the head */                                         \
-            if (icg + 1 < g.nchunks) {                                                                                     \
+            if (icg + 1 < nst) {                                                                                           \
                 ++icg;                                                                                                     \
             } else if (unit + G < nunits) {                                                                                \
                 unit += G;                                                                                                 \
-                cur = pipe_decode<MB, NB>(g, unit, nby, inv_wo);                                                           \
+                cur = pipe_decode<UPX, NB>(g, unit, nby, inv_wo);                                                          \
                 icg = 0;                                                                                                   \
                 rowb = (cur.oh_first * g.s + g.r0) * WC * 4;                                                               \
                 xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (size_t)cur.img * img_floats), 0, img_bytes, \
@@ -185,8 +196,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     do {                                                                                                                   \
         constexpr int boff_ = (S_) * PIPE_BUF1;                                                                            \
         if (in_scale) {                                     /* relu(x * scale + shift) of what is inside the tensor */     \
-            const float4 sc = *reinterpret_cast<const float4*>(smem + tab_off + (s_cg[S_] * 16 + cq4) * 4);                \
-            const float4 sh = *reinterpret_cast<const float4*>(smem + tab_off + (g.C + s_cg[S_] * 16 + cq4) * 4);          \
+            const float4 sc = *reinterpret_cast<const float4*>(smem + tab_off + (s_cg[S_] * (16 * KS) + cq4) * 4);         \
+            const float4 sh = *reinterpret_cast<const float4*>(smem + tab_off + (g.C + s_cg[S_] * (16 * KS) + cq4) * 4);   \
             _Pragma("unroll") for (int u = 0; u < PIPE_U; ++u) {                                                           \
                 float4 x = v[S_][u];                                                                                       \
                 x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y);                                                  \
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         // the slots of a stride-2 de-interleave that no item covers must read as zero: clear both buffers once (with stride 1
         // every slot a valid pixel reads is an item); the two loader waves meet at barrier (0) before either commits
         if (g.s != 1)
-            for (int e = ltid * 16; e < chunk_bytes; e += PIPE_LT * 16) {
+            for (int e = ltid * 16; e < stage_bytes; e += PIPE_LT * 16) {
                 *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(smem + PIPE_BUF1 + e) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -248,6 +259,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
 
     // ================= compute waves =================
     const int j = lane & 15, kq = lane >> 4;
+    const int mt = wave & (MT - 1), kh = wave / MT;        // pixel block of the unit, K half (KS == 2)
+    const int part_off = PIPE_BUF1 + stage_bytes + (in_scale ? 2 * g.C * 4 : 0) + PIPE_LT * 16;   // behind the loaders' dump zone
     // tap constants: packed-weight byte offset of (tap, chunk 0, block 0) and LDS byte offset of the tap inside the patch
     int tapw[9], tapx[9];
 #pragma unroll
@@ -260,11 +273,21 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     }
     const int lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp), 0, 0x7fffffff, 0x00020000);
+    // Weight pipeline depth: an item is 4 * MB * NB MFMAs = 128 * MB * NB clocks of the matrix pipe.  Two items ahead (three
+    // rotating sets) cover an L2 hit (~700 clocks) only from four-block tiles up; the one- and two-block tiles of the small deep
+    // stages take NINE sets, one per tap: item T's MFMAs are followed by the request of tap T of the NEXT chunk into the same set,
+    // so every request has a whole chunk (1152 * MB * NB clocks) to land.
+#ifdef DAM_PIPE_NO_W9
+    constexpr bool W9 = false;
+#else
+    constexpr bool W9 = MB * NB <= 2;
+#endif
+    constexpr int WSETS = W9 ? 9 : 3;
     v4f acc[MB][NB];
-    float4 wa[3][NB], xv[3][MB];
+    float4 wa[WSETS][NB], xv[3][MB];
     int base_b[MB];
     int unit = blockIdx.x;
-    PipeUnit cur = pipe_decode<MB, NB>(g, unit, nby, inv_wo);
+    PipeUnit cur = pipe_decode<UPX, NB>(g, unit, nby, inv_wo);
     int sbuf = 0;
 #define DAM_PIPE_W(S_, CPART_, T_)                                                                                         \
     do {                                                                                                                   \
@@ -279,30 +302,36 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
             xv[S_][mb] = *reinterpret_cast<const float4*>(smem + base_b[mb] + lo_);                                        \
     } while (0)
 #ifdef DAM_PIPE_DIAG_NOMFMA
-#define DAM_PIPE_MFMA(S_)                                                                                                  \
+#define DAM_PIPE_MFMA2(SW_, SX_)                                                                                           \
     do {                                                                                                                   \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                  \
             _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                            \
-                acc[mb][nb].x += wa[S_][nb].x * xv[S_][mb].x; acc[mb][nb].y += wa[S_][nb].y * xv[S_][mb].y;                \
-                acc[mb][nb].z += wa[S_][nb].z * xv[S_][mb].z; acc[mb][nb].w += wa[S_][nb].w * xv[S_][mb].w;                \
+                acc[mb][nb].x += wa[SW_][nb].x * xv[SX_][mb].x; acc[mb][nb].y += wa[SW_][nb].y * xv[SX_][mb].y;            \
+                acc[mb][nb].z += wa[SW_][nb].z * xv[SX_][mb].z; acc[mb][nb].w += wa[SW_][nb].w * xv[SX_][mb].w;            \
             }                                                                                                              \
     } while (0)
 #else
-#define DAM_PIPE_MFMA(S_)                                                                                                  \
+#define DAM_PIPE_MFMA2(SW_, SX_)                                                                                           \
     do {                                                                                                                   \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                  \
             _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                            \
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[S_][nb].x, xv[S_][mb].x, acc[mb][nb], 0, 0, 0);      \
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[S_][nb].y, xv[S_][mb].y, acc[mb][nb], 0, 0, 0);      \
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[S_][nb].z, xv[S_][mb].z, acc[mb][nb], 0, 0, 0);      \
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[S_][nb].w, xv[S_][mb].w, acc[mb][nb], 0, 0, 0);      \
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[SW_][nb].x, xv[SX_][mb].x, acc[mb][nb], 0, 0, 0);    \
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[SW_][nb].y, xv[SX_][mb].y, acc[mb][nb], 0, 0, 0);    \
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[SW_][nb].z, xv[SX_][mb].z, acc[mb][nb], 0, 0, 0);    \
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[SW_][nb].w, xv[SX_][mb].w, acc[mb][nb], 0, 0, 0);    \
             }                                                                                                              \
     } while (0)
 #endif
+#define DAM_PIPE_MFMA(S_) DAM_PIPE_MFMA2(S_, S_)
     {
-        const int cfirst = cur.nb0 * 1024;
+        const int cfirst = (kh * g.NBtot + cur.nb0) * 1024;
         DAM_PIPE_W(0, cfirst, 0);                   // weights of the first two items: nothing to wait for
         DAM_PIPE_W(1, cfirst, 1);
+        if constexpr (W9) {                         // ... of the whole first chunk
+            DAM_PIPE_W(2 % WSETS, cfirst, 2); DAM_PIPE_W(3 % WSETS, cfirst, 3); DAM_PIPE_W(4 % WSETS, cfirst, 4);
+            DAM_PIPE_W(5 % WSETS, cfirst, 5); DAM_PIPE_W(6 % WSETS, cfirst, 6); DAM_PIPE_W(7 % WSETS, cfirst, 7);
+            DAM_PIPE_W(8 % WSETS, cfirst, 8);
+        }
     }
     DAM_PSTAMP(0, 2);
     DAM_PIPE_BARRIER();                             // (0)
@@ -311,22 +340,22 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     DAM_PSTAMP(0, 5);
     for (;;) {
         const bool has_next = unit + G < nunits;
-        const PipeUnit nxt = has_next ? pipe_decode<MB, NB>(g, unit + G, nby, inv_wo) : cur;
+        const PipeUnit nxt = has_next ? pipe_decode<UPX, NB>(g, unit + G, nby, inv_wo) : cur;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            int p = cur.p0 + wave * MW + mb * 16 + j;
+            int p = cur.p0 + mt * MW + mb * 16 + j;
             p = p < HoWo ? p : HoWo - 1;
             const int oh = fast_div(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
             base_b[mb] = (((oh - cur.oh_first) * g.s) * g.PWT + ow) * 64 + kq * 16;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
         }
-        for (int cg = 0; cg < g.nchunks; ++cg) {
-            const int boff = (sbuf & 1) * PIPE_BUF1;
+        for (int cg = 0; cg < nst; ++cg) {
+            const int boff = (sbuf & 1) * PIPE_BUF1 + kh * chunk_bytes;
             ++sbuf;
-            const int ccur = (cg * g.NBtot + cur.nb0) * 1024;
+            const int ccur = ((cg * KS + kh) * g.NBtot + cur.nb0) * 1024;
             // the chunk behind this one in the stream (the last chunk of the last unit re-requests its own first blocks)
-            const int cnext = cg + 1 < g.nchunks ? ccur + g.NBtot * 1024 : nxt.nb0 * 1024;
+            const int cnext = cg + 1 < nst ? ccur + KS * g.NBtot * 1024 : (kh * g.NBtot + nxt.nb0) * 1024;
             // the order below IS the software pipeline: without the scheduling barriers the compiler sinks every request to
             // just in front of its first use (fewer live registers) and the MFMAs wait for L2 on every item
 #define DAM_PIPE_ITEM(SW_, CP_, TW_, SX_, TX_, SM_)                                                                        \
@@ -337,9 +366,21 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         DAM_PIPE_MFMA(SM_);                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
     } while (0)
+#define DAM_PIPE_ITEM9(T_)                                  /* X two taps ahead, MFMAs of tap T_, its set refilled from the next chunk */ \
+    do {                                                                                                                   \
+        if ((T_) + 2 < 9) DAM_PIPE_X(((T_) + 2) % 3, (T_) + 2 < 9 ? (T_) + 2 : 0);                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        DAM_PIPE_MFMA2((T_) % WSETS, (T_) % 3);                                                                            \
+        DAM_PIPE_W((T_) % WSETS, cnext, T_);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
             DAM_PIPE_X(0, 0);
             DAM_PIPE_X(1, 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (W9) {
+                DAM_PIPE_ITEM9(0); DAM_PIPE_ITEM9(1); DAM_PIPE_ITEM9(2); DAM_PIPE_ITEM9(3); DAM_PIPE_ITEM9(4);
+                DAM_PIPE_ITEM9(5); DAM_PIPE_ITEM9(6); DAM_PIPE_ITEM9(7); DAM_PIPE_ITEM9(8);
+            } else {
             DAM_PIPE_ITEM(2, ccur, 2, 2, 2, 0);
             DAM_PIPE_ITEM(0, ccur, 3, 0, 3, 1);
             DAM_PIPE_ITEM(1, ccur, 4, 1, 4, 2);
@@ -349,10 +390,32 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
             DAM_PIPE_ITEM(2, ccur, 8, 2, 8, 0);
             DAM_PIPE_ITEM(0, cnext, 0, 0, -1, 1);
             DAM_PIPE_ITEM(1, cnext, 1, 0, -1, 2);
+            }
 #undef DAM_PIPE_ITEM
+#undef DAM_PIPE_ITEM9
             DAM_PSTAMP(0, 6);
+            if (KS == 2 && kh == 1 && cg + 1 == nst) {          // the second K half's sums, for the wave that holds the first
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        *reinterpret_cast<v4f*>(smem + part_off + ((mt * MB + mb) * NB + nb) * 1024 + lane * 16) = acc[mb][nb];
+            }
             DAM_PIPE_BARRIER();                     // (2 + i)
             DAM_PSTAMP(0, 7);
+        }
+        if (KS == 2) {
+            if (kh == 1) {                          // no epilogue: on to the next unit (the same barriers as everybody)
+                if (!has_next) break;
+                unit += G;
+                cur = nxt;
+                continue;
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] += *reinterpret_cast<const v4f*>(smem + part_off + ((mt * MB + mb) * NB + nb) * 1024 + lane * 16);
         }
 
         // ---- write the tile out (as conv_igemm_kernel): lane holds channels 4*kq..+3 of pixel j of every (mb, nb) block ----
@@ -386,7 +449,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            const int p = cur.p0 + wave * MW + mb * 16 + j;
+            const int p = cur.p0 + mt * MW + mb * 16 + j;
             if (p >= HoWo) continue;
             const int oh = fast_div(p, g.Wo, inv_wo), ow = p - oh * g.Wo;
             const size_t opix = ((size_t)cur.img * g.OHt + (oh * g.os + g.oo_h)) * g.OWt + (ow * g.os + g.oo_w);
@@ -444,7 +507,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), 0x122, 0xF, 0xF, false)); \
         V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), 0x121, 0xF, 0xF, false)); \
     } while (0)
-            const size_t rec = ((size_t)cur.img * g.tiles_m + (cur.p0 / (64 * MB))) * 4 + wave;
+            const size_t rec = ((size_t)cur.img * g.tiles_m + (cur.p0 / UPX)) * MT + mt;
             float n = st_n;
             DAM_ROW_SUM(n);
 #pragma unroll
@@ -476,7 +539,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
 }
 
 // resident workgroups per launch: occupancy x CUs, asked once per instance and LDS size
-template <int MB, int NB, int PU, int STATS>
+template <int MB, int NB, int PU, int STATS, int KS>
 int pipe_slots(size_t lds) {
     static int cus = 0;
     static size_t cached_lds = ~(size_t)0;
@@ -488,7 +551,7 @@ int pipe_slots(size_t lds) {
     }
     if (cached_lds != lds) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_pipe_kernel<MB, NB, PU, STATS>), PIPE_THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_pipe_kernel<MB, NB, PU, STATS, KS>), PIPE_THREADS,
                                                          lds) != hipSuccess || per_cu < 1)
             per_cu = 1;
         cached = per_cu * cus;
@@ -497,7 +560,7 @@ int pipe_slots(size_t lds) {
     return cached;
 }
 
-template <int MB, int NB, int PU>
+template <int MB, int NB, int PU, int KS>
 int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, const float* bias, const float* sc, const float* sh,
                 float* Y, const float* res, const float* res_mask, float* workspace, float* stats, int* stats_parts,
                 const BnBwdEpi& bwd, hipStream_t st) {
@@ -505,17 +568,17 @@ int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
     // statistics records: one per (image tile, wave), each unit fills its own channels of it
     int mode = 0;
     if (stats) {
-        const int64_t parts = (int64_t)g.B * g.tiles_m * 4;
+        const int64_t parts = (int64_t)g.B * g.tiles_m * (4 / KS);
         if (parts > (bwd.x ? BN_BWD_RECORDS_MAX : BN_RECORDS_MAX)) stats = nullptr;    // the caller runs the separate pass instead
         else { mode = bwd.x ? 2 : 1; if (stats_parts) *stats_parts = (int)parts; }
     }
     if (bwd.x) res = mode == 2 ? bwd.x : nullptr;               // the sums epilogue reads x through the residual operand
-    int wgs = mode == 2 ? pipe_slots<MB, NB, PU, 2>(lds) : (mode == 1 ? pipe_slots<MB, NB, PU, 1>(lds) : pipe_slots<MB, NB, PU, 0>(lds));
+    int wgs = mode == 2 ? pipe_slots<MB, NB, PU, 2, KS>(lds) : (mode == 1 ? pipe_slots<MB, NB, PU, 1, KS>(lds) : pipe_slots<MB, NB, PU, 0, KS>(lds));
     if (const char* e = getenv("DAM_PIPE_WGS")) wgs = atoi(e);          // diagnostic
     if (wgs < 1) wgs = 1;
     if (wgs > nunits) wgs = nunits;
 #define DAM_PIPE_LAUNCH(S_)                                                                                                 \
-    hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, S_>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,  \
+    hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, S_, KS>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,  \
                        reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats, bwd)
     if (mode == 2) DAM_PIPE_LAUNCH(2); else if (mode == 1) DAM_PIPE_LAUNCH(1); else DAM_PIPE_LAUNCH(0);
 #undef DAM_PIPE_LAUNCH
@@ -537,11 +600,12 @@ int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, cons
     if ((size_t)g.H * g.W * g.C * 4 >= ((size_t)1 << 30)) return DAM_ERR_UNSUPPORTED;      // offsets of the range-checked loads
     const int64_t npix = (int64_t)g.Ho * g.Wo;
     const int nblk = g.N / 16;
-    auto patch_rows = [&](int mb) {
-        int rows_out = (int)((64 * mb + g.Wo - 2) / g.Wo + 1);
+    auto patch_rows_px = [&](int px) {            // patch rows under `px` consecutive output pixels
+        int rows_out = (int)((px + g.Wo - 2) / g.Wo + 1);
         if (rows_out > g.Ho) rows_out = g.Ho;
         return (rows_out - 1) * g.s + row_span + 1;
     };
+    auto patch_rows = [&](int mb) { return patch_rows_px(64 * mb); };
     auto fits = [&](int mb, int nb) {
         const int pr = patch_rows(mb);
         return nblk % nb == 0 && pr * g.PWin * 4 <= PIPE_LT * 8 && (size_t)pr * g.PWT * 64 <= PIPE_BUF1;
@@ -564,16 +628,26 @@ int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, cons
         if (MB < 1 || NB < 1 || !fits(MB, NB)) return DAM_ERR_UNSUPPORTED;
     }
     if (!MB) return DAM_ERR_UNSUPPORTED;
-    g.PR = patch_rows(MB);
-    g.tiles_m = (int)cdiv(npix, 64 * MB);
+    // K split over the wave pairs (kernel comment): for one-block tiles that leave the chip fewer than three units per CU
+    int KS = 1;
+    if (MB == 1 && NB == 1 && g.nchunks % 2 == 0 && cdiv(npix, 64) * nblk * g.B < 768) {
+        const int pr = patch_rows_px(32);
+        if (pr * g.PWin * 8 <= PIPE_LT * 3 && (size_t)pr * g.PWT * 128 <= PIPE_BUF1) KS = 2;     // (three items per loader thread)
+    }
+    if (const char* e = getenv("DAM_PIPE_KS")) { if (atoi(e) == 1) KS = 1; }     // diagnostic
+    const int upx = 64 * MB / KS;
+    g.PR = patch_rows_px(upx);
+    g.tiles_m = (int)cdiv(npix, upx);
     g.CG = 1; g.ksplit = 1; g.gps = g.nchunks;
-    // chunk buffer 0 (padded to PIPE_BUF1), chunk buffer 1, scale / shift tables, the dump zone
-    const size_t lds = PIPE_BUF1 + (size_t)g.PR * g.PWT * 64 + (sc ? (size_t)2 * g.C * 4 : 0) + PIPE_LT * 16;
-    const bool big = g.PR * g.PWin * 4 > PIPE_LT * 5;      // items per loader thread: 5 or 8
+    // stage buffer 0 (padded to PIPE_BUF1), stage buffer 1, scale / shift tables, the dump zone, the K halves' hand-over
+    const size_t lds = PIPE_BUF1 + (size_t)KS * g.PR * g.PWT * 64 + (sc ? (size_t)2 * g.C * 4 : 0) + PIPE_LT * 16 +
+                       (KS == 2 ? (size_t)2 * MB * NB * 1024 : 0);
+    const bool big = g.PR * g.PWin * 4 * KS > PIPE_LT * 5; // items per loader thread: 5 or 8
+    if (KS == 2) return launch_pipe<1, 1, 3, 2>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, bwd, st);
 #define DAM_PIPE_CASE(M_, N_)                                                                                              \
     if (MB == M_ && NB == N_)                                                                                              \
-        return big ? launch_pipe<M_, N_, 8>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, bwd, st) \
-                   : launch_pipe<M_, N_, 5>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, bwd, st)
+        return big ? launch_pipe<M_, N_, 8, 1>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, bwd, st) \
+                   : launch_pipe<M_, N_, 5, 1>(g, lds, X, Wp, bias, sc, sh, Y, res, res_mask, workspace, stats, stats_parts, bwd, st)
     DAM_PIPE_CASE(1, 4); DAM_PIPE_CASE(2, 2); DAM_PIPE_CASE(1, 2); DAM_PIPE_CASE(2, 1); DAM_PIPE_CASE(1, 1);
 #undef DAM_PIPE_CASE
     return DAM_ERR_UNSUPPORTED;

@@ -11,6 +11,8 @@ import deep_audio_mixer_amd  # noqa: E402,F401
 from deep_audio_mixer_amd import features, ops  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'layer1'
+which, _, opts = which.partition(':')            # layer4|5|6[:stats][+affine]: forward with the statistics epilogue / fused input affine
+opts = set(opts.split('+')) if opts else set()
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device('cuda', 0)
 B, H, W = 8, 1025, 130
@@ -34,7 +36,12 @@ elif which in ('layer4', 'layer5', 'layer6'):
     hw, c = {'layer4': ((129, 17), 96), 'layer5': ((65, 9), 128), 'layer6': ((33, 5), 256)}[which]
     x = torch.randn((B, hw[0], hw[1], c), device=dev)
     wp = ops.pack_weights(torch.randn((c, c, 3, 3), device=dev) * 0.05)
-    fn = lambda: ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1)
+    kw = {}
+    if 'stats' in opts:
+        kw['bn_partial'] = ops.bn_partial_buffer(dev, c)
+    if 'affine' in opts:
+        kw.update(in_scale=torch.rand(c, device=dev) + 0.5, in_shift=torch.randn(c, device=dev) * 0.1, relu_in=True)
+    fn = lambda: ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1, **kw)
 elif which in ('layer3s2', 'layer4s2', 'layer5s2', 'layer6s2'):       # the strided 3x3 convolution at the head of a stage
     hw, ci, co = {'layer3s2': ((513, 65), 32, 64), 'layer4s2': ((257, 33), 64, 96), 'layer5s2': ((129, 17), 96, 128),
                   'layer6s2': ((65, 9), 128, 256)}[which]

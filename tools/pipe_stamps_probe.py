@@ -6,7 +6,6 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('DAM_LIB_PATH', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdam_pipe_stamps.so'))
-os.environ.setdefault('DAM_TILE', '1x4')
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import deep_audio_mixer_amd  # noqa: E402,F401
@@ -25,7 +24,7 @@ ws.zero_()
 ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1)
 torch.cuda.synchronize()
 st = ws.view(torch.int64).cpu().numpy().astype(np.uint64)
-st = st[:st.size // 64 * 64].reshape(-1, 2, 32)
+st = st[:st.size // 128 * 128].reshape(-1, 2, 64)
 nwg = int((st[:, 0, 0] != 0).sum())
 names = {1: 'start', 2: 'setup', 3: 'bar0', 4: 'commit0', 5: 'bar1', 6: 'work', 7: 'bar', 8: 'epilogue'}
 mask = np.uint64((1 << 56) - 1)
