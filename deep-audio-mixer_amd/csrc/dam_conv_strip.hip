@@ -202,24 +202,36 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     //      and, in the self-overlapped form, by every wave for the workgroup's first tile)
     int lo0, hi0;
     tile_rows(t_begin, lo0, hi0);
-    constexpr int KP = NCH == 1 ? 1 : (LW ? 2 : 3);           // planes per loader wave per tile
-    constexpr int GPP = NCH == 1 ? (LW ? 14 : 9) : (LW ? 7 : 5);   // 1 KB pieces per plane (host: groups_per_plane <= GPP)
+    // HS = 2 (16-channel layers, self-overlapped form): a tile adds ~2 planes, so with whole planes two of the four loader waves
+    // carried all the pieces -- and all the VALU of a fused input affine (72 instructions per slot on the SIMDs of two compute
+    // waves, the other two idle: +8 us per launch).  A loader's unit is then HALF a plane: the even or the odd 1 KB pieces
+    // (wave parity), every wave the same 4-5 pieces.
+#ifdef DAM_STRIP_NO_HS          // timing A/B (tools/build_variant.sh)
+    constexpr int HS = 1;
+#else
+    constexpr int HS = (NCH == 1 && !LW && SO != 0) ? 2 : 1;
+#endif
+    constexpr int KP = (NCH == 1 ? 1 : (LW ? 2 : 3)) * HS;    // units (planes / half planes) per loader wave per tile
+    constexpr int GPPF = NCH == 1 ? (LW ? 14 : 9) : (LW ? 7 : 5);  // 1 KB pieces per plane (host: groups_per_plane <= GPPF)
+    constexpr int GPP = (GPPF + HS - 1) / HS;                 // ... per unit
+    const int hsel = HS == 2 ? (wave & 1) : 0;
     int loffb[GPP];
     unsigned long long cmask[GPP];
 #pragma unroll
-    for (int gi = 0; gi < GPP; ++gi) {
+    for (int gu = 0; gu < GPP; ++gu) {
+        const int gi = gu * HS + hsel;
         const int L = gi * 64 + lane, slot = L >> 2, quad = L & 3;
         int pw = slot;
         if (g.s != 1) pw = slot < g.PWs ? 2 * slot : 2 * (slot - g.PWs) + 1;
         const int iw = pw + g.c0;
         const bool ok = gi < groups_per_plane && slot < g.PWT && pw < g.PWin && iw >= 0 && iw < g.W;
         const int iwc = iw < 0 ? 0 : (iw >= g.W ? g.W - 1 : iw);
-        loffb[gi] = (iwc * g.C + quad * 4) * 4;
-        cmask[gi] = __ballot(ok);
+        loffb[gu] = (iwc * g.C + quad * 4) * 4;
+        cmask[gu] = __ballot(ok);
     }
     // buffer addressing: scalar resource (this image) + scalar plane offset + per-lane column offset, no VALU
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, g.H * g.W * g.C * 4, 0x00020000);
-    const int lane16 = lane * 16;
+    const int lane16 = lane * 16 + hsel * 1024;
     const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
     v4f lvA[KP][GPP], lvB[KP][GPP];
     int dstA[KP], dstB[KP];                          // scalar: ring byte offset of the plane | 1 << 30 if the row is
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             if (hi_ >= first_) { planes_ = (hi_ - first_ + 1) << chs; loaded_hi = hi_; }                                   \
         }                                                                                                                  \
         _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                                   \
-            const int pl_ = cw + STRIP_LOADERS * k;                                                                        \
+            const int pl_ = (cw + STRIP_LOADERS * k) / HS;                                                                 \
             const bool used_ = pl_ < planes_;                                                                              \
             const int cc_ = pl_ & (NCH - 1), ih_ = first_ + (pl_ >> chs);                                                  \
             const bool rowok_ = used_ && ih_ >= 0 && ih_ < g.H;                                                            \
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     } while (0)
 #define DAM_STRIP_WRITE(ADDR_, DATA_, GI_)                                                                                 \
     asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
-                 : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024) : "memory")
+                 : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024 * HS) : "memory")
 #define DAM_STRIP_COMMIT(LV_, DST_, CC_) DAM_STRIP_COMMIT_N(KP, LV_, DST_, CC_)
 #define DAM_STRIP_COMMIT_N(KPX_, LV_, DST_, CC_)                                                                           \
     do {                                                                                                                   \
@@ -282,12 +294,12 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
 #define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_) do { } while (0)
 #endif
     // SO prologue: the rows of the workgroup's FIRST tile as whole planes too, spread over all NT / 64 waves (plane = wave + k * NT/64)
-    constexpr int KP0 = NCH == 1 ? 1 : 2;
+    constexpr int KP0 = (NCH == 1 ? 1 : 2) * HS;
 #define DAM_STRIP_REQUEST0(LV_, DST_, CC_)                                                                                 \
     do {                                                                                                                   \
         const int planes_ = (hi0 - lo0 + 1) << chs;                                                                        \
         _Pragma("unroll") for (int k = 0; k < KP0; ++k) {                                                                  \
-            const int pl_ = wave + (NT / 64) * k;                                                                          \
+            const int pl_ = (wave + (NT / 64) * k) / HS;                                                                   \
             const bool used_ = pl_ < planes_;                                                                              \
             const int cc_ = pl_ & (NCH - 1), ih_ = lo0 + (pl_ >> chs);                                                     \
             const bool rowok_ = used_ && ih_ >= 0 && ih_ < g.H;                                                            \

@@ -23,7 +23,12 @@ if which in ('layer1', 'layer1_wgrad', 'layer1_dgrad'):
     wp, wpt = ops.pack_weights(wt), ops.pack_weights(wt, transpose=True)
     dy = torch.randn((B, H, W, 16), device=dev)
     if which == 'layer1':
-        fn = lambda: ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1)
+        kw = {}
+        if 'stats' in opts:
+            kw['bn_partial'] = ops.bn_partial_buffer(dev, 16)
+        if 'affine' in opts:
+            kw.update(in_scale=torch.rand(16, device=dev) + 0.5, in_shift=torch.randn(16, device=dev) * 0.1, relu_in=True)
+        fn = lambda: ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1, **kw)
     elif which == 'layer1_dgrad':
         fn = lambda: ops.conv2d_dgrad(dy, wpt, 16, H, W, 3, 3, 1, 1, 1, res=dy, res_mask=x)
     else:
