@@ -310,8 +310,20 @@ struct RowsGeo {
     int tiles_k;             // in-channel tiles
     int gpp;                 // 1 KB pieces per row plane
 };
+// Diagnostic build only (-DDAM_WGR_STAMPS, tools/wgr_stamps_probe.py; results are wrong): instead of its slab a workgroup leaves
+// s_memtime stamps of compute wave 0 and loader wave 0, [role][32] of (tag << 56 | time): 1 start, 2 first rows staged,
+// 5 end of a slot's MFMAs / commits, 7 behind the slot's barrier, 8 end.
+#ifdef DAM_WGR_STAMPS
+#define DAM_WSTAMP(tag)                                                                                                \
+    do {                                                                                                              \
+        if (lane == 0 && (wave == 0 || wave == 4) && stamp_n < 32)                                                    \
+            stamp_v[stamp_n++] = ((unsigned long long)(tag) << 56) | ((unsigned long long)__builtin_readcyclecounter() & ((1ull << 56) - 1)); \
+    } while (0)
+#else
+#define DAM_WSTAMP(tag) do { } while (0)
+#endif
 constexpr int RW_LOADERS = 8;                 // loader waves (waves 4..11)
-constexpr int RW_THREADS = 256 + 64 * RW_LOADERS, RW_GUARD = 64, RW_TAIL = 256;
+constexpr int RW_THREADS = 256 + 64 * RW_LOADERS, RW_GUARD = 64, RW_TAIL = 1280;   // (tail: the step-split last slot prefetches up to 1 KB past a row)
 // v % d for the two ring sizes (scalar multiply-shift, v < 30000)
 template <int D> __device__ __forceinline__ int rw_mod(int v) { return D == 10 ? v - ((v * 52429) >> 19) * 10 : v - ((v * 43691) >> 18) * 6; }
 
@@ -338,8 +350,11 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         if (L < full * nxg) { const int c = L & 7, r = L >> 3; bx = r % nxg; by = (r / nxg) * 8 + c; }
     }
     const int tn = bx / g.tiles_k, tk = bx - tn * g.tiles_k;
-    const int img = by / g.spi, r_begin = (by - img * g.spi) * g.rps;
-    const int r_end = r_begin + g.rps < g.H ? r_begin + g.rps : g.H;
+    // strips: the image's rows in spi nearly equal parts (the feature maps are 2^k + 1 rows high: with strips of whole slots
+    // 1025 rows on 32 strips took 9 slots of 4 rows per workgroup for 8.01 slots of work); a last slot of one row is split
+    // over all four compute waves by MFMA steps (the waves' sums are added at the end whatever produced them)
+    const int img = by / g.spi, sidx = by - img * g.spi;
+    const int r_begin = (int)(((long long)sidx * g.H) / g.spi), r_end = (int)(((long long)(sidx + 1) * g.H) / g.spi);
     const int n_slots = (r_end - r_begin + RPS - 1) / RPS;
     const int n_slots2 = (n_slots + 1) & ~1;
     const int ROWB = g.P4 * 64;
@@ -347,18 +362,34 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
     const int XBASE = RW_GUARD, DBASE = XBASE + TKB * XPLANE;
     const int lds_bytes = DBASE + TNB * DPLANE + RW_TAIL;
 
-    // every thread zeroes its share of the LDS image (padding cells stay zero for the lifetime of the workgroup); the
-    // loader waves have the rows of slot 0 in flight while that happens
+    // The cells the loaders never write must read as zero for the lifetime of the workgroup: per ring row the padding cells
+    // (cell 0 = column -1, cells W + 1 .. P4 - 1), the guard in front of the first row and the tail behind the last.  Only
+    // those are cleared (one pass; clearing the whole 150 KB image took the 12 waves 5.5 k clocks of a 27 k-clock prologue) and
+    // they are disjoint from what a commit writes, so the clearing needs no barrier of its own.
 #define DAM_RW_ZERO()                                                                                                      \
     do {                                                                                                                   \
-        for (int e = tid * 16; e < lds_bytes; e += RW_THREADS * 16)                                                        \
+        const int npad_ = g.P4 - g.W, nrow_ = TKB * RW_NRX + TNB * RW_NRD;                                                 \
+        for (int e = tid; e < nrow_ * npad_ * 4; e += RW_THREADS) {                                                        \
+            const int q_ = e & 3, c_ = (e >> 2) % npad_, r_ = (e >> 2) / npad_;                                            \
+            const int cell_ = c_ == 0 ? 0 : g.W + c_;                                                                      \
+            *reinterpret_cast<float4*>(smem + XBASE + r_ * ROWB + cell_ * 64 + q_ * 16) = make_float4(0.f, 0.f, 0.f, 0.f); \
+        }                                                                                                                  \
+        for (int e = tid * 16; e < RW_GUARD; e += RW_THREADS * 16)                                                         \
             *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                    \
+        for (int e = tid * 16; e < RW_TAIL; e += RW_THREADS * 16)                                                          \
+            *reinterpret_cast<float4*>(smem + lds_bytes - RW_TAIL + e) = make_float4(0.f, 0.f, 0.f, 0.f);                  \
     } while (0)
 
     v4f acc[NBLK];
 #pragma unroll
     for (int i = 0; i < NBLK; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+#ifdef DAM_WGR_STAMPS
+    unsigned long long stamp_v[32];
+    int stamp_n = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) stamp_v[i] = 0;
+#endif
+    DAM_WSTAMP(1);
 
     if (wave >= 4) {
         // ================================ loader waves ================================
@@ -451,26 +482,37 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         constexpr int KPB = (2 * TKB + RW_LOADERS - 1) / RW_LOADERS;
         v4f lvb[KPB][GPP], lv2[KP][GPP];
         int dstb[KPB], dst2[KP], affb[KPB];
+        DAM_WSTAMP(9);                                                         // setup done
         DAM_RW_REQUEST(r_begin - 1, RPS, r_begin, RPS, lv, dst, KP, aff);
         DAM_RW_REQUEST(r_begin + RPS - 1, 2, r_begin, 0, lvb, dstb, KPB, affb);
+        DAM_WSTAMP(10);                                                        // first rows requested
         DAM_RW_ZERO();
+        DAM_WSTAMP(11);                                                        // padding cells cleared
         DAM_RW_COMMIT(lv, dst, KP, aff);
         DAM_RW_COMMIT(lvb, dstb, KPB, affb);
+        DAM_WSTAMP(12);                                                        // first rows written (their loads have landed)
+        // the compute waves start slot 0 HERE; the requests for slots 1 and 2 follow (in front of this barrier they held the
+        // first MFMA back by 5-8 k clocks: with three slots of rows wanted by 256 CUs at once the request queue backs up)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // steady state, two slots ahead (HBM latency under this load is about one slot): slot s writes the rows slot s+1
         // adds (X rows r_begin+RPS(s+1)+1 .. +RPS, dY rows r_begin+RPS(s+1) .. +RPS-1; requested during slot s-1) and
         // requests those of slot s+3.  Two register sets alternate; slots come in pairs so that no load sits inside a
         // conditional.
 #define DAM_RW_SLOT(T_, LV_, DST_, AFF_) DAM_RW_REQUEST(r_begin + RPS * (T_) + 1, RPS, r_begin + RPS * (T_), RPS, LV_, DST_, KP, AFF_)
+        DAM_WSTAMP(2);
         DAM_RW_SLOT(1, lv, dst, aff);
         DAM_RW_SLOT(2, lv2, dst2, aff2);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int s = 0; s < n_slots2; s += 2) {
             DAM_RW_COMMIT(lv, dst, KP, aff);
             DAM_RW_SLOT(s + 3, lv, dst, aff);
+            DAM_WSTAMP(5);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            DAM_WSTAMP(7);
             DAM_RW_COMMIT(lv2, dst2, KP, aff2);
             DAM_RW_SLOT(s + 4, lv2, dst2, aff2);
+            DAM_WSTAMP(5);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            DAM_WSTAMP(7);
         }
 #undef DAM_RW_SLOT
 #undef DAM_RW_REQUEST
@@ -481,23 +523,10 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         const int cw = wave;
         const int lane_b = kq * 64 + j * 4;       // lane group kq owns cell 4t + kq of step t, lane j channel j of the cell
         DAM_RW_ZERO();
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS
-        for (int s = 0; s < n_slots2; ++s) {
-            const int rw = cw / HV, half = cw - rw * HV;                      // row of the slot, part of the row
-            const int r = r_begin + RPS * s + rw;
-            if (r < r_end) {
-                int vx[TKB][3], vd[TNB];
-                const int part = half * STEPS * 256;                          // byte offset of this wave's first cell
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int xi = rw_mod<RW_NRX>(RPS * s + rw + a);          // row r - 1 + a relative to r_begin - 1
-#pragma unroll
-                    for (int kb = 0; kb < TKB; ++kb) vx[kb][a] = lane_b + (XBASE - 64 + kb * XPLANE + xi * ROWB + part);
-                }
-#pragma unroll
-                for (int nb = 0; nb < TNB; ++nb)
-                    vd[nb] = lane_b + (DBASE + nb * DPLANE + ((RPS * s + rw) & (RW_NRD - 1)) * ROWB + part);
-                float av[2][TNB], bv[2][TKB][9];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS, padding cleared
+        DAM_WSTAMP(2);
+        // one (row, first cell, step stride) assignment of this wave for the slot: F = 1 a whole row part (the steady state),
+        // F = 4 / 2 every fourth / second MFMA step of the one / two rows of a strip's last slot
 #define DAM_RW_LOAD(T_, BUF_)                                                                                              \
     do {                                                                                                                   \
         _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                                 \
@@ -507,27 +536,49 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
                 _Pragma("unroll") for (int b = 0; b < 3; ++b)                                                              \
                     bv[BUF_][kb][a * 3 + b] = *reinterpret_cast<const float*>(smem + vx[kb][a] + ((T_) * 256 + b * 64));   \
     } while (0)
-                DAM_RW_LOAD(0, 0);
-#pragma unroll
-                for (int t = 0; t < STEPS; ++t) {
-                    if (t + 1 < STEPS) DAM_RW_LOAD(t + 1, (t + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nb = 0; nb < TNB; ++nb)
-#pragma unroll
-                        for (int kb = 0; kb < TKB; ++kb)
-#pragma unroll
-                            for (int tap = 0; tap < 9; ++tap) {
-                                const int idx = (nb * TKB + kb) * 9 + tap;
-                                acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][nb], bv[t & 1][kb][tap], acc[idx], 0, 0, 0);
-                            }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#undef DAM_RW_LOAD
+#define DAM_RW_ROW(F_, RW_, PART_, SUB_)                      /* steps SUB_, SUB_ + F_, ... of row RW_ of the slot */ \
+    do {                                                                                                                   \
+        int vx[TKB][3], vd[TNB];                                                                                           \
+        _Pragma("unroll") for (int a = 0; a < 3; ++a) {                                                                    \
+            const int xi = rw_mod<RW_NRX>(RPS * s + (RW_) + a);               /* row r - 1 + a relative to r_begin - 1 */  \
+            _Pragma("unroll") for (int kb = 0; kb < TKB; ++kb) vx[kb][a] = lane_b + (XBASE - 64 + kb * XPLANE + xi * ROWB + (PART_)); \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                                 \
+            vd[nb] = lane_b + (DBASE + nb * DPLANE + ((RPS * s + (RW_)) & (RW_NRD - 1)) * ROWB + (PART_));                 \
+        float av[2][TNB], bv[2][TKB][9];                                                                                   \
+        constexpr int NS_ = (STEPS + (F_) - 1) / (F_);                                                                     \
+        DAM_RW_LOAD(0, 0);                                                                                                 \
+        _Pragma("unroll") for (int t = 0; t < NS_; ++t) {                                                                  \
+            if ((F_) > 1 && (SUB_) + (F_) * t >= STEPS) break;                /* (scalar; last step of the split form only) */ \
+            if (t + 1 < NS_) DAM_RW_LOAD((F_) * (t + 1), (t + 1) & 1);                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                             \
+                _Pragma("unroll") for (int kb = 0; kb < TKB; ++kb)                                                         \
+                    _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                                  \
+                        const int idx = (nb * TKB + kb) * 9 + tap;                                                         \
+                        acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][nb], bv[t & 1][kb][tap], acc[idx], 0, 0, 0); \
+                    }                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+        }                                                                                                                  \
+    } while (0)
+        for (int s = 0; s < n_slots2; ++s) {
+            const int rows_here = r_end - (r_begin + RPS * s);                // rows of this slot (<= 0: none)
+            // a strip's last row: every fourth step per wave.  Only for the one-block tile: with 18 accumulator blocks a second
+            // copy of the MFMA stream -- unrolled, rolled, or the same copy with an early exit (which halves its speed) -- makes
+            // the register allocator spill (168 registers at three waves per SIMD)
+            if (HV == 1 && TNB * TKB == 1 && rows_here == 1) {
+                DAM_RW_ROW(4, 0, cw * 256, cw);
+            } else {
+                const int rw = cw / HV, half = cw - rw * HV;                  // row of the slot, part of the row
+                if (rw < rows_here) DAM_RW_ROW(1, rw, half * STEPS * 256, 0);
             }
+            DAM_WSTAMP(5);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            DAM_WSTAMP(7);
         }
     }
+#undef DAM_RW_ROW
+#undef DAM_RW_LOAD
 
     // combine the 4 compute waves through LDS (sequential adds: fixed order), one slab per workgroup
     __syncthreads();
@@ -549,8 +600,18 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         __syncthreads();
     }
     float4* out = reinterpret_cast<float4*>(partial) + ((size_t)by * gridDim.x + bx) * NBLK * 64;
+#ifdef DAM_WGR_STAMPS
+    DAM_WSTAMP(8);
+    if (lane == 0 && (wave == 0 || wave == 4)) {
+        unsigned long long* sp = reinterpret_cast<unsigned long long*>(out) + (wave >> 2) * 32;
+        for (int i = 0; i < 32; ++i) sp[i] = stamp_v[i];
+    }
+#else
     for (int e = tid; e < NBLK * 64; e += RW_THREADS) out[e] = reinterpret_cast<const float4*>(red)[e];
+#endif
 }
+
+#undef DAM_RW_ZERO
 
 template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV = 1>
 int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* dY, const float* in_scale, const float* in_shift,
@@ -583,9 +644,10 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     if (nx * B * spi < 205 && lds * 2 <= 160 * 1024) spi = strips(2);
     if (const char* e = getenv("DAM_WGR_PERCU")) spi = strips(atoi(e) == 2 && lds * 2 <= 160 * 1024 ? 2 : 1);      // diagnostic
     if (spi > (int)cdiv(H, RPS)) spi = (int)cdiv(H, RPS);
-    for (;; --spi) {
-        g.rps = (int)cdiv(cdiv(H, spi), RPS) * RPS;
-        g.spi = (int)cdiv(H, g.rps);
+    if (spi > H) spi = H;
+    for (;; --spi) {                              // (rows in spi nearly equal parts, see the kernel)
+        g.spi = spi;
+        g.rps = (int)cdiv(H, spi);
         if ((int64_t)B * g.spi * nx * NBLK * 256 <= ws_floats || spi == 1) break;
     }
     const int nsplit = B * g.spi;
@@ -646,8 +708,8 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2G
         if (L < full * nxg) { const int c = L & 7, r = L >> 3; bx = r % nxg; by = (r / nxg) * 8 + c; }
     }
     const int tn = bx / g.tiles_k, tk = bx - tn * g.tiles_k;
-    const int img = by / g.spi, r_begin = (by - img * g.spi) * g.rps;
-    const int r_end = r_begin + g.rps < g.Ho ? r_begin + g.rps : g.Ho;
+    const int img = by / g.spi, sidx = by - img * g.spi;             // strips and their last slot as in wgrad_rows_kernel
+    const int r_begin = (int)(((long long)sidx * g.Ho) / g.spi), r_end = (int)(((long long)(sidx + 1) * g.Ho) / g.spi);
     const int n_slots = (r_end - r_begin + RPS - 1) / RPS;
     const int n_slots2 = (n_slots + 1) & ~1;
 
@@ -786,20 +848,7 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2G
         const int lane_b = kq * 64 + j * 4;       // lane group kq owns cell 4t + kq of step t, lane j channel j of the cell
         DAM_RW_ZERO();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS
-        for (int s = 0; s < n_slots2; ++s) {
-            const int rw = cw / HV, half = cw - rw * HV;                      // row of the slot, part of the row
-            const int r = r_begin + RPS * s + rw;
-            if (r < r_end) {
-                int vx[3], vd[TNB];
-                const int part = half * STEPS * 256;                          // byte offset of this wave's first cell
-#pragma unroll
-                for (int a = 0; a < 3; ++a)                                   // X row 2r - 1 + a, relative to 2*r_begin - 1
-                    vx[a] = lane_b + (XBASE + rw_mod<NRX>(2 * (RPS * s + rw) + a) * XROWB + part);
-#pragma unroll
-                for (int nb = 0; nb < TNB; ++nb)
-                    vd[nb] = lane_b + (DBASE + nb * DPLANE + ((RPS * s + rw) & (NRD - 1)) * DROWB + part);
-                float av[2][TNB], bv[2][9];
-                // column taps: odd-plane cell ow, even-plane cell ow, odd-plane cell ow + 1
+        // column taps: odd-plane cell ow, even-plane cell ow, odd-plane cell ow + 1
 #define DAM_RW2_LOAD(T_, BUF_)                                                                                             \
     do {                                                                                                                   \
         _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                                 \
@@ -810,23 +859,39 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2G
             bv[BUF_][a * 3 + 2] = *reinterpret_cast<const float*>(smem + vx[a] + ((T_) * 256 + 64));                       \
         }                                                                                                                  \
     } while (0)
-                DAM_RW2_LOAD(0, 0);
-#pragma unroll
-                for (int t = 0; t < STEPS; ++t) {
-                    if (t + 1 < STEPS) DAM_RW2_LOAD(t + 1, (t + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nb = 0; nb < TNB; ++nb)
-#pragma unroll
-                        for (int tap = 0; tap < 9; ++tap)
-                            acc[nb * 9 + tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][nb], bv[t & 1][tap], acc[nb * 9 + tap], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#undef DAM_RW2_LOAD
+#define DAM_RW2_ROW(F_, RW_, PART_, SUB_)                     /* as DAM_RW_ROW of wgrad_rows_kernel */                      \
+    do {                                                                                                                   \
+        int vx[3], vd[TNB];                                                                                                \
+        _Pragma("unroll") for (int a = 0; a < 3; ++a)                         /* X row 2r - 1 + a, relative to 2*r_begin - 1 */ \
+            vx[a] = lane_b + (XBASE + rw_mod<NRX>(2 * (RPS * s + (RW_)) + a) * XROWB + (PART_));                           \
+        _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                                 \
+            vd[nb] = lane_b + (DBASE + nb * DPLANE + ((RPS * s + (RW_)) & (NRD - 1)) * DROWB + (PART_));                   \
+        float av[2][TNB], bv[2][9];                                                                                        \
+        constexpr int NS_ = (STEPS + (F_) - 1) / (F_);                                                                     \
+        DAM_RW2_LOAD(0, 0);                                                                                                \
+        _Pragma("unroll") for (int t = 0; t < NS_; ++t) {                                                                  \
+            if ((F_) > 1 && (SUB_) + (F_) * t >= STEPS) break;                                                             \
+            if (t + 1 < NS_) DAM_RW2_LOAD((F_) * (t + 1), (t + 1) & 1);                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                             \
+                _Pragma("unroll") for (int tap = 0; tap < 9; ++tap)                                                        \
+                    acc[nb * 9 + tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][nb], bv[t & 1][tap], acc[nb * 9 + tap], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+        }                                                                                                                  \
+    } while (0)
+        for (int s = 0; s < n_slots2; ++s) {
+            const int rows_here = r_end - (r_begin + RPS * s);                // rows of this slot (<= 0: none)
+            if (HV == 1 && TNB == 1 && rows_here == 1) {
+                DAM_RW2_ROW(4, 0, cw * 256, cw);
+            } else {
+                const int rw = cw / HV, half = cw - rw * HV;                  // row of the slot, part of the row
+                if (rw < rows_here) DAM_RW2_ROW(1, rw, half * STEPS * 256, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
+#undef DAM_RW2_ROW
+#undef DAM_RW2_LOAD
 #undef DAM_RW_ZERO
 
     // combine the 4 compute waves through LDS (sequential adds: fixed order), one slab per workgroup
@@ -878,9 +943,10 @@ int launch_wgrad_rows_s2(int B, int H, int W, int C, int Ho, int Wo, int N, cons
     int spi = strips(1);
     if (nx * B * spi < 205 && lds * 2 <= 160 * 1024) spi = strips(2);
     if (spi > (int)cdiv(Ho, RPS)) spi = (int)cdiv(Ho, RPS);
-    for (;; --spi) {
-        g.rps = (int)cdiv(cdiv(Ho, spi), RPS) * RPS;
-        g.spi = (int)cdiv(Ho, g.rps);
+    if (spi > Ho) spi = Ho;
+    for (;; --spi) {                              // (rows in spi nearly equal parts, see the kernel)
+        g.spi = spi;
+        g.rps = (int)cdiv(Ho, spi);
         if ((int64_t)B * g.spi * nx * NBLK * 256 <= ws_floats || spi == 1) break;
     }
     const int nsplit = B * g.spi;

@@ -53,8 +53,8 @@ elif which in ('layer3s2', 'layer4s2', 'layer5s2', 'layer6s2'):       # the stri
     x = torch.randn((B, hw[0], hw[1], ci), device=dev)
     wp = ops.pack_weights(torch.randn((co, ci, 3, 3), device=dev) * 0.05)
     fn = lambda: ops.conv2d_fwd(x, wp, co, 3, 3, 2, 1, 1)
-elif which in ('layer3_wgrad', 'layer4_wgrad', 'layer5_wgrad', 'layer6_wgrad'):
-    hw, c = {'layer3_wgrad': ((257, 33), 64), 'layer4_wgrad': ((129, 17), 96), 'layer5_wgrad': ((65, 9), 128),
+elif which in ('layer2_wgrad', 'layer3_wgrad', 'layer4_wgrad', 'layer5_wgrad', 'layer6_wgrad'):
+    hw, c = {'layer2_wgrad': ((513, 65), 32), 'layer3_wgrad': ((257, 33), 64), 'layer4_wgrad': ((129, 17), 96), 'layer5_wgrad': ((65, 9), 128),
              'layer6_wgrad': ((33, 5), 256)}[which]
     x = torch.randn((B, hw[0], hw[1], c), device=dev)
     dy = torch.randn((B, hw[0], hw[1], c), device=dev)
