@@ -487,7 +487,7 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     // 16-bit mono tracks at an odd sample stride start on odd 2-byte boundaries: the tuned kernel's 4-byte point loads would
     // be misaligned, the generic kernel reads sample by sample
     if ((pcm_dtype & ~DAM_PCM_INDIRECT) == DAM_PCM_S16 && channels == 1 && ((outer_stride | inner_stride) & 1)) fast = false;
-    if (!fast && (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))) return DAM_ERR_UNSUPPORTED;
+    if (!fast && (n_fft < 64 || n_fft > 16384 || (n_fft & (n_fft - 1)))) return DAM_ERR_UNSUPPORTED;    // (two LDS buffers of n_fft/2 points: 128 KB at 16384)
     const int indirect = (pcm_dtype & DAM_PCM_INDIRECT) ? 1 : 0;
     pcm_dtype &= ~DAM_PCM_INDIRECT;
     if (pcm_dtype != DAM_PCM_F32 && pcm_dtype != DAM_PCM_F64 && pcm_dtype != DAM_PCM_S16 && pcm_dtype != DAM_PCM_S32)
@@ -519,9 +519,20 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
         const dim3 ggrid((unsigned)n_frames, (unsigned)n_tracks);
         const size_t lds = (size_t)n_fft * sizeof(float2);        // two buffers of n_fft/2 complex points
 #define DAM_STFT_GENERIC(T, C, P)                                                                                     \
-    hipLaunchKernelGGL((stft_generic_kernel<T, C, P>), ggrid, dim3(256), lds, s, (const T*)pcm, n_samples, outer_stride, \
-                       (int)n_inner, inner_stride, channel_stride, window, tw, gain, n_fft, hop, n_frames, amin, floor_db, \
-                       normalize, out, out_tail, n_tail, indirect)
+    do {                                                                                                              \
+        if (lds > 48 * 1024) {                                     /* 8192 / 16384-point windows: raise the kernel's LDS limit once */ \
+            static bool raised = false;                                                                               \
+            if (!raised) {                                                                                            \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_generic_kernel<T, C, P>),                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) != hipSuccess)        \
+                    return DAM_ERR_LAUNCH;                                                                            \
+                raised = true;                                                                                        \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((stft_generic_kernel<T, C, P>), ggrid, dim3(256), lds, s, (const T*)pcm, n_samples, outer_stride, \
+                           (int)n_inner, inner_stride, channel_stride, window, tw, gain, n_fft, hop, n_frames, amin, floor_db, \
+                           normalize, out, out_tail, n_tail, indirect);                                               \
+    } while (0)
         if (pcm_dtype == DAM_PCM_F32) {
             if (channels == 1) DAM_STFT_GENERIC(float, 1, false);
             else if (planar) DAM_STFT_GENERIC(float, 2, true);

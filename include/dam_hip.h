@@ -76,7 +76,7 @@ int dam_stft_fill_twiddles_host(int n_fft, float* table_host /* [2*count] re,im 
  *   out      : [n_tracks][n_fft/2+1][T] float32, T = 1 + n_samples/hop
  * center=True / reflect padding / onesided / unnormalised, as torch.stft's defaults.
  * Supported: channels 1 or 2, n_samples > n_fft/2, hop >= 1; n_fft == 2048 with an even hop (every call site of the
- * reference: data/dataset.py:132-133 defaults) runs the tuned in-register kernel, any other power of two from 64 to 4096
+ * reference: data/dataset.py:132-133 defaults) runs the tuned in-register kernel, any other power of two from 64 to 16384
  * (or an odd hop) a generic one-workgroup-per-frame kernel; window then has n_fft entries (torch.hann_window(n_fft)). */
 int dam_stft_logmag_f32(const void* pcm, int pcm_dtype, int64_t n_tracks, int64_t n_samples, int channels,
                         int64_t pcm_track_stride, const float* window, const float* twiddles,

@@ -76,7 +76,7 @@ def test_normalize_and_edges(feats):
     with pytest.raises(RuntimeError, match='DAM_ERR_UNSUPPORTED'):
         feats.stft_logmag(torch.zeros(1, 40960, device='cuda'), n_fft=1000, hop=256)      # not a power of two
     with pytest.raises(RuntimeError, match='DAM_ERR_UNSUPPORTED'):
-        feats.stft_logmag(torch.zeros(1, 40960, device='cuda'), n_fft=8192, hop=256)
+        feats.stft_logmag(torch.zeros(1, 40960, device='cuda'), n_fft=32768, hop=256)      # above 16384: two LDS buffers do not fit
     with pytest.raises(RuntimeError, match='GPU only'):
         feats.stft_logmag(torch.zeros(1, 4096), hop=1024)
 
@@ -97,7 +97,8 @@ def test_full_size_properties(feats):
 
 
 @pytest.mark.parametrize('n_fft,hop,channels,dtype', [(1024, 256, 2, np.float32), (4096, 1024, 1, np.float64), (512, 100, 2, np.float64),
-                                                      (2048, 441, 2, np.float32), (64, 16, 1, np.float32)])
+                                                      (2048, 441, 2, np.float32), (64, 16, 1, np.float32), (8192, 2048, 2, np.float32),
+                                                      (16384, 4096, 1, np.float32)])
 def test_other_window_sizes(feats, n_fft, hop, channels, dtype):
     """compute_features(audio, window_size, hop_length) for windows other than 2048 and odd hops (generic kernel): stereo mean,
     gain, normalisation and the (stems, mix) output split behave as in the tuned kernel."""
