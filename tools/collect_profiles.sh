@@ -20,7 +20,7 @@ done
 run --kernel-trace --stats --output-format csv -d $root/$out/trace_C5 -- python3 $root/bench.py --config C5 --steps 3 --warmup 1 --no-roofline
 cp $out/trace_C5/*/*_kernel_stats.csv $out/C5_kernel_stats.csv
 echo "[collect] C5 trace done"
-for probe in layer1 layer1_wgrad layer3 layer5 layer4_wgrad layer3s2_wgrad stft; do
+for probe in layer1 layer1_wgrad layer3 layer5 layer6 layer4_wgrad layer6_wgrad layer3s2_wgrad stft; do
   i=0
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
