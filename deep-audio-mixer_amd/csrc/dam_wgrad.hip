@@ -329,8 +329,11 @@ template <int D> __device__ __forceinline__ int rw_mod(int v) { return D == 10 ?
 
 // HV: 1 = a compute wave takes a whole output row per slot (4 rows per slot), 2 = half a row (2 rows per slot, for rows too
 // wide for ten-row rings: the reference's native 216-frame spectrograms); STEPS = MFMA steps per wave and row (part)
-template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV>
-__global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g, const float* __restrict__ X,
+// NL: loader waves, 8 or 4.  The hardware starts a workgroup's waves one after the other (the 12th wave of a 768-thread workgroup
+// begins ~7 k clocks after the first when all CUs start at once); the narrow stages' few planes per slot do not need eight loaders,
+// and at eight waves per workgroup two workgroups really are co-resident on a CU (107 registers x 16 waves).
+template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV, int NL>
+__global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo g, const float* __restrict__ X,
                                                                 const float* __restrict__ dY, const float* __restrict__ in_scale,
                                                                 const float* __restrict__ in_shift, int relu_in,
                                                                 float* __restrict__ partial) {
@@ -369,14 +372,14 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
 #define DAM_RW_ZERO()                                                                                                      \
     do {                                                                                                                   \
         const int npad_ = g.P4 - g.W, nrow_ = TKB * RW_NRX + TNB * RW_NRD;                                                 \
-        for (int e = tid; e < nrow_ * npad_ * 4; e += RW_THREADS) {                                                        \
+        for (int e = tid; e < nrow_ * npad_ * 4; e += (256 + 64 * NL)) {                                                        \
             const int q_ = e & 3, c_ = (e >> 2) % npad_, r_ = (e >> 2) / npad_;                                            \
             const int cell_ = c_ == 0 ? 0 : g.W + c_;                                                                      \
             *reinterpret_cast<float4*>(smem + XBASE + r_ * ROWB + cell_ * 64 + q_ * 16) = make_float4(0.f, 0.f, 0.f, 0.f); \
         }                                                                                                                  \
-        for (int e = tid * 16; e < RW_GUARD; e += RW_THREADS * 16)                                                         \
+        for (int e = tid * 16; e < RW_GUARD; e += (256 + 64 * NL) * 16)                                                         \
             *reinterpret_cast<float4*>(smem + e) = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
-        for (int e = tid * 16; e < RW_TAIL; e += RW_THREADS * 16)                                                          \
+        for (int e = tid * 16; e < RW_TAIL; e += (256 + 64 * NL) * 16)                                                          \
             *reinterpret_cast<float4*>(smem + lds_bytes - RW_TAIL + e) = make_float4(0.f, 0.f, 0.f, 0.f);                  \
     } while (0)
 
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
 #define DAM_RW_REQUEST(XR0_, NX_, DR0_, ND_, LV_, DST_, KP_, AFF_)                                                                               \
     do {                                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < KP_; ++k) {                                                                  \
-            const int pl_ = cwl + RW_LOADERS * k;                                                                          \
+            const int pl_ = cwl + NL * k;                                                                          \
             const int nxp_ = (NX_) * TKB;                                                                                  \
             const bool isx_ = pl_ < nxp_;                                                                                  \
             const int q_ = isx_ ? pl_ : pl_ - nxp_;                                                                        \
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         }                                                                                                                  \
     } while (0)
         // rows of slot 0: X rows r_begin-1 .. r_begin+RPS, dY rows r_begin .. r_begin+RPS-1: both rounds requested up front
-        constexpr int KPB = (2 * TKB + RW_LOADERS - 1) / RW_LOADERS;
+        constexpr int KPB = (2 * TKB + NL - 1) / NL;
         v4f lvb[KPB][GPP], lv2[KP][GPP];
         int dstb[KPB], dst2[KP], affb[KPB];
         DAM_WSTAMP(9);                                                         // setup done
@@ -607,13 +610,13 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_kernel(const RowsGeo g,
         for (int i = 0; i < 32; ++i) sp[i] = stamp_v[i];
     }
 #else
-    for (int e = tid; e < NBLK * 64; e += RW_THREADS) out[e] = reinterpret_cast<const float4*>(red)[e];
+    for (int e = tid; e < NBLK * 64; e += (256 + 64 * NL)) out[e] = reinterpret_cast<const float4*>(red)[e];
 #endif
 }
 
 #undef DAM_RW_ZERO
 
-template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV = 1>
+template <int TNB, int TKB, int STEPS, int KP, int GPP, int HV = 1, int NL = 8>
 int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* dY, const float* in_scale, const float* in_shift,
                       int relu_in, float* partial, int64_t ws_floats, float* dw, int n_real, int k_real, void* queue,
                       hipStream_t st) {
@@ -624,7 +627,7 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     g.P4 = ((W + 2 + 4 * HV - 1) / (4 * HV)) * (4 * HV);
     if (g.P4 != STEPS * 4 * HV) return DAM_ERR_UNSUPPORTED;
     g.gpp = (g.P4 * 64 + 1023) / 1024;
-    if (g.gpp > GPP || (RPS * (TKB + TNB) + RW_LOADERS - 1) / RW_LOADERS > KP) return DAM_ERR_UNSUPPORTED;
+    if (g.gpp > GPP || (RPS * (TKB + TNB) + NL - 1) / NL > KP) return DAM_ERR_UNSUPPORTED;
     const int nblk = C / 16;
     if (nblk % TNB || nblk % TKB || H >= 8000) return DAM_ERR_UNSUPPORTED;
     const int tiles_n = nblk / TNB;
@@ -654,12 +657,12 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV, NL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return DAM_ERR_LAUNCH;
         raised = true;
     }
-    hipLaunchKernelGGL((wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV>), dim3(nx, nsplit), dim3(RW_THREADS), lds, st, g, X, dY, in_scale,
+    hipLaunchKernelGGL((wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV, NL>), dim3(nx, nsplit), dim3((256 + 64 * NL)), lds, st, g, X, dY, in_scale,
                        in_shift, relu_in, partial);
     DAM_CHECK_LAUNCH();
     return reduce_submit(queue, partial, dw, nsplit, nx, TNB, TKB, 3, 3, n_real, k_real, 3, 3, 1, g.tiles_k, st);
@@ -1152,11 +1155,13 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
 #define DAM_WGR(...) launch_wgrad_rows<__VA_ARGS__>(B, H, W, C, x, dy, in_scale, in_shift, relu_in, workspace, workspace_floats, dw, n_out, k_real, reduce_queue, st)
         // <TN, TK, steps, planes per loader wave, pieces per plane, row parts>: the shapes of the ResNet stages at 130 frames
         // (3 s clips) and at the reference's native 216 frames
+        // (the last parameter, loader waves: four measured 53.7 -> 48.5 us on the 129x17 stage, where two workgroups then share a
+        // CU; no difference on the three wide stages -- 56.6 / 57.5 / 59.5 against 57.0 / 57.0 / 59.2 us -- and 31.8 -> 32.7 on 65x9)
         if (C == 16) { rc = DAM_WGR(1, 1, 33, 1, 9); if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGR(1, 1, 28, 1, 14, 2); }
         else if (W > 80) rc = DAM_WGR(2, 1, 14, 1, 7, 2);
         else if (W > 48) { rc = DAM_WGR(2, 1, 17, 2, 5); if (rc == DAM_ERR_UNSUPPORTED) rc = DAM_WGR(2, 1, 14, 2, 4); }
         else if (W > 20) rc = DAM_WGR(2, 1, 9, 2, 3);
-        else if (W > 12) rc = DAM_WGR(2, 1, 5, 2, 2);       // 17-pixel rows (129x17 stage): 69.8 -> 66.9 us incl. the slab reduce
+        else if (W > 12) rc = getenv("DAM_WGR_NL8") ? DAM_WGR(2, 1, 5, 2, 2) : DAM_WGR(2, 1, 5, 3, 2, 1, 4);   // 17-pixel rows (129x17 stage), four loader waves
         else if (W > 6) rc = DAM_WGR(2, 1, 3, 2, 1);        // 9-pixel rows (65x9 stage): 40.8 -> 32.1 us; narrower: tile kernel
 #undef DAM_WGR
         if (rc != DAM_ERR_UNSUPPORTED) return rc;
