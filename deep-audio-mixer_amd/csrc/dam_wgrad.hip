@@ -35,7 +35,7 @@ struct WgradGeo {
     int tiles_n, tiles_k, tap_groups;
     int tiles_m, total_tiles, nsplit;
     int in_nchw, relu_in;
-    int TMW;                 // pixels per tile (256 or 128): 4 waves x TMW/4 pixels
+    int TMW;                 // pixels per tile (a multiple of 16, <= 256): 4 waves x TMW/4 pixels
 };
 
 namespace {
@@ -1205,7 +1205,11 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     g.PWs = (int)cdiv(g.PWin, stride);
     g.PWT = g.PWs * stride;
     const int ta_rows = (kh == 3 && kw == 3) ? 3 : 1;               // TA of the instantiations below
-    auto set_tile = [&](int tmw) {
+    auto set_tile = [&](int tmw_max) {
+        // pixels per tile: the image in equal parts of at most tmw_max pixels, rounded up to the 16 a step of the four waves takes
+        // (165 pixels of the 33 x 5 stage in a 256-pixel tile were 16 MFMA steps per wave for 10.3 of work: 176 -> 11)
+        const int64_t npix_ = (int64_t)Ho * Wo, parts_ = cdiv(npix_, tmw_max);
+        const int tmw = getenv("DAM_WG_FIXED_TILE") ? tmw_max : (int)(cdiv(cdiv(npix_, parts_), 16) * 16);
         int rows_out = (tmw + Wo - 2) / Wo + 1;
         if (rows_out > Ho) rows_out = Ho;
         g.TMW = tmw;
