@@ -632,23 +632,33 @@ def run_ingest(name, cfg, args):
         t_frames = 1 + n // cfg['hop']
         frames = B * S * t_frames
         out = {}
-        for label, force_f32 in (('int16_staging', False), ('float32_staging', True)):
-            ds = MultitrackAudioDataset(root, chunk_length=cfg['seconds'], sr=sr, tracklist=tracklist, seed=1)
-            if force_f32:
-                ds.staging_format = lambda: (np.dtype(np.float32), CHANNELS)
-            for _ in ds.iter_batches(B, workers=args.workers, drop_last=True):        # warm pass: page cache, tables, pinned
-                pass
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            k = 0
-            for _ in range(max(1, args.steps // 12)):
-                for x, gt in ds.iter_batches(B, workers=args.workers, drop_last=True):
-                    k += 1
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            bytes_h2d = B * (S + 1) * n * CHANNELS * (4 if force_f32 else 2)
-            out[label] = {'frames_per_s': frames * k / dt, 'ms_per_batch': 1e3 * dt / k, 'batches': k,
-                          'h2d_bytes_per_batch': bytes_h2d, 'h2d_GBps': bytes_h2d * k / dt / 1e9}
+        # two rounds of both legs, alternating (a single 12-batch pass per leg measured mostly which leg ran second: thread
+        # start-up and page-cache state differ by 2 x from run to run); each leg: one warm pass, then >= 4 passes timed; the
+        # faster round of a leg is reported, both are kept
+        passes = max(4, args.steps // 12)
+        for rnd in range(2):
+            for label, force_f32 in (('int16_staging', False), ('float32_staging', True)):
+                ds = MultitrackAudioDataset(root, chunk_length=cfg['seconds'], sr=sr, tracklist=tracklist, seed=1)
+                if force_f32:
+                    ds.staging_format = lambda: (np.dtype(np.float32), CHANNELS)
+                for _ in ds.iter_batches(B, workers=args.workers, drop_last=True):    # warm pass: page cache, tables, pinned
+                    pass
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                k = 0
+                for _ in range(passes):
+                    for x, gt in ds.iter_batches(B, workers=args.workers, drop_last=True):
+                        k += 1
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                bytes_h2d = B * (S + 1) * n * CHANNELS * (4 if force_f32 else 2)
+                rec = {'frames_per_s': frames * k / dt, 'ms_per_batch': 1e3 * dt / k, 'batches': k,
+                       'h2d_bytes_per_batch': bytes_h2d, 'h2d_GBps': bytes_h2d * k / dt / 1e9}
+                prev = out.get(label)
+                rounds = (prev['ms_per_batch_rounds'] if prev else []) + [rec['ms_per_batch']]
+                if prev is None or rec['ms_per_batch'] < prev['ms_per_batch']:
+                    out[label] = rec
+                out[label]['ms_per_batch_rounds'] = rounds
         print(json.dumps({
             'metric': 'stem-spectrogram-frames/sec (ingest: WAV -> features)', 'value': out['int16_staging']['frames_per_s'],
             'unit': 'stem-spectrogram-frames/s', 'n_gpus': 1, 'higher_is_better': True, 'data': 'synthetic 16-bit stereo WAV on tmpfs',

@@ -254,11 +254,17 @@ class MultitrackAudioDataset(data.Dataset):
                         uploaded[slot].synchronize()                    # the slot's previous upload has left host[slot]
                         view = host[slot].numpy()
 
+                        # one task = a few tracks of one clip (K tracks in `per` pieces): a task per track made the pool's
+                        # bookkeeping (72 futures per batch, all under the interpreter lock) a third of a batch's time
+                        per = max(1, min(K, (len(group) * K + 2 * max(1, workers) - 1) // (2 * max(1, workers))))
+
                         def one(job, view=view):
-                            b, k, item = job
+                            b, k0, k1, item = job
                             song_i, chunk_i = self._calculate_song_index(item)
-                            self._read_chunk_into(view[b, k], self.songlist[song_i], self._tracklist[k], chunk_i * n, (chunk_i + 1) * n)
-                        started.append((slot, group, [pool.submit(one, (b, k, item)) for b, item in enumerate(group) for k in range(K)]))
+                            for k in range(k0, k1):
+                                self._read_chunk_into(view[b, k], self.songlist[song_i], self._tracklist[k], chunk_i * n, (chunk_i + 1) * n)
+                        started.append((slot, group, [pool.submit(one, (b, k0, min(K, k0 + per), item))
+                                                      for b, item in enumerate(group) for k0 in range(0, K, per)]))
                         j += 1
                     slot, group, reads = started.popleft()
                     for f in reads:

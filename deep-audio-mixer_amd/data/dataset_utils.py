@@ -1,6 +1,7 @@
 """Mirror of the reference's data/dataset_utils.py helpers that sit on the path."""
 import os
 import struct
+import threading
 
 import numpy as np
 
@@ -43,6 +44,28 @@ _WAVE_FORMAT_PCM, _WAVE_FORMAT_IEEE_FLOAT, _WAVE_FORMAT_EXTENSIBLE = 1, 3, 0xFFF
 _headers = {}
 
 
+_fds = {}                      # (path, mtime, size) -> read-only descriptor kept open for positioned reads (first _FDS_MAX files)
+_FDS_MAX = 256
+_fds_lock = threading.Lock()
+
+
+def _get_fd(path, h):
+    """(descriptor, close it after use?): cached for the first _FDS_MAX files -- never evicted, so a descriptor in use by another
+    decode thread cannot be closed under it -- a fresh one beyond that."""
+    key = h['_key']
+    fd = _fds.get(key)
+    if fd is not None:
+        return fd, False
+    with _fds_lock:
+        fd = _fds.get(key)
+        if fd is not None:
+            return fd, False
+        if len(_fds) < _FDS_MAX:
+            fd = _fds[key] = os.open(path, os.O_RDONLY)
+            return fd, False
+    return os.open(path, os.O_RDONLY), True
+
+
 def wav_header(path):
     """Parses the RIFF chunks of a WAV file once: {'tag' (1 integer PCM / 3 IEEE float), 'channels', 'rate', 'bits',
     'frame_bytes', 'data_offset', 'frames'}.  WAVE_FORMAT_EXTENSIBLE files (what DAWs write for 24-bit / multichannel
@@ -80,7 +103,7 @@ def wav_header(path):
     offset, size = data
     size = min(size, st.st_size - offset)                  # streamed files may carry a placeholder size
     h = dict(tag=tag, channels=channels, rate=rate, bits=bits, frame_bytes=frame_bytes, data_offset=offset,
-             frames=size // frame_bytes)
+             frames=size // frame_bytes, _key=key)
     _headers[key] = h
     return h
 
@@ -139,14 +162,25 @@ def read_wav_native(path, start=0, stop=None, out=None):
             out[...] = a
             return out, rate
         return a, rate
+    if width != 3 and out is not None and out.dtype == kind and out.shape == (stop - start, ch) and out.flags.c_contiguous:
+        # the ingest path: positioned read on a cached descriptor straight into the caller's (page-locked) buffer -- no
+        # open / seek / close per chunk, no file position shared between the decode threads
+        fd, owned = _get_fd(path, h)
+        try:
+            buf, off, want = memoryview(out).cast('B'), h['data_offset'] + start * h['frame_bytes'], out.nbytes
+            got = 0
+            while got < want:
+                r = os.preadv(fd, [buf[got:]], off + got)
+                if r <= 0:
+                    raise ValueError('%s: short read' % path)
+                got += r
+        finally:
+            if owned:
+                os.close(fd)
+        return out, h['rate']
     with open(path, 'rb') as fh:
         fh.seek(h['data_offset'] + start * h['frame_bytes'])
         if width != 3:
-            if out is not None and out.dtype == kind and out.shape == (stop - start, ch) and out.flags.c_contiguous:
-                got = fh.readinto(memoryview(out).cast('B'))
-                if got != out.nbytes:
-                    raise ValueError('%s: short read' % path)
-                return out, h['rate']
             a = np.frombuffer(fh.read((stop - start) * h['frame_bytes']), dtype=kind).reshape(-1, ch)
         else:
             b = np.frombuffer(fh.read((stop - start) * h['frame_bytes']), dtype=np.uint8).reshape(-1, 3)
