@@ -160,6 +160,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         // flight the loaders, not the MFMAs, set the pace).  A round = commit the older set, refill it from the head of the
         // stream, barrier; a refill is ALWAYS PIPE_U loads (behind the end of the stream at an offset that fails the range
         // check: no memory traffic), so the wait in front of a commit is the compile-time vmcnt(PIPE_U), not 0.
+        const float relu_lo = g.relu_in ? 0.f : -__builtin_inff();
         float4 v[2][PIPE_U];
         int unit = blockIdx.x;                                   // head of the stream: the next chunk to request
         PipeUnit cur = pipe_decode<UPX, NB>(g, unit, nby, inv_wo);
@@ -202,9 +203,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                 float4 x = v[S_][u];                                                                                       \
                 x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y);                                                  \
                 x.z = fmaf(x.z, sc.z, sh.z); x.w = fmaf(x.w, sc.w, sh.w);                                                  \
-                if (g.relu_in) {                                                                                           \
-                    x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);            \
-                }                                                                                                          \
+                x.x = fmaxf(x.x, relu_lo); x.y = fmaxf(x.y, relu_lo); x.z = fmaxf(x.z, relu_lo); x.w = fmaxf(x.w, relu_lo); /* -inf: no ReLU */ \
                 if ((unsigned)(gcol[u] + s_sb[S_]) >= img_bytes) x = make_float4(0.f, 0.f, 0.f, 0.f);                      \
                 *reinterpret_cast<float4*>(smem + boff_ + dst[u]) = x;                                                     \
             }                                                                                                              \

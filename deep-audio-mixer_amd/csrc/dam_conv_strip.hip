@@ -233,6 +233,8 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, g.H * g.W * g.C * 4, 0x00020000);
     const int lane16 = lane * 16 + hsel * 1024;
     const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float relu_lo = relu_in ? 0.f : -__builtin_inff();       // (a run-time `if (relu_in)` became four v_cndmask per piece on the loaders)
+    const v4f relu_lo4 = {relu_lo, relu_lo, relu_lo, relu_lo};
     v4f lvA[KP][GPP], lvB[KP][GPP];
     int dstA[KP], dstB[KP];                          // scalar: ring byte offset of the plane | 1 << 30 if the row is
     int ccA[KP], ccB[KP];                            // outside the tensor (zeros are written), -1 = nothing to write; chunk
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
                         const v4f sh_ = (NCH > 1 && CC_[k] > 0) ? shq[NCH - 1] : shq[0];                                   \
                         _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) {                                               \
                             v4f v_ = __builtin_elementwise_fma(LV_[k][gi], sc_, sh_);                                      \
-                            if (relu_in) v_ = __builtin_elementwise_max(v_, zero4);                                        \
+                            v_ = __builtin_elementwise_max(v_, relu_lo4);   /* max(., -inf) when there is no ReLU: no selects */ \
                             DAM_STRIP_WRITE(va_, v_, gi);                                                                  \
                         }                                                                                                  \
                     } else {                                                                                               \

@@ -414,6 +414,8 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY) + (size_t)img * g.H * g.W * g.C, 0, img_bytes, 0x00020000);
         const int lane16 = lane * 16;
         const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+        const float relu_lo = relu_in ? 0.f : -__builtin_inff();
+        const v4f relu_lo4 = {relu_lo, relu_lo, relu_lo, relu_lo};
         // fused input affine on the X planes (the producer's BatchNorm + ReLU): a lane holds channel quad (lane & 3) of a cell
         const bool has_aff = in_scale != nullptr;
         v4f scq[TKB], shq[TKB];
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
                     const v4f sh_ = (TKB > 1 && AFF_[k] > 0) ? shq[TKB - 1] : shq[0];                                      \
                     _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) {                                                   \
                         v4f v_ = __builtin_elementwise_fma(LV_[k][gi], sc_, sh_);                                          \
-                        if (relu_in) v_ = __builtin_elementwise_max(v_, zero4);                                            \
+                        v_ = __builtin_elementwise_max(v_, relu_lo4);       /* -inf without ReLU: no selects */             \
                         DAM_RW_WRITE(va_, v_, gi);                                                                         \
                     }                                                                                                      \
                 } else {                                                                                                   \
