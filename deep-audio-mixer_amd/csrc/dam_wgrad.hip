@@ -530,6 +530,24 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
         DAM_RW_ZERO();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS, padding cleared
         DAM_WSTAMP(2);
+        // operand reads of step t + 1 against the MFMAs of step t: one read behind each of the first MFMAs (as a burst in front
+        // of them -- build flag DAM_WGR_NO_INTERLEAVE, scheduling barriers only -- the launch is 1.3-1.6 us slower: the pipe drains
+        // while seven reads issue)
+#ifndef DAM_WGR_NO_INTERLEAVE
+#define DAM_RW_SCHED_A() do { } while (0)
+#define DAM_RW_SCHED_B()                                                                                                   \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 9 * TNB * TKB, 0);                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+#else
+#define DAM_RW_SCHED_A() __builtin_amdgcn_sched_barrier(0)
+#define DAM_RW_SCHED_B() __builtin_amdgcn_sched_barrier(0)
+#endif
         // one (row, first cell, step stride) assignment of this wave for the slot: F = 1 a whole row part (the steady state),
         // F = 4 / 2 every fourth / second MFMA step of the one / two rows of a strip's last slot
 #define DAM_RW_LOAD(T_, BUF_)                                                                                              \
@@ -556,14 +574,14 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
         _Pragma("unroll") for (int t = 0; t < NS_; ++t) {                                                                  \
             if ((F_) > 1 && (SUB_) + (F_) * t >= STEPS) break;                /* (scalar; last step of the split form only) */ \
             if (t + 1 < NS_) DAM_RW_LOAD((F_) * (t + 1), (t + 1) & 1);                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            DAM_RW_SCHED_A();                                                                                              \
             _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                             \
                 _Pragma("unroll") for (int kb = 0; kb < TKB; ++kb)                                                         \
                     _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                                  \
                         const int idx = (nb * TKB + kb) * 9 + tap;                                                         \
                         acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][nb], bv[t & 1][kb][tap], acc[idx], 0, 0, 0); \
                     }                                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            DAM_RW_SCHED_B();                                                                                              \
         }                                                                                                                  \
     } while (0)
         for (int s = 0; s < n_slots2; ++s) {
@@ -584,6 +602,8 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
     }
 #undef DAM_RW_ROW
 #undef DAM_RW_LOAD
+#undef DAM_RW_SCHED_A
+#undef DAM_RW_SCHED_B
 
     // combine the 4 compute waves through LDS (sequential adds: fixed order), one slab per workgroup
     __syncthreads();
@@ -853,6 +873,21 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2G
         const int lane_b = kq * 64 + j * 4;       // lane group kq owns cell 4t + kq of step t, lane j channel j of the cell
         DAM_RW_ZERO();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // rows of slot 0 are in LDS
+#ifdef DAM_WGR_S2_INTERLEAVE                     /* as in wgrad_rows_kernel; here measured SLOWER (42.0 -> 43.6, 40.3 -> 42.2, 46.2 -> 47.0 us): off */
+#define DAM_RW2_SCHED_A() do { } while (0)
+#define DAM_RW2_SCHED_B()                                                                                                  \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 9 * TNB, 0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+#else
+#define DAM_RW2_SCHED_A() __builtin_amdgcn_sched_barrier(0)
+#define DAM_RW2_SCHED_B() __builtin_amdgcn_sched_barrier(0)
+#endif
         // column taps: odd-plane cell ow, even-plane cell ow, odd-plane cell ow + 1
 #define DAM_RW2_LOAD(T_, BUF_)                                                                                             \
     do {                                                                                                                   \
@@ -877,11 +912,11 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2G
         _Pragma("unroll") for (int t = 0; t < NS_; ++t) {                                                                  \
             if ((F_) > 1 && (SUB_) + (F_) * t >= STEPS) break;                                                             \
             if (t + 1 < NS_) DAM_RW2_LOAD((F_) * (t + 1), (t + 1) & 1);                                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            DAM_RW2_SCHED_A();                                                                                             \
             _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                             \
                 _Pragma("unroll") for (int tap = 0; tap < 9; ++tap)                                                        \
                     acc[nb * 9 + tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][nb], bv[t & 1][tap], acc[nb * 9 + tap], 0, 0, 0); \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            DAM_RW2_SCHED_B();                                                                                             \
         }                                                                                                                  \
     } while (0)
         for (int s = 0; s < n_slots2; ++s) {
@@ -897,6 +932,8 @@ __global__ __launch_bounds__(RW_THREADS) void wgrad_rows_s2_kernel(const RowsS2G
     }
 #undef DAM_RW2_ROW
 #undef DAM_RW2_LOAD
+#undef DAM_RW2_SCHED_A
+#undef DAM_RW2_SCHED_B
 #undef DAM_RW_ZERO
 
     // combine the 4 compute waves through LDS (sequential adds: fixed order), one slab per workgroup
