@@ -357,13 +357,30 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
             const int cnext = cg + 1 < nst ? ccur + KS * g.NBtot * 1024 : (kh * g.NBtot + nxt.nb0) * 1024;
             // the order below IS the software pipeline: without the scheduling barriers the compiler sinks every request to
             // just in front of its first use (fewer live registers) and the MFMAs wait for L2 on every item
+// Four-block items (five requests per 16 MFMAs): each request sits behind one of the item's first MFMAs instead of all five in
+// front of them -- 257 x 33 stage 53.8 -> 52.9 us over four runs; smaller items measured no different and keep the plain order.
+#define DAM_PIPE_SCHED_A()                                                                                                 \
+    do { if constexpr (NB < 4) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DAM_PIPE_SCHED_B()                                                                                                 \
+    do {                                                                                                                   \
+        if constexpr (NB >= 4) {                                                                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) {                                                            \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                         \
+            }                                                                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x100, MB, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * MB * NB, 0);                                                   \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
 #define DAM_PIPE_ITEM(SW_, CP_, TW_, SX_, TX_, SM_)                                                                        \
     do {                                                                                                                   \
         DAM_PIPE_W(SW_, CP_, TW_);                                                                                         \
         if ((TX_) >= 0) DAM_PIPE_X(SX_, (TX_) < 0 ? 0 : (TX_));                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        DAM_PIPE_SCHED_A();                                                                                                \
         DAM_PIPE_MFMA(SM_);                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        DAM_PIPE_SCHED_B();                                                                                                \
     } while (0)
 #define DAM_PIPE_ITEM9(T_)                                  /* X two taps ahead, MFMAs of tap T_, its set refilled from the next chunk */ \
     do {                                                                                                                   \
