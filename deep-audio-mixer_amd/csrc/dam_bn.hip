@@ -133,6 +133,10 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __re
     }
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c == 0 && lane == 0 && num_batches) *num_batches += 1;
+    // the channel's parameters and running statistics are requested together with the records: read behind the reduction
+    // (lane 0 only) they were a second memory round trip in a kernel that is nothing but round trips
+    const float gam_c = gamma[c], bet_c = beta[c];
+    const float rm_c = running_mean ? running_mean[c] : 0.f, rv_c = running_mean ? running_var[c] : 0.f;
     // Every lane requests ALL its records (<= 16: parts <= 1024) before it touches the first: the records come from other
     // XCDs' workgroups, each load is a memory-side round trip, and a load-merge-load chain made this 5 us kernel cost 5-7 us.
     // Merging is two plain wave reductions instead of a chain of Chan updates (no divide per record):
@@ -172,13 +176,13 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __re
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     save_mean[c] = mean;
     save_invstd[c] = invstd;
-    const float sc = gamma[c] * invstd;
+    const float sc = gam_c * invstd;
     scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
+    shift[c] = bet_c - mean * sc;
     if (running_mean) {
         const double unbiased = na > 1 ? qa / (na - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        running_mean[c] = (1.f - momentum) * rm_c + momentum * mean;
+        running_var[c] = (1.f - momentum) * rv_c + momentum * (float)unbiased;
     }
 }
 
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
                                        const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */) {
     const int c = blockIdx.x, lane = threadIdx.x;
+    const float gam_c = gamma[c], inv_c = invstd[c], mean_c = mean[c];      // (requested with the records, see bn_stats_finalize_kernel)
     double s1 = 0, s2 = 0;
     {   // all loads of the lane in flight before the first add (see bn_stats_finalize_kernel)
         constexpr int U = 16;
@@ -380,11 +385,11 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
     if (lane != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
-    const double g = (double)gamma[c] * invstd[c];
+    const double g = (double)gam_c * inv_c;
     double c2 = 0, c3 = 0;
     if (training) {
-        c2 = -g * invstd[c] * s2 / count;
-        c3 = -g * s1 / count - c2 * mean[c];
+        c2 = -g * inv_c * s2 / count;
+        c3 = -g * s1 / count - c2 * mean_c;
     }
     coef[c] = (float)g; coef[C + c] = (float)c2; coef[2 * C + c] = (float)c3;
 }
@@ -498,6 +503,8 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_pair_kernel(const float* _
                                                                   float* __restrict__ dgamma_b, float* __restrict__ dbeta_b,
                                                                   float* __restrict__ coef) {
     const int c = blockIdx.x, lane = threadIdx.x;
+    const float gam_a = gamma_a[c], inv_a = invstd_a[c], mu_a = mean_a[c];   // (requested with the records)
+    const float gam_b = gamma_b[c], inv_b = invstd_b[c], mu_b = mean_b[c];
     double s1 = 0, s2 = 0, s3 = 0;
     {   // all loads of the lane in flight before the first add (see bn_stats_finalize_kernel)
         constexpr int U = 16;
@@ -521,11 +528,11 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_pair_kernel(const float* _
     if (lane != 0) return;
     dbeta_a[c] = (float)s1; dbeta_b[c] = (float)s1;
     dgamma_a[c] = (float)s2; dgamma_b[c] = (float)s3;
-    const double ga = (double)gamma_a[c] * invstd_a[c], gb = (double)gamma_b[c] * invstd_b[c];
+    const double ga = (double)gam_a * inv_a, gb = (double)gam_b * inv_b;
     double a2 = 0, a3 = 0, b2 = 0, b3 = 0;
     if (training) {
-        a2 = -ga * invstd_a[c] * s2 / count; a3 = -ga * s1 / count - a2 * mean_a[c];
-        b2 = -gb * invstd_b[c] * s3 / count; b3 = -gb * s1 / count - b2 * mean_b[c];
+        a2 = -ga * inv_a * s2 / count; a3 = -ga * s1 / count - a2 * mu_a;
+        b2 = -gb * inv_b * s3 / count; b3 = -gb * s1 / count - b2 * mu_b;
     }
     coef[c] = (float)ga; coef[C + c] = (float)a2; coef[2 * C + c] = (float)a3;
     coef[3 * C + c] = (float)gb; coef[4 * C + c] = (float)b2; coef[5 * C + c] = (float)b3;
