@@ -26,7 +26,7 @@ torch.autograd.backward(boundary activation, its gradient, inputs=early paramete
 """
 import torch
 
-from . import distributed, features, ops
+from . import distributed, features, layers, ops
 
 
 class TrainStep:
@@ -55,6 +55,8 @@ class TrainStep:
         self.x = torch.empty((batch, n_stems, f, t), dtype=torch.float32, device=dev)
         self.gt = torch.empty((batch, f, t), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self._unit_seed = torch.ones((), dtype=torch.float32, device=dev)
+        setattr(self._unit_seed, layers.UNIT_SEED, True)
         self.use_graph = use_graph
         self._graphs = None
         self._steps_run = 0
@@ -118,10 +120,12 @@ class TrainStep:
         self._front_end()
         self.opt.zero_grad(set_to_none=True)
         loss, self.masked, self.gains = self.model.forward_mse(self.x, self.gt)
-        loss.backward()
+        loss.backward(self._unit_seed if loss.dim() == 0 else None)      # (no ones_like fill, no seed multiply: layers.UNIT_SEED)
         ops.side_stream_join(self.device)
         ops.wgrad_flush(self.device)                # every weight gradient's slab reduction, one launch
-        self.loss.copy_(loss.detach())
+        # the loss tensor itself is the step's output: inside a captured graph its address is fixed (the graph's pool keeps it
+        # while this reference lives), so no copy launch into a separate buffer
+        self.loss = loss.detach()
         self.opt.gather_grads()
 
     def _stage1(self):

@@ -207,6 +207,9 @@ def inference_mode(module):
     return not module.training and not torch.is_grad_enabled()
 
 
+UNIT_SEED = '_dam_unit_seed'        # attribute of a gradient seed tensor that is known to hold 1.0 (engine.TrainStep)
+
+
 class _UpstreamBn:
     """What the consumer of a relu(bn(c)) activation needs to take that BatchNorm's two backward sums in its own data-gradient
     epilogue (ops.conv2d_dgrad(bn_bwd=)), and the slot where it leaves them for the producer's backward.  Travels as an attribute
@@ -411,13 +414,18 @@ class HeadsMseFn(torch.autograd.Function):
         masked, loss, dg = ops.masksum_mse(x, g, gt.contiguous())
         ctx.save_for_backward(trunk, h, cw, fw, dg)
         ctx.mark_non_differentiable(masked, g)
+        ctx.set_materialize_grads(False)      # (two zero-fill launches per step for gradients nobody reads, one of them 4 MB)
         ctx.slots = (_slot(cw), _slot(cb), _slot(fw), _slot(fb))
         return loss.reshape(()), masked, g
 
     @staticmethod
     def backward(ctx, dloss, _dm, _dg):
         trunk, h, cw, fw, dg = ctx.saved_tensors
-        dtrunk, dcw, dcb, dfw, dfb = ops.heads_bwd(dg * dloss, h, trunk, cw, fw, outs=ctx.slots)
+        if dloss is None:
+            dloss = torch.zeros((), dtype=torch.float32, device=dg.device)
+        # engine.TrainStep seeds the backward pass with its own constant 1 (UNIT_SEED marks it): no multiply launch then
+        seed = dg if getattr(dloss, UNIT_SEED, False) else dg * dloss
+        dtrunk, dcw, dcb, dfw, dfb = ops.heads_bwd(seed, h, trunk, cw, fw, outs=ctx.slots)
         sl = ctx.slots
         return (dtrunk, None, None, None if sl[0] is not None else dcw, None if sl[1] is not None else dcb,
                 None if sl[2] is not None else dfw, None if sl[3] is not None else dfb)
