@@ -139,9 +139,12 @@ def test_full_resolution_layer1(ops):
 
 
 @pytest.mark.parametrize('B,C,H,W', [(2, 16, 23, 130), (1, 16, 9, 127), (2, 32, 21, 65), (1, 64, 19, 33), (3, 32, 4, 66),
-                                     (1, 64, 37, 31), (1, 16, 9, 216), (2, 32, 7, 108), (1, 64, 11, 54), (1, 16, 3, 213)])
+                                     (1, 64, 37, 31), (1, 16, 9, 216), (2, 32, 7, 108), (1, 64, 11, 54), (1, 16, 3, 213),
+                                     (8, 16, 165, 130), (2, 96, 33, 17), (1, 128, 65, 9), (2, 256, 33, 5)])
 def test_wgrad_row_streaming_shapes(ops, B, C, H, W):
-    """3x3 / stride 1 / pad 1 weight gradient at the widths of the ResNet stages (row-streaming kernel), ragged strips."""
+    """3x3 / stride 1 / pad 1 weight gradient at the widths of the ResNet stages (row-streaming kernel), ragged strips.
+    (8, 16, 165, 130): 32 strips of 5 or 6 rows per image -- last slots of ONE row, which the one-block tile splits over its four
+    waves by MFMA steps; 17-pixel rows: the four-loader-wave instantiation; 5-pixel rows: the tile kernel with a 176-pixel tile."""
     g = torch.Generator().manual_seed(B * 1000 + C + H + W)
     x = torch.randn(B, C, H, W, generator=g)
     dy = torch.randn(B, C, H, W, generator=g)
