@@ -472,3 +472,36 @@ def test_dgrad_identity_shortcut_with_upstream_sums(ops, B, C, H, W):
     dz = dx3.double() * (um > 0)
     for col, ref in ((0, dz.sum((0, 1, 2)).cpu()), (1, (dz * xhat).sum((0, 1, 2)).cpu())):
         assert (sums[:, col] - ref).abs().max().item() <= 2e-5 * n ** 0.5 * dz.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize('C,H,W', [(128, 65, 9), (256, 33, 5)])
+def test_loader_wave_kernel_k_split_matches_unsplit(ops, monkeypatch, C, H, W):
+    """The deep stages' one-block tile splits K over the wave pairs (32-pixel units, partial sums handed over through LDS).
+    At the benchmark's shapes (batch 8), with the fused input affine and the statistics epilogue: output and merged statistics
+    agree with the unsplit form (DAM_PIPE_KS=1) to float32 summation-order noise, and with float64."""
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(8, H, W, C, generator=g).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5))
+    wp = ops.pack_weights(w.cuda())
+    sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), (0.2 * torch.randn(C, generator=g)).cuda()
+    gamma, beta = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+
+    def run():
+        buf = ops.bn_partial_buffer(x.device, C).clone()
+        y, parts = ops.conv2d_fwd(x, wp, C, 3, 3, 1, 1, 1, in_scale=sc, in_shift=sh, relu_in=True, bn_partial=buf)
+        assert parts > 0
+        return y, ops.bn_finalize(buf, parts, gamma, beta, None, None, None, 0.1, 1e-5)
+
+    y2, st2 = run()
+    monkeypatch.setenv('DAM_PIPE_KS', '1')
+    y1, st1 = run()
+    monkeypatch.delenv('DAM_PIPE_KS')
+    a = torch.relu(x.double().cpu() * sc.double().cpu() + sh.double().cpu()).permute(0, 3, 1, 2)
+    want = torch.nn.functional.conv2d(a, w.double(), padding=1).permute(0, 2, 3, 1)
+    scale = want.abs().max().item()
+    assert (y2.double().cpu() - want).abs().max().item() <= 2e-6 * scale
+    assert (y2 - y1).abs().max().item() <= 2e-6 * scale
+    assert not torch.equal(y2, y1) or C < 32           # (two different summation orders: identical bits would mean one path ran twice)
+    for a2, a1 in zip(st2[:2], st1[:2]):                # save_mean, save_invstd
+        assert (a2 - a1).abs().max().item() <= 2e-6 * a1.abs().max().item()
+

@@ -66,6 +66,42 @@ def test_wav_partial_read(tmp_path):
         dataset_utils.load_tracks(str(tmp_path), 'A')                 # 8 kHz files asked for at 44.1 kHz
 
 
+def test_wav_native_reads_from_many_threads(tmp_path):
+    """read_wav_native(out=...) is the ingest path: positioned reads (os.preadv) on a cached descriptor straight into the
+    caller's buffer.  Eight threads read overlapping chunks of two files at once, every chunk must be the file's own samples
+    (a shared file position or a descriptor closed under a reader would show here); a rewritten file is read anew."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(11)
+    data = {}
+    for name, ch in (('a.wav', 2), ('b.wav', 1)):
+        x = rng.integers(-30000, 30000, (50000, ch), dtype=np.int16)
+        with wave.open(str(tmp_path / name), 'wb') as w:
+            w.setnchannels(ch), w.setsampwidth(2), w.setframerate(44100)
+            w.writeframes(x.tobytes())
+        data[name] = x
+
+    def one(i):
+        name = 'a.wav' if i % 2 else 'b.wav'
+        x = data[name]
+        lo = (i * 977) % 40000
+        out = np.empty((7001, x.shape[1]), dtype=np.int16)
+        got, rate = dataset_utils.read_wav_native(str(tmp_path / name), lo, lo + 7001, out=out)
+        return rate == 44100 and got is out and np.array_equal(out, x[lo:lo + 7001])
+
+    with ThreadPoolExecutor(8) as pool:
+        assert all(pool.map(one, range(200)))
+    # the same path with other contents (new size): the header and descriptor caches key on (path, mtime, size)
+    y = rng.integers(-100, 100, (1234, 2), dtype=np.int16)
+    with wave.open(str(tmp_path / 'a.wav'), 'wb') as w:
+        w.setnchannels(2), w.setsampwidth(2), w.setframerate(22050)
+        w.writeframes(y.tobytes())
+    out = np.empty((1000, 2), dtype=np.int16)
+    got, rate = dataset_utils.read_wav_native(str(tmp_path / 'a.wav'), 100, 1100, out=out)
+    assert rate == 22050 and np.array_equal(out, y[100:1100])
+    with pytest.raises(ValueError):                     # a chunk past the end of the data: short read, reported
+        dataset_utils.read_wav_native(str(tmp_path / 'a.wav'), 1000, 1300, out=np.empty((300, 2), dtype=np.int16))
+
+
 def test_wav_extensible_float_and_musdb_layout(tmp_path):
     """WAVE_FORMAT_EXTENSIBLE (24-bit) and IEEE-float files, which the stdlib wave module rejects, decode like
     soundfile; MUSDB18-HQ layout loader; split_songlist."""
