@@ -130,7 +130,7 @@ int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_tensors, int6
  *     bias + sum_{a<nA, b<nB, k} Wp[wt_base + a*wt_sa + b*wt_sb][k][:] *
  *            f(x[b, oh*in_stride + off_h + a*step_h, ow*in_stride + off_w + b*step_w, k])
  * for oh < Ho, ow < Wo, with x = 0 outside [0,H)x[0,W) and f(v) = v, or v*in_scale[k]+in_shift[k]
- * (then ReLU if relu_in) -- the producer's BatchNorm apply fused into the load -- and g(v) = v, or max(v, 0) if relu_out:
+ * (then ReLU if relu_in; without it the loaders clamp at -inf, so a NaN input reads as -inf) -- the producer's BatchNorm apply fused into the load -- and g(v) = v, or max(v, 0) if relu_out:
  * with an eval-mode BatchNorm folded into the weights (scale) and `bias` (shift), one launch is the reference's
  * relu(bn(conv(x)) [+ shortcut]) (models/model_resnet.py:23-28,97).
  *   x : NHWC [B][H][W][C] (C % 16 == 0, k_chunks == C/16), or with in_nchw=1 the reference's

@@ -505,3 +505,23 @@ def test_loader_wave_kernel_k_split_matches_unsplit(ops, monkeypatch, C, H, W):
     for a2, a1 in zip(st2[:2], st1[:2]):                # save_mean, save_invstd
         assert (a2 - a1).abs().max().item() <= 2e-6 * a1.abs().max().item()
 
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 16, 21, 130), (2, 32, 19, 65), (1, 64, 23, 33), (2, 128, 17, 9)])
+def test_fused_input_affine_without_relu(ops, B, C, H, W):
+    """in_scale / in_shift with relu_in = 0 (the loaders apply the ReLU as max(., lower bound) with the bound at -inf then):
+    forward and weight gradient of every loader family (strip, loader-wave tile, row-streaming weight gradient) against float64."""
+    g = torch.Generator().manual_seed(7 * C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    dy = torch.randn(B, C, H, W, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, 0.3 * torch.randn(C, generator=g)
+    a = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)           # negative values stay
+    assert (a < 0).any()
+    want = torch.nn.functional.conv2d(a, w.double(), padding=1)
+    got = ops.conv2d_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), C, 3, 3, 1, 1, 1, in_scale=sc.cuda(), in_shift=sh.cuda(),
+                         relu_in=False)
+    close(nchw(got), want, 2e-5)
+    want_dw = torch.nn.grad.conv2d_weight(a, w.shape, dy.double(), 1, 1)
+    got_dw = ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), C, 3, 3, 1, 1, 1, in_scale=sc.cuda(), in_shift=sh.cuda(), relu_in=False)
+    close(got_dw, want_dw, 5e-5)
+
