@@ -273,13 +273,15 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     const int lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp), 0, 0x7fffffff, 0x00020000);
     // Weight pipeline depth: an item is 4 * MB * NB MFMAs = 128 * MB * NB clocks of the matrix pipe.  Two items ahead (three
-    // rotating sets) cover an L2 hit (~700 clocks) only from four-block tiles up; the one- and two-block tiles of the small deep
-    // stages take NINE sets, one per tap: item T's MFMAs are followed by the request of tap T of the NEXT chunk into the same set,
-    // so every request has a whole chunk (1152 * MB * NB clocks) to land.
+    // rotating sets) cover an L2 hit (~700 clocks) only from four-block tiles up; the one-block tile of the small deep stages
+    // takes NINE sets, one per tap: item T's MFMAs are followed by the request of tap T of the NEXT chunk into the same set, so
+    // every request has a whole chunk (1152 clocks) to land.  (Measured: no difference on those stages -- a build whose weight
+    // loads all hit one 4 KB block is no faster either, the weights are not what they wait for -- so the two-block tiles, where
+    // nine sets cost 48 registers, keep three.)
 #ifdef DAM_PIPE_NO_W9
     constexpr bool W9 = false;
 #else
-    constexpr bool W9 = MB * NB <= 2;
+    constexpr bool W9 = MB * NB == 1;
 #endif
     constexpr int WSETS = W9 ? 9 : 3;
     v4f acc[MB][NB];
