@@ -648,7 +648,9 @@ int conv_pipe_try(ConvGeo g, int row_span, const float* X, const float* Wp, cons
     if (!MB) return DAM_ERR_UNSUPPORTED;
     // K split over the wave pairs (kernel comment): for one-block tiles that leave the chip fewer than three units per CU
     int KS = 1;
-    if (MB == 1 && NB == 1 && g.nchunks % 2 == 0 && cdiv(npix, 64) * nblk * g.B < 768) {
+    // (>= 2 stages per unit: the hand-over area of unit u + 1 is written in front of that unit's LAST barrier, which the reading
+    // waves of unit u pass only after their read -- with one stage per unit that barrier would also be the first)
+    if (MB == 1 && NB == 1 && g.nchunks % 2 == 0 && g.nchunks >= 4 && cdiv(npix, 64) * nblk * g.B < 768) {
         const int pr = patch_rows_px(32);
         if (pr * g.PWin * 8 <= PIPE_LT * 3 && (size_t)pr * g.PWT * 128 <= PIPE_BUF1) KS = 2;     // (three items per loader thread)
     }
