@@ -76,8 +76,25 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void head_bwd_pixel_kernel(const float* __restrict__ dg, const float* __restrict__ h,
                                                              int P, int C, int S, const float* __restrict__ cw,
                                                              const float* __restrict__ fcw, float* __restrict__ e_out,
-                                                             float* __restrict__ dtrunk) {
+                                                             float* __restrict__ dtrunk, int B, float* __restrict__ dfcw,
+                                                             float* __restrict__ dfcb) {
     extern __shared__ float w_s[];   // [S][C]
+    if (blockIdx.y == (unsigned)B) {
+        // the extra row of workgroups: the Linear layer's gradients (dfcw[s][p] = sum_b dg[b][s] * h[b][s][p], dfcb[s] = sum_b
+        // dg[b][s]) -- the same inputs, a launch of their own cost the step ~5 us for 1320 sums
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S * P; i += gridDim.x * blockDim.x) {
+            const int s = i / P, p = i - s * P;
+            float a = 0.f;
+            for (int bb = 0; bb < B; ++bb) a = fmaf(dg[bb * S + s], h[((size_t)bb * S + s) * P + p], a);
+            dfcw[i] = a;
+            if (i < S) {
+                float t = 0.f;
+                for (int bb = 0; bb < B; ++bb) t += dg[bb * S + i];
+                dfcb[i] = t;
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < S * C; e += blockDim.x) w_s[e] = cw[e];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
@@ -106,23 +123,6 @@ __global__ __launch_bounds__(256) void head_bwd_pixel_kernel(const float* __rest
             }
             row[q] = o;
         }
-    }
-}
-
-// dfcw[s][p] = sum_b dg[b][s] * h[b][s][p];  dfcb[s] = sum_b dg[b][s]
-__global__ void head_bwd_fc_kernel(const float* __restrict__ dg, const float* __restrict__ h, int B, int P, int S,
-                                   float* __restrict__ dfcw, float* __restrict__ dfcb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < S * P) {
-        const int s = i / P, p = i - s * P;
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a = fmaf(dg[b * S + s], h[((size_t)b * S + s) * P + p], a);
-        dfcw[i] = a;
-    }
-    if (i < S) {
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a += dg[b * S + i];
-        dfcb[i] = a;
     }
 }
 
@@ -306,16 +306,14 @@ extern "C" int dam_heads_bwd_f32(const float* dgains, const float* h, const floa
                                  float* dfc_w, float* dfc_b, float* workspace, void* stream) {
     if (!dgains || !h || !trunk || !conv_w || !fc_w || !dtrunk || !dconv_w || !dconv_b || !dfc_w || !dfc_b || !workspace)
         return DAM_ERR_BAD_ARG;
-    if (C % 16 || S < 1 || S > MAX_STEMS || B > 65535 || C > 1024) return DAM_ERR_UNSUPPORTED;
+    if (C % 16 || S < 1 || S > MAX_STEMS || B > 65534 || C > 1024) return DAM_ERR_UNSUPPORTED;   // (grid y = B + 1)
     hipStream_t st = (hipStream_t)stream;
     float* e = workspace;
     float* partial = workspace + (size_t)B * S * P;
     float* partial_b = partial + (size_t)1024 * S * C;
     const int gx = (int)(cdiv(P, 4) < 1024 ? cdiv(P, 4) : 1024);
-    hipLaunchKernelGGL(head_bwd_pixel_kernel, dim3(gx, B), dim3(256), (size_t)S * C * sizeof(float), st, dgains, h, P, C, S,
-                       conv_w, fc_w, e, dtrunk);
-    DAM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_bwd_fc_kernel, dim3((unsigned)cdiv((int64_t)S * P, 256)), dim3(256), 0, st, dgains, h, B, P, S, dfc_w, dfc_b);
+    hipLaunchKernelGGL(head_bwd_pixel_kernel, dim3(gx, B + 1), dim3(256), (size_t)S * C * sizeof(float), st, dgains, h, P, C, S,
+                       conv_w, fc_w, e, dtrunk, B, dfc_w, dfc_b);       // (row B of the grid: the Linear layer's gradients)
     DAM_CHECK_LAUNCH();
     const int Q = C / 4;
     int R = 256 / Q; if (R < 1) R = 1;
