@@ -533,12 +533,15 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
         // operand reads of step t + 1 against the MFMAs of step t: one read behind each of the first MFMAs (as a burst in front
         // of them -- build flag DAM_WGR_NO_INTERLEAVE, scheduling barriers only -- the launch is 1.3-1.6 us slower: the pipe drains
         // while seven reads issue)
+#ifndef DAM_WGR_IL_STRIDE
+#define DAM_WGR_IL_STRIDE (NL == 4 ? 2 : 1)   /* MFMAs between two operand reads: 2 measured -1.1 us on the four-loader 129x17 kernel, +0.5 us on the others */
+#endif
 #ifndef DAM_WGR_NO_INTERLEAVE
 #define DAM_RW_SCHED_A() do { } while (0)
 #define DAM_RW_SCHED_B()                                                                                                   \
     do {                                                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, DAM_WGR_IL_STRIDE, 0);                                             \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
         }                                                                                                                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 9 * TNB * TKB, 0);                                                     \
