@@ -361,6 +361,38 @@ def dist_env():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
 
 
+def replica_sync_proof(model, opt, device, dev_index, world):
+    """After the timed steps every rank all-gathers (a) a checksum of the optimizer's flat PARAMETER buffer -- identical
+    only if every step's gradients were summed over all ranks: each rank trains on its own clips -- (b) a checksum of the
+    first BatchNorm's running mean (local statistics: expected to DIFFER between ranks, reported, not required), (c) which
+    physical device it ran on (index, PCI bus id, uuid where the runtime gives one).  World size 1: all None."""
+    import torch
+    if world <= 1:
+        return {'replicas_in_sync': None, 'checksums': None, 'devices': None}
+    flat = opt._flat.detach()
+    ints = flat.view(torch.int32).to(torch.int64)
+    # order-sensitive 64-bit checksum of the raw parameter bits (position-weighted sum, exact in int64 arithmetic mod 2^64)
+    w = torch.arange(1, ints.numel() + 1, device=device, dtype=torch.int64)
+    mine = torch.stack([(ints * w).sum(), ints.sum(),
+                        next(b for n, b in model.named_buffers() if n.endswith('running_mean')).detach().double().sum().mul(1e6).round().to(torch.int64)])
+    if torch.distributed.get_backend() != 'nccl':      # gloo rehearsal: its CUDA path stalls behind busy streams (DESIGN section 5)
+        torch.cuda.synchronize()
+        mine = mine.cpu()
+    allc = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(allc, mine)
+    props = torch.cuda.get_device_properties(dev_index)
+    ident = {'device_index': dev_index, 'name': props.name, 'uuid': str(getattr(props, 'uuid', '')),
+             'pci_bus_id': getattr(props, 'pci_bus_id', None), 'pci_device_id': getattr(props, 'pci_device_id', None)}
+    idents = [None] * world
+    torch.distributed.all_gather_object(idents, ident)
+    rows = [[int(v) for v in c.tolist()] for c in allc]
+    in_sync = all(r[:2] == rows[0][:2] for r in rows)
+    return {'replicas_in_sync': bool(in_sync),
+            'checksums': {'flat_params_weighted': [r[0] for r in rows], 'flat_params_sum': [r[1] for r in rows],
+                          'bn_running_mean_sum_x1e6 (local statistics, may differ)': [r[2] for r in rows]},
+            'devices': idents}
+
+
 def run_train(name, cfg, args):
     import torch
     rank, world, local = dist_env()
@@ -451,6 +483,7 @@ def run_train(name, cfg, args):
     else:
         allr = [(rank_ms, exposed)]
     gflop_step = cfg['gflop_fwd'] * 2.98 * B            # fwd+bwd algorithmic FLOPs per rank and step (SURVEY 8d ratio)
+    sync = replica_sync_proof(model, opt, device, dev_index, world)
 
     result = {
         'metric': 'stem-spectrogram-frames/sec (train)', 'value': value, 'unit': 'stem-spectrogram-frames/s',
@@ -461,6 +494,10 @@ def run_train(name, cfg, args):
                    'dist_backend': (backend if world > 1 else None),
                    'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == 'nccl' else None,
                    'grad_buckets': opt.n_buckets, 'allreduce_overlap': bool(step.staged),
+                   # N > 1: proof that the ranks were N distinct devices and that the all-reduce averaged -- replicas that
+                   # each saw DIFFERENT clips hold bit-identical parameters after the timed steps (None on one rank)
+                   'replicas_in_sync': sync['replicas_in_sync'], 'replica_checksums': sync['checksums'],
+                   'rank_devices': sync['devices'],
                    # the reference loop reads loss.item() every batch (model_trainer.py:41,43); the timed region here does not
                    # (throughput metric): the host only enqueues graph replays.  `--via-trainer` times the loop WITH the sync.
                    'sync_per_step': False},
@@ -554,10 +591,14 @@ def run_via_trainer(name, cfg, args):
     n_songs, chunks = 8, 48                                      # 384 clips = 48 batches of 8 per epoch (1.8 GB of 16-bit PCM)
     songs, tracklist = _synthetic_songs(cfg, n_songs, chunks, pcm16=not args.float_pcm)
     ds = MultitrackAudioDataset.from_arrays(songs, chunk_length=cfg['seconds'], sr=cfg['sr'], tracklist=tracklist, seed=1)
-    train = ds.batch_loader(B, drop_last=True, workers=args.workers)
-    val = ds.batch_loader(B, indices=list(range(B)), workers=args.workers)
+    # the loader hands ModelTrainer the uploaded PCM (PcmBatch): the captured step contains the front-end and reads it in
+    # place; --feature-loader: the round-3 arrangement (front-end per batch on the copy stream, features copied into the step)
+    pcm_fed = not args.feature_loader
+    train = ds.batch_loader(B, drop_last=True, workers=args.workers, pcm=pcm_fed)
+    val = ds.batch_loader(B, indices=list(range(B)), workers=args.workers, pcm=pcm_fed)
     model = build_model(cfg, device)
-    opt = Adam(model.parameters(), weight_decay=1e-5)
+    # training.ipynb cell 11, as written: torch's own Adam -- ModelTrainer adopts it into the fused launch
+    opt = Adam(model.parameters(), weight_decay=1e-5) if args.own_adam else torch.optim.Adam(model.parameters(), weight_decay=1e-5)
     trainer = ModelTrainer(model, torch.nn.MSELoss(), opt, device, model_name='bench')
     epoch_s = []
     inner = trainer._train_epoch
@@ -595,6 +636,8 @@ def run_via_trainer(name, cfg, args):
         'config': {'workload': cfg['workload'] + ' -- through ModelTrainer.fit(Dataset.batch_loader(8)) from in-memory songs (%s)' % ('float32' if args.float_pcm else '16-bit PCM'),
                    'sync_per_step': 'every batch\'s loss is read on the host and logged, one batch late (ModelTrainer._run)',
                    'decode_threads': args.workers, 'pcm': 'float32' if args.float_pcm else 'int16 (16-bit PCM)',
+                   'optimizer_passed': 'deep_audio_mixer_amd.optim.Adam' if args.own_adam else 'torch.optim.Adam (adopted by ModelTrainer)',
+                   'loader': 'PcmBatch (front-end inside the captured step)' if pcm_fed else 'features (front-end per batch on the copy stream)',
                    'graph_steps': trainer.graph_steps,
                    'eager_steps': trainer.eager_steps, 'epochs_timed': n_epochs, 'batches_per_epoch': len(train),
                    'ms_per_step_incl_validation_and_checkpoint': 1e3 * fit_s / steps, 'final_train_loss': tl[-1]}}), flush=True)
@@ -767,6 +810,8 @@ def main():
                     help='diagnostic line: frames/s of WAV files -> decode threads -> pinned -> H2D -> STFT (iter_batches)')
     ap.add_argument('--workers', type=int, default=8, help='--ingest / --via-trainer: decode threads')
     ap.add_argument('--float-pcm', action='store_true', help='--via-trainer: float32 in-memory songs instead of 16-bit PCM')
+    ap.add_argument('--feature-loader', action='store_true', help='--via-trainer: loader yields features (round-3 arrangement)')
+    ap.add_argument('--own-adam', action='store_true', help='--via-trainer: pass optim.Adam instead of torch.optim.Adam')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')

@@ -15,6 +15,7 @@
 //     both BasicBlock shortcuts (identity, or the shortcut conv's own BatchNorm folded in);
 //   * backward: one reduction pass (sum dz, sum dz*xhat; dz = dy * (y > 0)) and one apply pass
 //     dx = c1*dz + c2*x + c3 with per-channel constants.
+#include <cstdlib>
 #include "dam_common.h"
 #include "dam_bn_fin.h"
 
@@ -26,14 +27,14 @@ static_assert(BN_MAX_PARTS == BN_BWD_RECORDS_MAX, "records a data-gradient epilo
 
 struct BnLaunch { int threads, q, r, parts; int64_t ppb; };
 
-inline BnLaunch bn_plan(int64_t P, int C) {
+inline BnLaunch bn_plan(int64_t P, int C, int max_parts = BN_MAX_PARTS) {
     BnLaunch l;
     l.q = C / 4;
     l.r = 256 / l.q;
     if (l.r < 1) l.r = 1;
     l.threads = l.q * l.r;
     int64_t parts = cdiv(P, (int64_t)l.r * 16);          // ~16 pixels (two batches of 8 loads) per thread
-    if (parts > BN_MAX_PARTS) parts = BN_MAX_PARTS;
+    if (parts > max_parts) parts = max_parts;
     if (parts < 1) parts = 1;
     l.ppb = cdiv(P, parts);
     l.parts = (int)cdiv(P, l.ppb);
@@ -606,9 +607,321 @@ __global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const float* _
     if (lane == 0) out[c] = (float)s;
 }
 
+// ================================================================================================================================
+// Finalize INSIDE the elementwise consumer (round 4).  A finalize launch is 4.6-5 us whatever it does and a ResNet18 step had fifty of
+// them; round 3's attempt to merge the records in every workgroup of the 4096-workgroup apply launches lost to the table traffic
+// (every workgroup re-read every channel's records: ~6 M cache-line requests per launch).  What makes it pay:
+//   * the grid is what the chip holds (<= 512 workgroups), each workgroup walks a contiguous pixel range, and
+//   * a workgroup only merges the channels it applies: workgroup (slice, range) owns CS = 16 or 32 channels, so its table is
+//     parts x CS records (<= ~100 KB, usually 20-60), requested in one burst behind the workgroup's first data loads;
+//   * the merge is one pass in double around a pivot (record 0's mean): N = sum n, S = sum n (mean - m0),
+//     Q = sum (M2 + n (mean - m0)^2); mean = m0 + S / N, M2 = Q - S^2 / N -- the shifted-data form of the pooled variance, exact to
+//     double rounding (no Chan chain, no second pass over the records);
+//   * range 0 of every slice writes what later kernels read (save_mean, save_invstd, scale, shift, the running statistics;
+//     dgamma / dbeta in the backward form).
+// The records' producers ran in earlier launches (the kernel boundary is the synchronisation), so plain loads are fine.
+// ================================================================================================================================
+#define DAM_Z4 make_float4(0.f, 0.f, 0.f, 0.f)
+constexpr int FA_THREADS = 256;
+constexpr int FA_U = 4;                 // pixel pieces in flight per thread and stream
+
+struct FaPlan { int cs, nslices, nranges, q, ppi; int64_t ppr; };
+
+// CS: the whole row for thin layers (one 128-byte line per pixel at 32 channels), 16-channel slices above that (64-byte pieces:
+// the wide layers' tensors are small and L2 resident; what matters there is the table a workgroup has to merge)
+inline FaPlan fa_plan(int64_t P, int C, int parts, int rec_floats) {
+    FaPlan f;
+    f.cs = C <= 32 ? C : 16;
+    // a slice table beyond ~96 KB costs more to read than it saves: narrower slices are not possible (16 = one MFMA block of
+    // channels everywhere else in this library), so callers keep `parts` bounded (dam_bn_backward_f32 caps its own partial pass)
+    (void)parts; (void)rec_floats;
+    f.nslices = C / f.cs;
+    f.q = f.cs / 4;
+    f.ppi = FA_THREADS / f.q;
+    int64_t want = P / ((int64_t)f.ppi * FA_U * 2);       // >= two batches of loads per thread
+    const int64_t cap = 512 / f.nslices > 0 ? 512 / f.nslices : 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    f.ppr = cdiv(P, want);
+    f.nranges = (int)cdiv(P, f.ppr);
+    return f;
+}
+
+// Sums NV per-record values over the slice's records: thread (c = tid % CS, i = tid / CS) takes records i, i + TPC, ...;
+// tid < CS ends up with the channel's totals in acc[].  `term(rec, v)` turns one record (NR floats) into its NV addends.
+template <int NR, int NV, typename F>
+__device__ __forceinline__ void fa_slice_sums(const float* __restrict__ partial, int parts, int C, int ch, int CS, double* red,
+                                              double (&acc)[NV], F term) {
+    const int tid = threadIdx.x, TPC = FA_THREADS / CS, i0 = tid / CS;
+    constexpr int RU = 8;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0;
+    for (int p0 = i0; p0 < parts; p0 += TPC * RU) {
+        float rec[RU][NR];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int p = p0 + u * TPC;
+            const float* o = partial + ((size_t)(p < parts ? p : i0) * C + ch) * NR;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) rec[u][k] = o[k];
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+            if (p0 + u * TPC < parts) {
+                double v[NV];
+                term(rec[u], v);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) acc[k] += v[k];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[tid * NV + k] = acc[k];
+    __syncthreads();
+    if (tid < CS)
+        for (int i = 1; i < TPC; ++i)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] += red[(tid + i * CS) * NV + k];
+}
+
+__global__ __launch_bounds__(FA_THREADS) void bn_fin_apply_kernel(const float* __restrict__ partial, int parts, int C, int CS,
+                                                                   const BnFinArgs fin, const float* __restrict__ x, int64_t P,
+                                                                   int64_t ppr, const float* __restrict__ res,
+                                                                   const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                                   int relu, float* __restrict__ y, unsigned char* __restrict__ sign_bits) {
+    __shared__ double red[FA_THREADS * 3];
+    __shared__ __attribute__((aligned(16))) float tab[2 * 32];
+    const int tid = threadIdx.x, slice = blockIdx.y, q = CS / 4, tq = tid % q, tp = tid / q, ppi = FA_THREADS / q;
+    const int Q = C / 4, cq = slice * q + tq;
+    const int64_t lo = blockIdx.x * ppr, hi = (lo + ppr < P) ? lo + ppr : P;
+    // the first pieces are requested before the records: the table's round trip hides behind them
+    float4 xv[FA_U], rv[FA_U];
+#pragma unroll
+    for (int u = 0; u < FA_U; ++u) {
+        const int64_t p = lo + tp + (int64_t)u * ppi;
+        xv[u] = p < hi ? reinterpret_cast<const float4*>(x)[p * Q + cq] : DAM_Z4;
+        rv[u] = (res && p < hi) ? reinterpret_cast<const float4*>(res)[p * Q + cq] : DAM_Z4;
+    }
+    float4 ra = make_float4(1.f, 1.f, 1.f, 1.f), rb = DAM_Z4;
+    if (rscale) { ra = reinterpret_cast<const float4*>(rscale)[cq]; rb = reinterpret_cast<const float4*>(rshift)[cq]; }
+    {
+        const int cl = tid % CS, ch = slice * CS + cl;
+        const float m0 = partial[(size_t)ch * 3 + 1];
+        const float gam = fin.gamma[ch], bet = fin.beta[ch];
+        const bool writer = blockIdx.x == 0 && tid < CS;
+        const float rm = (writer && fin.running_mean) ? fin.running_mean[ch] : 0.f, rvv = (writer && fin.running_mean) ? fin.running_var[ch] : 0.f;
+        double acc[3];
+        fa_slice_sums<3, 3>(partial, parts, C, ch, CS, red, acc, [m0](const float (&r)[3], double (&v)[3]) {
+            const double n = (double)r[0], d = (double)r[1] - (double)m0;
+            v[0] = n; v[1] = n * d; v[2] = n != 0.0 ? (double)r[2] + n * d * d : 0.0;
+        });
+        if (tid < CS) {
+            const double na = acc[0], ds = acc[1] / na, qa = acc[2] - acc[1] * ds;
+            const double var = qa / na;
+            const float mean = (float)((double)m0 + ds);
+            const float invstd = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + (double)fin.eps));
+            const float sc = gam * invstd, sh = bet - mean * sc;
+            tab[cl] = sc; tab[CS + cl] = sh;
+            if (writer) {
+                fin.save_mean[ch] = mean; fin.save_invstd[ch] = invstd; fin.scale[ch] = sc; fin.shift[ch] = sh;
+                if (fin.running_mean) {
+                    const double unbiased = na > 1 ? (qa > 0 ? qa : 0.0) / (na - 1) : var;
+                    fin.running_mean[ch] = (1.f - fin.momentum) * rm + fin.momentum * mean;
+                    fin.running_var[ch] = (1.f - fin.momentum) * rvv + fin.momentum * (float)unbiased;
+                }
+                if (ch == 0 && fin.num_batches) *fin.num_batches += 1;
+            }
+        }
+        __syncthreads();
+    }
+    const float4 sc = *reinterpret_cast<const float4*>(tab + tq * 4), sh = *reinterpret_cast<const float4*>(tab + CS + tq * 4);
+    for (int64_t p0 = lo + tp;;) {
+#pragma unroll
+        for (int u = 0; u < FA_U; ++u) {
+            const int64_t p = p0 + (int64_t)u * ppi;
+            if (p >= hi) continue;
+            const float4 v = xv[u];
+            float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+            if (res) {
+                float4 r = rv[u];
+                if (rscale) r = make_float4(fmaf(r.x, ra.x, rb.x), fmaf(r.y, ra.y, rb.y), fmaf(r.z, ra.z, rb.z), fmaf(r.w, ra.w, rb.w));
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            reinterpret_cast<float4*>(y)[p * Q + cq] = o;
+            if (sign_bits) sign_bits[p * Q + cq] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
+        }
+        p0 += (int64_t)ppi * FA_U;
+        if (p0 >= hi) break;
+#pragma unroll
+        for (int u = 0; u < FA_U; ++u) {
+            const int64_t p = p0 + (int64_t)u * ppi;
+            xv[u] = p < hi ? reinterpret_cast<const float4*>(x)[p * Q + cq] : DAM_Z4;
+            rv[u] = (res && p < hi) ? reinterpret_cast<const float4*>(res)[p * Q + cq] : DAM_Z4;
+        }
+    }
+}
+
+// Backward: records [parts][C][2] = (sum dz, sum dz * xhat) -> dgamma / dbeta (range 0 writes them) and dx = c1 dz + c2 x + c3.
+template <int MASK>
+__global__ __launch_bounds__(FA_THREADS) void bn_bwd_fin_apply_kernel(const float* __restrict__ partial, int parts, int C, int CS,
+                                                                       double count, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                       int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                       const float* __restrict__ dy, const float* __restrict__ y_mask,
+                                                                       const float* __restrict__ x, int64_t P, int64_t ppr,
+                                                                       const float* __restrict__ mscale, const float* __restrict__ mshift,
+                                                                       float* __restrict__ dx) {
+    __shared__ double red[FA_THREADS * 2];
+    __shared__ __attribute__((aligned(16))) float tab[3 * 32];
+    const int tid = threadIdx.x, slice = blockIdx.y, q = CS / 4, tq = tid % q, tp = tid / q, ppi = FA_THREADS / q;
+    const int Q = C / 4, cq = slice * q + tq;
+    const int64_t lo = blockIdx.x * ppr, hi = (lo + ppr < P) ? lo + ppr : P;
+    float4 gv[FA_U], xv[FA_U], mv[FA_U];
+#define DAM_FA_BWD_LOAD(P0_)                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < FA_U; ++u) {                                                                        \
+        const int64_t p = (P0_) + (int64_t)u * ppi;                                                                           \
+        const bool ok = p < hi;                                                                                               \
+        gv[u] = ok ? reinterpret_cast<const float4*>(dy)[p * Q + cq] : DAM_Z4;                                                    \
+        xv[u] = ok ? reinterpret_cast<const float4*>(x)[p * Q + cq] : DAM_Z4;                                                     \
+        if (MASK == 1) mv[u] = ok ? reinterpret_cast<const float4*>(y_mask)[p * Q + cq] : DAM_Z4;                                 \
+        if (MASK == 3) mv[u] = sign_quad(ok ? reinterpret_cast<const unsigned char*>(y_mask)[p * Q + cq] : 0);                \
+    }
+    DAM_FA_BWD_LOAD(lo + tp)
+    float4 msc = DAM_Z4, msh = DAM_Z4;
+    if (MASK == 2) { msc = reinterpret_cast<const float4*>(mscale)[cq]; msh = reinterpret_cast<const float4*>(mshift)[cq]; }
+    {
+        const int cl = tid % CS, ch = slice * CS + cl;
+        const float gam = gamma[ch], inv = invstd[ch], mu = mean[ch];
+        double acc[2];
+        fa_slice_sums<2, 2>(partial, parts, C, ch, CS, red, acc, [](const float (&r)[2], double (&v)[2]) { v[0] = (double)r[0]; v[1] = (double)r[1]; });
+        if (tid < CS) {
+            const double s1 = acc[0], s2 = acc[1];
+            const double g = (double)gam * inv;
+            double c2 = 0, c3 = 0;
+            if (training) { c2 = -g * inv * s2 / count; c3 = -g * s1 / count - c2 * mu; }
+            tab[cl] = (float)g; tab[CS + cl] = (float)c2; tab[2 * CS + cl] = (float)c3;
+            if (blockIdx.x == 0) { dbeta[ch] = (float)s1; dgamma[ch] = (float)s2; }
+        }
+        __syncthreads();
+    }
+    const float4 c1 = *reinterpret_cast<const float4*>(tab + tq * 4), c2 = *reinterpret_cast<const float4*>(tab + CS + tq * 4),
+                 c3 = *reinterpret_cast<const float4*>(tab + 2 * CS + tq * 4);
+    for (int64_t p0 = lo + tp;;) {
+#pragma unroll
+        for (int u = 0; u < FA_U; ++u) {
+            const int64_t p = p0 + (int64_t)u * ppi;
+            if (p >= hi) continue;
+            float4 g = gv[u];
+            const float4 v = xv[u];
+            if (MASK != 0) {
+                float4 m = mv[u];
+                if (MASK == 2) m = make_float4(fmaf(v.x, msc.x, msh.x), fmaf(v.y, msc.y, msh.y), fmaf(v.z, msc.z, msh.z), fmaf(v.w, msc.w, msh.w));
+                g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+            }
+            float4 o;
+            o.x = fmaf(c1.x, g.x, fmaf(c2.x, v.x, c3.x)); o.y = fmaf(c1.y, g.y, fmaf(c2.y, v.y, c3.y));
+            o.z = fmaf(c1.z, g.z, fmaf(c2.z, v.z, c3.z)); o.w = fmaf(c1.w, g.w, fmaf(c2.w, v.w, c3.w));
+            reinterpret_cast<float4*>(dx)[p * Q + cq] = o;
+        }
+        p0 += (int64_t)ppi * FA_U;
+        if (p0 >= hi) break;
+        DAM_FA_BWD_LOAD(p0)
+    }
+#undef DAM_FA_BWD_LOAD
+}
+
+// The pair form (a residual block's bn2 and its shortcut BatchNorm): records [parts][C][3] = (sum dz, sum dz xhat_a, sum dz xhat_b).
+template <bool BITS>
+__global__ __launch_bounds__(FA_THREADS) void bn_bwd_fin_apply_pair_kernel(const float* __restrict__ partial, int parts, int C, int CS,
+        double count, const float* __restrict__ gamma_a, const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
+        const float* __restrict__ gamma_b, const float* __restrict__ mean_b, const float* __restrict__ invstd_b, int training,
+        float* __restrict__ dgamma_a, float* __restrict__ dbeta_a, float* __restrict__ dgamma_b, float* __restrict__ dbeta_b,
+        const float* __restrict__ dy, const float* __restrict__ y_mask, const float* __restrict__ xa, const float* __restrict__ xb,
+        int64_t P, int64_t ppr, float* __restrict__ dxa, float* __restrict__ dxb) {
+    __shared__ double red[FA_THREADS * 3];
+    __shared__ __attribute__((aligned(16))) float tab[6 * 32];
+    const int tid = threadIdx.x, slice = blockIdx.y, q = CS / 4, tq = tid % q, tp = tid / q, ppi = FA_THREADS / q;
+    const int Q = C / 4, cq = slice * q + tq;
+    const int64_t lo = blockIdx.x * ppr, hi = (lo + ppr < P) ? lo + ppr : P;
+    constexpr int UP = 2;               // four streams: two pieces each in flight
+    float4 gv[UP], va[UP], vb[UP], mv[UP];
+#define DAM_FA_PAIR_LOAD(P0_)                                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                                          \
+        const int64_t p = (P0_) + (int64_t)u * ppi;                                                                           \
+        const bool ok = p < hi;                                                                                               \
+        gv[u] = ok ? reinterpret_cast<const float4*>(dy)[p * Q + cq] : DAM_Z4;                                                    \
+        va[u] = ok ? reinterpret_cast<const float4*>(xa)[p * Q + cq] : DAM_Z4;                                                    \
+        vb[u] = ok ? reinterpret_cast<const float4*>(xb)[p * Q + cq] : DAM_Z4;                                                    \
+        if (BITS) mv[u] = sign_quad(ok ? reinterpret_cast<const unsigned char*>(y_mask)[p * Q + cq] : 0);                     \
+        else mv[u] = ok ? reinterpret_cast<const float4*>(y_mask)[p * Q + cq] : DAM_Z4;                                           \
+    }
+    DAM_FA_PAIR_LOAD(lo + tp)
+    {
+        const int cl = tid % CS, ch = slice * CS + cl;
+        const float ga_ = gamma_a[ch], ia = invstd_a[ch], ma = mean_a[ch], gb_ = gamma_b[ch], ib = invstd_b[ch], mb = mean_b[ch];
+        double acc[3];
+        fa_slice_sums<3, 3>(partial, parts, C, ch, CS, red, acc,
+                            [](const float (&r)[3], double (&v)[3]) { v[0] = (double)r[0]; v[1] = (double)r[1]; v[2] = (double)r[2]; });
+        if (tid < CS) {
+            const double s1 = acc[0], s2 = acc[1], s3 = acc[2];
+            const double ga = (double)ga_ * ia, gb = (double)gb_ * ib;
+            double a2 = 0, a3 = 0, b2 = 0, b3 = 0;
+            if (training) {
+                a2 = -ga * ia * s2 / count; a3 = -ga * s1 / count - a2 * ma;
+                b2 = -gb * ib * s3 / count; b3 = -gb * s1 / count - b2 * mb;
+            }
+            tab[cl] = (float)ga; tab[CS + cl] = (float)a2; tab[2 * CS + cl] = (float)a3;
+            tab[3 * CS + cl] = (float)gb; tab[4 * CS + cl] = (float)b2; tab[5 * CS + cl] = (float)b3;
+            if (blockIdx.x == 0) {
+                dbeta_a[ch] = (float)s1; dbeta_b[ch] = (float)s1; dgamma_a[ch] = (float)s2; dgamma_b[ch] = (float)s3;
+            }
+        }
+        __syncthreads();
+    }
+    float4 k[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) k[i] = *reinterpret_cast<const float4*>(tab + i * CS + tq * 4);
+    for (int64_t p0 = lo + tp;;) {
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int64_t p = p0 + (int64_t)u * ppi;
+            if (p >= hi) continue;
+            float4 g = gv[u];
+            const float4 m = mv[u], v = va[u], w = vb[u];
+            g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+            float4 o, r;
+            o.x = fmaf(k[0].x, g.x, fmaf(k[1].x, v.x, k[2].x)); o.y = fmaf(k[0].y, g.y, fmaf(k[1].y, v.y, k[2].y));
+            o.z = fmaf(k[0].z, g.z, fmaf(k[1].z, v.z, k[2].z)); o.w = fmaf(k[0].w, g.w, fmaf(k[1].w, v.w, k[2].w));
+            r.x = fmaf(k[3].x, g.x, fmaf(k[4].x, w.x, k[5].x)); r.y = fmaf(k[3].y, g.y, fmaf(k[4].y, w.y, k[5].y));
+            r.z = fmaf(k[3].z, g.z, fmaf(k[4].z, w.z, k[5].z)); r.w = fmaf(k[3].w, g.w, fmaf(k[4].w, w.w, k[5].w));
+            reinterpret_cast<float4*>(dxa)[p * Q + cq] = o;
+            reinterpret_cast<float4*>(dxb)[p * Q + cq] = r;
+        }
+        p0 += (int64_t)ppi * UP;
+        if (p0 >= hi) break;
+        DAM_FA_PAIR_LOAD(p0)
+    }
+#undef DAM_FA_PAIR_LOAD
+}
+
+#undef DAM_Z4
 inline int elt_blocks(int64_t n) {
     int64_t b = cdiv(n, 256);
     return (int)(b < 4096 ? (b < 1 ? 1 : b) : 4096);
+}
+
+// DAM_BN_FUSED_FIN=0 keeps the separate finalize launches (A/B switch, read once)
+inline bool fa_enabled() {
+    static const bool on = [] { const char* e = getenv("DAM_BN_FUSED_FIN"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// records a partial pass may leave for a fused consumer: a workgroup's slice table stays <= 64 KB
+inline int fa_max_parts(int C, int rec_floats) {
+    const int cs = C <= 32 ? C : 16;
+    int m = 65536 / (cs * rec_floats * 4);
+    if (m > BN_MAX_PARTS) m = BN_MAX_PARTS;
+    return m < 64 ? 64 : m;
 }
 
 }  // namespace
@@ -617,6 +930,46 @@ inline int elt_blocks(int64_t n) {
 using namespace dam;
 
 extern "C" int64_t dam_bn_workspace_floats(int C) { return (int64_t)BN_RECORDS_MAX * C * 3; }
+
+// First half of dam_bn_stats_f32 on its own: the partial records [*parts_host][C][3], sized for a fused consumer
+// (dam_bn_finalize_apply_f32) -- or for dam_bn_finalize_f32.
+extern "C" int dam_bn_stats_partial_f32(const float* x, int64_t n_pixels, int C, float* workspace, int* parts_host, void* stream) {
+    if (!x || !workspace || !parts_host || n_pixels <= 0) return DAM_ERR_BAD_ARG;
+    if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
+    const BnLaunch l = bn_plan(n_pixels, C, fa_max_parts(C, 3));
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), (hipStream_t)stream,
+                       x, n_pixels, C, l.q, l.r, l.ppb, workspace, BnFinArgs{}, (const float*)nullptr, (float*)nullptr);
+    DAM_CHECK_LAUNCH();
+    *parts_host = l.parts;
+    return DAM_OK;
+}
+
+// Finalize + apply in one launch: merges `parts` records [parts][C][3] (a convolution epilogue's, dam_bn_stats_partial_f32's)
+// exactly as dam_bn_finalize_f32 does -- fin's outputs and running statistics are written -- and applies
+// y = relu?(x * scale + shift [+ res [* res_scale + res_shift]]) [+ sign bytes] as dam_bn_apply_f32 does.
+extern "C" int dam_bn_finalize_apply_f32(const float* partial, int parts, int C, const dam_bn_fin* fin, const float* x,
+                                         int64_t n_pixels, const float* res, const float* res_scale, const float* res_shift,
+                                         int relu, float* y, uint8_t* sign_bits, void* stream) {
+    if (!partial || parts <= 0 || !fin || !x || !y || n_pixels <= 0) return DAM_ERR_BAD_ARG;
+    if (!fin->gamma || !fin->beta || !fin->save_mean || !fin->save_invstd || !fin->scale || !fin->shift) return DAM_ERR_BAD_ARG;
+    if (res_scale && (!res || !res_shift)) return DAM_ERR_BAD_ARG;
+    if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (!fa_enabled()) {
+        int rc = dam_bn_finalize_f32(partial, parts, C, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
+                                     fin->num_batches_tracked, fin->momentum, fin->eps, fin->save_mean, fin->save_invstd, fin->scale,
+                                     fin->shift, stream);
+        if (rc != DAM_OK) return rc;
+        return dam_bn_apply_f32(x, n_pixels, C, fin->scale, fin->shift, res, res_scale, res_shift, relu, y, sign_bits, stream);
+    }
+    const FaPlan f = fa_plan(n_pixels, C, parts, 3);
+    const BnFinArgs a{fin->gamma, fin->beta, fin->running_mean, fin->running_var, (long long*)fin->num_batches_tracked, fin->momentum,
+                      fin->eps, fin->save_mean, fin->save_invstd, fin->scale, fin->shift, nullptr};
+    hipLaunchKernelGGL(bn_fin_apply_kernel, dim3(f.nranges, f.nslices), dim3(FA_THREADS), 0, st, partial, parts, C, f.cs, a, x,
+                       n_pixels, f.ppr, res, res_scale, res_shift, relu, y, sign_bits);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
 
 extern "C" int dam_bn_stats_f32(const float* x, int64_t n_pixels, int C, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -713,7 +1066,8 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
         return DAM_ERR_BAD_ARG;
     if (mask_bits) y_mask = reinterpret_cast<const float*>(mask_bits);       // MASK == 3 reads it as bytes
     if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
-    BnLaunch l = bn_plan(n_pixels, C);
+    const bool fused = fa_enabled() && !counter;
+    BnLaunch l = bn_plan(n_pixels, C, fused ? fa_max_parts(C, 2) : BN_MAX_PARTS);
     if (partials_given < 0 || partials_given > BN_MAX_PARTS) return DAM_ERR_BAD_ARG;
     if (partials_given) { l.parts = partials_given; counter = nullptr; }       // records from a data-gradient epilogue
     hipStream_t st = (hipStream_t)stream;
@@ -727,6 +1081,17 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
     else if (mask == 1) DAM_BN_PARTIAL(1); else if (mask == 2) DAM_BN_PARTIAL(2); else if (mask == 3) DAM_BN_PARTIAL(3); else DAM_BN_PARTIAL(0);
 #undef DAM_BN_PARTIAL
     DAM_CHECK_LAUNCH();
+    if (fused) {        // finalize inside the apply launch (bn_bwd_fin_apply_kernel)
+        const FaPlan f = fa_plan(n_pixels, C, l.parts, 2);
+#define DAM_BN_FA(M_)                                                                                                        \
+    hipLaunchKernelGGL(bn_bwd_fin_apply_kernel<M_>, dim3(f.nranges, f.nslices), dim3(FA_THREADS), 0, st, workspace, l.parts, C, \
+                       f.cs, (double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, dy, y_mask, x, n_pixels, \
+                       f.ppr, mask_scale, mask_shift, dx)
+        if (mask == 1) DAM_BN_FA(1); else if (mask == 2) DAM_BN_FA(2); else if (mask == 3) DAM_BN_FA(3); else DAM_BN_FA(0);
+#undef DAM_BN_FA
+        DAM_CHECK_LAUNCH();
+        return DAM_OK;
+    }
     if (!counter) {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C,
                            (double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef);
@@ -757,7 +1122,8 @@ extern "C" int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, co
         !mean_b || !invstd_b || !dx_b || !dgamma_b || !dbeta_b || !workspace || n_pixels <= 0)
         return DAM_ERR_BAD_ARG;
     if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
-    const BnLaunch l = bn_plan(n_pixels, C);
+    const bool fused = fa_enabled();
+    const BnLaunch l = bn_plan(n_pixels, C, fused ? fa_max_parts(C, 3) : BN_MAX_PARTS);
     if ((size_t)l.r * C * 3 * sizeof(float) > 64 * 1024) return DAM_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + (size_t)BN_MAX_PARTS * C * 3;
@@ -768,6 +1134,19 @@ extern "C" int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, co
         hipLaunchKernelGGL(bn_bwd_partial_pair_kernel<false>, dim3(l.parts), dim3(l.threads), (size_t)l.r * C * 3 * sizeof(float), st,
                            dy, y_mask, x_a, x_b, n_pixels, C, l.q, l.r, l.ppb, mean_a, invstd_a, mean_b, invstd_b, workspace);
     DAM_CHECK_LAUNCH();
+    if (fused) {
+        const FaPlan f = fa_plan(n_pixels, C, l.parts, 3);
+        if (bits)
+            hipLaunchKernelGGL(bn_bwd_fin_apply_pair_kernel<true>, dim3(f.nranges, f.nslices), dim3(FA_THREADS), 0, st, workspace, l.parts,
+                               C, f.cs, (double)n_pixels, gamma_a, mean_a, invstd_a, gamma_b, mean_b, invstd_b, training, dgamma_a,
+                               dbeta_a, dgamma_b, dbeta_b, dy, y_mask, x_a, x_b, n_pixels, f.ppr, dx_a, dx_b);
+        else
+            hipLaunchKernelGGL(bn_bwd_fin_apply_pair_kernel<false>, dim3(f.nranges, f.nslices), dim3(FA_THREADS), 0, st, workspace, l.parts,
+                               C, f.cs, (double)n_pixels, gamma_a, mean_a, invstd_a, gamma_b, mean_b, invstd_b, training, dgamma_a,
+                               dbeta_a, dgamma_b, dbeta_b, dy, y_mask, x_a, x_b, n_pixels, f.ppr, dx_a, dx_b);
+        DAM_CHECK_LAUNCH();
+        return DAM_OK;
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_pair_kernel, dim3(C), dim3(64), 0, st, workspace, l.parts, C, (double)n_pixels, gamma_a,
                        mean_a, invstd_a, gamma_b, mean_b, invstd_b, training, dgamma_a, dbeta_a, dgamma_b, dbeta_b, coef);
     DAM_CHECK_LAUNCH();

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                                                                  const float* __restrict__ in_shift, float* __restrict__ Y,
                                                                  const float* __restrict__ res, const float* __restrict__ res_mask,
                                                                  float* __restrict__ stamps, float* __restrict__ stats,
-                                                                 const BnBwdEpi bwd) {
+                                                                 const BnBwdEpi bwd, const int stats_acc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
             if (!s_live[0]) break;
         }
         DAM_PIPE_BARRIER();                         // the last chunk is consumed
+        if (STATS && stats_acc) DAM_PIPE_BARRIER(); // the compute waves' statistics are in LDS (their merge follows, see below)
 #undef DAM_PIPE_REFILL
 #undef DAM_PIPE_COMMIT
 #undef DAM_PIPE_ROUND_END
@@ -260,6 +261,12 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     const int j = lane & 15, kq = lane >> 4;
     const int mt = wave & (MT - 1), kh = wave / MT;        // pixel block of the unit, K half (KS == 2)
     const int part_off = PIPE_BUF1 + stage_bytes + (in_scale ? 2 * g.C * 4 : 0) + PIPE_LT * 16;   // behind the loaders' dump zone
+    // stats_acc (one channel-block group per image row of units: every unit of the launch has the SAME channels): the waves'
+    // statistics accumulate over the units this workgroup walks -- in LDS, [wave][channel][k, s1, s2] + [wave] n -- and the
+    // workgroup leaves ONE record per channel at the end instead of one per wave and unit (257 x 33 stage: 512 instead of 4256)
+    const int sacc_off = part_off + (KS == 2 ? 2 * MB * NB * 1024 : 0);
+    float* const sacc = reinterpret_cast<float*>(smem + sacc_off) + wave * (g.N * 3 + 4);
+    bool sacc_first = true;
     // tap constants: packed-weight byte offset of (tap, chunk 0, block 0) and LDS byte offset of the tap inside the patch
     int tapw[9], tapx[9];
 #pragma unroll
@@ -451,6 +458,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                                     (bias ? bias[(cur.nb0 + nb) * 16 + kq * 4 + r] : 0.f);
                 st_k[nb][r] = STATS == 1 ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, first), 0x150, 0xF, 0xF, false))
                                     : 0.f;                                     // row_newbcast:0 -- lane 0 of the row
+                // accumulating form: ONE shift per channel for everything this wave sees (its first unit's, kept in LDS)
+                if (STATS == 1 && stats_acc && !sacc_first) st_k[nb][r] = sacc[((cur.nb0 + nb) * 16 + kq * 4 + r) * 3];
                 st_s1[nb][r] = 0.f; st_s2[nb][r] = 0.f;
             }
         // STATS == 2: `res` is the BatchNorm's input x (nothing is added); per channel quad the two affine maps
@@ -528,6 +537,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
             const size_t rec = ((size_t)cur.img * g.tiles_m + (cur.p0 / UPX)) * MT + mt;
             float n = st_n;
             DAM_ROW_SUM(n);
+            if (stats_acc && j == 0 && kq == 0) sacc[g.N * 3] = sacc_first ? n : sacc[g.N * 3] + n;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -536,7 +546,13 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                     DAM_ROW_SUM(s1);
                     DAM_ROW_SUM(s2);
                     const int ch = (cur.nb0 + nb) * 16 + kq * 4 + r;
-                    if (STATS == 2) {
+                    if (stats_acc) {            // this wave's own LDS cells: plain read-add-write, fixed order
+                        if (j == 0 && ch < g.N) {
+                            float* o = sacc + ch * 3;
+                            if (sacc_first) { o[0] = st_k[nb][r]; o[1] = s1; o[2] = s2; }
+                            else { o[1] += s1; o[2] += s2; }
+                        }
+                    } else if (STATS == 2) {
                         if (j == 0 && ch < g.N) { float* o = stats + (rec * g.N + ch) * 2; o[0] = s1; o[1] = s2; }
                     } else if (j == 0 && ch < g.N) {
                         const float md = n > 0.f ? s1 / n : 0.f;
@@ -545,11 +561,42 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                     }
                 }
 #undef DAM_ROW_SUM
+            sacc_first = false;
         }
         DAM_PSTAMP(0, 8);
         if (!has_next) break;
         unit += G;
         cur = nxt;
+    }
+    if (STATS && stats_acc) {
+        // every wave's sums are in LDS: one barrier (the loaders join it, see their last line), then the first N lanes of the
+        // workgroup merge the MT waves of a channel in wave order and write the workgroup's record
+        DAM_PIPE_BARRIER();
+        const int c = tid;
+        if (c < g.N) {
+            const float* base = reinterpret_cast<const float*>(smem + sacc_off);
+            const int wstride = g.N * 3 + 4;
+            if (STATS == 2) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int w = 0; w < MT; ++w) { s1 += base[w * wstride + c * 3 + 1]; s2 += base[w * wstride + c * 3 + 2]; }
+                float* o = stats + ((size_t)blockIdx.x * g.N + c) * 2;
+                o[0] = s1; o[1] = s2;
+            } else {
+                float na = 0.f, ma = 0.f, qa = 0.f;          // Chan merge of the waves' (n, mean, M2), fixed order
+                for (int w = 0; w < MT; ++w) {
+                    const float nb_ = base[w * wstride + g.N * 3];
+                    if (nb_ <= 0.f) continue;
+                    const float k_ = base[w * wstride + c * 3], s1 = base[w * wstride + c * 3 + 1], s2 = base[w * wstride + c * 3 + 2];
+                    const float md = s1 / nb_, mb_ = k_ + md, qb = fmaxf(s2 - s1 * md, 0.f);
+                    const float nn = na + nb_, d = mb_ - ma;
+                    ma += d * (nb_ / nn);
+                    qa += qb + d * d * (na * nb_ / nn);
+                    na = nn;
+                }
+                float* o = stats + ((size_t)blockIdx.x * g.N + c) * 3;
+                o[0] = na; o[1] = ma; o[2] = qa;
+            }
+        }
     }
 #undef DAM_PIPE_W
 #undef DAM_PIPE_X
@@ -584,20 +631,27 @@ int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
                 const BnBwdEpi& bwd, hipStream_t st) {
     const int nunits = g.tiles_m * (g.N / 16 / NB) * g.B;
     // statistics records: one per (image tile, wave), each unit fills its own channels of it
-    int mode = 0;
+    int mode = 0, acc = 0;
     if (stats) {
         const int64_t parts = (int64_t)g.B * g.tiles_m * (4 / KS);
-        if (parts > (bwd.x ? BN_BWD_RECORDS_MAX : BN_RECORDS_MAX)) stats = nullptr;    // the caller runs the separate pass instead
-        else { mode = bwd.x ? 2 : 1; if (stats_parts) *stats_parts = (int)parts; }
+        mode = bwd.x ? 2 : 1;
+        // one channel-block group per unit row (every unit has all the layer's channels: the 1 x 4 tile of a 64-channel stage):
+        // the workgroups accumulate over their units and leave ONE record each (kernel: stats_acc)
+        static const bool acc_ok = [] { const char* e = getenv("DAM_PIPE_STATS_ACC"); return !(e && e[0] == '0'); }();
+        if (acc_ok && g.N == 16 * NB && g.N <= PIPE_THREADS - PIPE_LT) acc = 1;
+        else if (parts > (bwd.x ? BN_BWD_RECORDS_MAX : BN_RECORDS_MAX)) { stats = nullptr; mode = 0; }   // the caller runs the separate pass
+        else if (stats_parts) *stats_parts = (int)parts;
     }
     if (bwd.x) res = mode == 2 ? bwd.x : nullptr;               // the sums epilogue reads x through the residual operand
+    if (acc) lds += (size_t)(4 / KS) * (g.N * 3 + 4) * sizeof(float);
     int wgs = mode == 2 ? pipe_slots<MB, NB, PU, 2, KS>(lds) : (mode == 1 ? pipe_slots<MB, NB, PU, 1, KS>(lds) : pipe_slots<MB, NB, PU, 0, KS>(lds));
     if (const char* e = getenv("DAM_PIPE_WGS")) wgs = atoi(e);          // diagnostic
     if (wgs < 1) wgs = 1;
     if (wgs > nunits) wgs = nunits;
+    if (acc && stats_parts) *stats_parts = wgs;
 #define DAM_PIPE_LAUNCH(S_)                                                                                                 \
     hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, S_, KS>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,  \
-                       reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats, bwd)
+                       reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats, bwd, acc)
     if (mode == 2) DAM_PIPE_LAUNCH(2); else if (mode == 1) DAM_PIPE_LAUNCH(1); else DAM_PIPE_LAUNCH(0);
 #undef DAM_PIPE_LAUNCH
     DAM_CHECK_LAUNCH();

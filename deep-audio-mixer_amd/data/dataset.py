@@ -26,7 +26,8 @@ import torch
 from torch.utils import data
 
 from .. import features, staging
-from .dataset_utils import native_dtype, read_wav, read_wav_native, wav_header, wav_num_frames
+from .dataset_utils import (cached_files_begin, close_cached_files, native_dtype, read_wav, read_wav_native, wav_header,
+                            wav_num_frames)
 
 
 class MultitrackAudioDataset(data.Dataset):
@@ -143,7 +144,12 @@ class MultitrackAudioDataset(data.Dataset):
         32-bit PCM -> int16 / int32, dataset_utils.read_wav_native: no host conversion), in-memory arrays as they are."""
         if self._arrays is not None:
             return np.asarray(self._arrays[song_name][track_name][lo:hi])
-        return read_wav_native(self._get_track_path(song_name, track_name), lo, hi)[0]
+        path = self._get_track_path(song_name, track_name)
+        if native_dtype(wav_header(path)) is None:
+            # 8-bit PCM / float64 files: no sample type the kernel reads -- float64 in [-1, 1), what soundfile.read yields
+            # at data/dataset.py:194 (the front-end takes float64 PCM as it is)
+            return read_wav(path, lo, hi, dtype=np.float64)[0]
+        return read_wav_native(path, lo, hi)[0]
 
     @staticmethod
     def _common_pcm(chunks):
@@ -199,8 +205,13 @@ class MultitrackAudioDataset(data.Dataset):
         kind = kinds.pop() if len(kinds) == 1 else None
         return (np.dtype(np.float32) if kind is None else kind), chans.pop()
 
-    def iter_batches(self, batch_size, indices=None, workers=8, drop_last=False):
-        """Yields (train_features [B,S,1025,T], gt_features [B,1025,T]) float32 CUDA tensors for consecutive groups of
+    def iter_batches(self, batch_size, indices=None, workers=8, drop_last=False, pcm=False):
+        """pcm=True: yields PcmBatch objects instead -- the uploaded PCM of the batch ([B, S+1, n, ch] in the staging format)
+        and its augmentation gains, NOT yet turned into features: ModelTrainer binds them to a step whose captured graph
+        contains the front-end (engine.TrainStep.bind_clips: no feature copy, no separate front-end launch); any other
+        consumer unpacks them like a (features, target) pair and gets the features computed on the spot.
+
+        Yields (train_features [B,S,1025,T], gt_features [B,1025,T]) float32 CUDA tensors for consecutive groups of
         `batch_size` items of `indices` (default: every item, in order) -- what ``DataLoader(self, batch_size)`` yields,
         with the reads of data/dataset.py:192-196 done by `workers` threads straight into page-locked memory (integer PCM
         stays integer: staging_format), three staging slots -- batch k in use, k+1 on the copy stream, k+2 being decoded in
@@ -230,7 +241,9 @@ class MultitrackAudioDataset(data.Dataset):
             busy = _th.Lock()
             self._staging_cache = (key, host, dev, busy)
         busy.acquire()
+        cached_files_begin()
         uploaded = [torch.cuda.Event() for _ in range(NS)]
+        consumed = [torch.cuda.Event() for _ in range(NS)]     # pcm=True: what the consumer enqueued on dev[slot] has run
         copy_stream = torch.cuda.Stream(device=self._device)
 
         import queue
@@ -251,7 +264,8 @@ class MultitrackAudioDataset(data.Dataset):
                         if stop.is_set():
                             return
                         slot, group = j % NS, groups[j]
-                        uploaded[slot].synchronize()                    # the slot's previous upload has left host[slot]
+                        with staging.capture_guard:
+                            uploaded[slot].synchronize()                # the slot's previous upload has left host[slot]
                         view = host[slot].numpy()
 
                         # one task = a few tracks of one clip (K tracks in `per` pieces): a task per track made the pool's
@@ -269,52 +283,86 @@ class MultitrackAudioDataset(data.Dataset):
                     slot, group, reads = started.popleft()
                     for f in reads:
                         f.result()                                      # raises a reader's error (re-raised in the consumer)
+                    if stop.is_set():
+                        return
                     B = len(group)
                     # upload AND front-end launch on the copy stream, from this thread: the features of batch j + 1 are
                     # computed while the consumer's step on batch j runs -- nothing of it is left on the consumer's
-                    # critical path (with a per-step loss.item() the device idles for every host call in between)
-                    with torch.cuda.device(self._device), torch.cuda.stream(copy_stream):
+                    # critical path (with a per-step loss.item() the device idles for every host call in between).
+                    # capture_guard: never while the consumer captures its step into a hipGraph (ModelTrainer, third batch)
+                    with staging.capture_guard, torch.cuda.device(self._device), torch.cuda.stream(copy_stream):
+                        if pcm:                                                     # the consumer's step read dev[slot] in place
+                            copy_stream.wait_event(consumed[slot])
                         dev[slot][:B].copy_(host[slot][:B], non_blocking=True)      # (stream order: after the launch that
                         uploaded[slot].record(copy_stream)                          # read dev[slot] NS batches ago)
                         gain = None
                         if self._augment:
                             gain = features.augment_gains(self._aug_seed, K, items=self._aug_keys(group), device=self._device)
-                        x, gt = features.stft_logmag_clips(dev[slot][:B], 2048, 1024, gain=gain, normalize=self._normalize)
+                        if pcm:
+                            payload = PcmBatch(dev[slot][:B], gain, self._normalize)
+                        else:
+                            payload = features.stft_logmag_clips(dev[slot][:B], 2048, 1024, gain=gain, normalize=self._normalize)
                         done = torch.cuda.Event()
                         done.record(copy_stream)
-                    ready.put((x, gt, done))
+                    ready.put((payload, done, slot))
                 ready.put(None)
             except BaseException as e:       # noqa: B036 -- handed to the consumer, which re-raises it
                 ready.put(e)
-
-        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
-            th = threading.Thread(target=feeder, args=(pool,), daemon=True)
-            th.start()
-            try:
-                while True:
-                    item = ready.get()
-                    if item is None:
-                        break
-                    if isinstance(item, BaseException):
-                        raise item
-                    x, gt, done = item
-                    cur = torch.cuda.current_stream(self._device)
-                    cur.wait_event(done)
-                    x.record_stream(cur)            # allocated on the copy stream, used on the consumer's
-                    gt.record_stream(cur)
-                    free.release()                  # the staging slot is free: its PCM has been turned into features
-                    yield x, gt
             finally:
-                stop.set()
-                free.release()          # a feeder waiting for a slot sees `stop` and leaves
-                th.join()
-                torch.cuda.current_stream(self._device).wait_stream(copy_stream)
-                busy.release()
+                # an early exit (the consumer stopped iterating, or a reader raised) leaves reads running that write into the
+                # page-locked slots: they are waited for HERE, before the consumer's `finally` may hand the slots to the next
+                # pass (a cancelled future never ran; a running one is joined)
+                for _, _, reads in started:
+                    for f in reads:
+                        if not f.cancel():
+                            try:
+                                f.result()
+                            except BaseException:      # noqa: B036 -- already reported, or irrelevant after a stop
+                                pass
 
-    def batch_loader(self, batch_size, indices=None, workers=8, drop_last=False):
+        try:
+            with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+                th = threading.Thread(target=feeder, args=(pool,), daemon=True)
+                th.start()
+                try:
+                    while True:
+                        item = ready.get()
+                        if item is None:
+                            break
+                        if isinstance(item, BaseException):
+                            raise item
+                        payload, done, slot = item
+                        cur = torch.cuda.current_stream(self._device)
+                        cur.wait_event(done)
+                        if pcm:
+                            if payload.gain is not None:
+                                payload.gain.record_stream(cur)
+                            yield payload
+                            # back here the consumer has enqueued everything that reads this batch (ModelTrainer: the step's
+                            # graph replay): the slot's next upload waits for that work, not for the host
+                            consumed[slot].record(torch.cuda.current_stream(self._device))
+                            free.release()
+                            continue
+                        x, gt = payload
+                        x.record_stream(cur)            # allocated on the copy stream, used on the consumer's
+                        gt.record_stream(cur)
+                        free.release()                  # the staging slot is free: its PCM has been turned into features
+                        yield x, gt
+                finally:
+                    stop.set()
+                    free.release()          # a feeder waiting for a slot sees `stop` and leaves
+                    th.join()               # (it has joined its outstanding reads by then)
+                    torch.cuda.current_stream(self._device).wait_stream(copy_stream)
+        finally:
+            # only now -- the pool has shut down, no reader can still write into host[] -- may another pass reuse the slots
+            busy.release()
+            close_cached_files()
+
+    def batch_loader(self, batch_size, indices=None, workers=8, drop_last=False, pcm=False):
         """iter_batches as a re-iterable loader with ``len()`` -- what ModelTrainer.fit / the notebooks' loops expect of a
-        DataLoader (one pass per ``for`` loop)."""
-        return _BatchLoader(self, batch_size, indices, workers, drop_last)
+        DataLoader (one pass per ``for`` loop).  pcm=True: PcmBatch items (see iter_batches) -- ModelTrainer then runs the
+        front-end inside its captured step."""
+        return _BatchLoader(self, batch_size, indices, workers, drop_last, pcm)
 
     def _read_chunk_into(self, out, song_name, track_name, lo, hi):
         """One track's chunk into a [n, channels] view of a staging buffer (dtype: staging_format)."""
@@ -403,13 +451,32 @@ class MultitrackAudioDataset(data.Dataset):
         return {track_name: mean(loudness[track_name]) for track_name in loudness}
 
 
+class PcmBatch:
+    """One batch of uploaded clips that has not been through the front-end yet: `clips` [B, S+1, n, ch] on the device (mix
+    last; float32, or int16 / int32 as the files hold it), `gain` [B, S+1] augmentation draws or None.  Unpacks like the
+    (train_features, gt_features) pair of data/dataset.py:207-210 -- the front-end then runs on the current stream -- so a
+    plain ``for feats, target in loader`` loop works; ModelTrainer takes the PCM itself (engine.TrainStep.bind_clips).
+    Valid until the loader is asked for its next batch (the staging slot is then refilled)."""
+    __slots__ = ('clips', 'gain', 'normalize', 'n_fft', 'hop')
+
+    def __init__(self, clips, gain=None, normalize=False, n_fft=2048, hop=1024):
+        self.clips, self.gain, self.normalize, self.n_fft, self.hop = clips, gain, bool(normalize), n_fft, hop
+
+    def features(self):
+        return features.stft_logmag_clips(self.clips, self.n_fft, self.hop, gain=self.gain, normalize=self.normalize)
+
+    def __iter__(self):
+        return iter(self.features())
+
+
 class _BatchLoader:
-    def __init__(self, dataset, batch_size, indices, workers, drop_last):
+    def __init__(self, dataset, batch_size, indices, workers, drop_last, pcm=False):
         self.dataset, self.batch_size, self.indices, self.workers, self.drop_last = dataset, batch_size, indices, workers, drop_last
+        self.pcm = pcm
 
     def __len__(self):
         n = len(self.dataset) if self.indices is None else len(self.indices)
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def __iter__(self):
-        return self.dataset.iter_batches(self.batch_size, self.indices, self.workers, self.drop_last)
+        return self.dataset.iter_batches(self.batch_size, self.indices, self.workers, self.drop_last, pcm=self.pcm)

@@ -45,13 +45,16 @@ _headers = {}
 
 
 _fds = {}                      # (path, mtime, size) -> read-only descriptor kept open for positioned reads (first _FDS_MAX files)
+_fd_of_path = {}               # path -> the key its cached descriptor was opened under
 _FDS_MAX = 256
 _fds_lock = threading.Lock()
+_fd_users = 0                  # ingest passes (MultitrackAudioDataset.iter_batches) currently reading through the cache
 
 
 def _get_fd(path, h):
-    """(descriptor, close it after use?): cached for the first _FDS_MAX files -- never evicted, so a descriptor in use by another
-    decode thread cannot be closed under it -- a fresh one beyond that."""
+    """(descriptor, close it after use?): cached for the first _FDS_MAX files, a fresh one beyond that.  A cached descriptor
+    is closed when the file behind its path has changed (new mtime / size: a re-rendered stem) and by close_cached_files()
+    when the last ingest pass ends -- never while a pass that may be reading through it is running."""
     key = h['_key']
     fd = _fds.get(key)
     if fd is not None:
@@ -60,10 +63,38 @@ def _get_fd(path, h):
         fd = _fds.get(key)
         if fd is not None:
             return fd, False
+        stale = _fd_of_path.get(path)
+        if stale is not None and stale != key and _fd_users <= 1:
+            old = _fds.pop(stale, None)            # the path was rewritten: its old descriptor points at a dead inode
+            if old is not None:
+                os.close(old)
+            _headers.pop(stale, None)
         if len(_fds) < _FDS_MAX:
             fd = _fds[key] = os.open(path, os.O_RDONLY)
+            _fd_of_path[path] = key
             return fd, False
     return os.open(path, os.O_RDONLY), True
+
+
+def cached_files_begin():
+    """An ingest pass starts reading through the descriptor cache (paired with close_cached_files())."""
+    global _fd_users
+    with _fds_lock:
+        _fd_users += 1
+
+
+def close_cached_files(force=False):
+    """End of an ingest pass: when no other pass is running, every cached descriptor is closed (a long-lived process that
+    walks many datasets, or rewrites its files between passes, would otherwise hold up to _FDS_MAX of them for good).
+    force=True closes regardless of the pass count (tests; the caller guarantees no reader is running)."""
+    global _fd_users
+    with _fds_lock:
+        _fd_users = max(0, _fd_users - 1)
+        if _fd_users == 0 or force:
+            for fd in _fds.values():
+                os.close(fd)
+            _fds.clear()
+            _fd_of_path.clear()
 
 
 def wav_header(path):

@@ -31,11 +31,14 @@ from . import distributed, features, layers, ops
 
 class TrainStep:
     def __init__(self, model, optimizer, n_stems, n_samples=None, channels=2, batch=8, n_fft=2048, hop=1024,
-                 use_graph=True, device=None, overlap=True, feature_shape=None, pcm_dtype=torch.float32):
+                 use_graph=True, device=None, overlap=True, feature_shape=None, pcm_dtype=torch.float32, track_gains=False,
+                 normalize=False):
         """feature_shape=(F, T): the step starts from FEATURES instead of PCM (what a DataLoader over the reference's
         Dataset yields, model_trainer.py:31-33): no front-end launch in the step, `load_features(x, gt)` fills the static
         inputs.  pcm_dtype: float32, or int16 / int32 for integer PCM read by the front-end as decoded from the file
-        (DAM_PCM_S16 / DAM_PCM_S32, include/dam_hip.h)."""
+        (DAM_PCM_S16 / DAM_PCM_S32, include/dam_hip.h).  track_gains: the front-end multiplies every track by an entry of a
+        static [B, S+1] table (data/dataset.py:164-168, 198-199: the augmentation draws; `bind_clips(clips, gain)` fills it,
+        ones otherwise).  normalize: the per-frame max-abs normalisation of data/dataset.py:159-160 (off at the reference HEAD)."""
         self.model, self.opt = model, optimizer
         self.device = device or next(model.parameters()).device
         self.n_fft, self.hop, self.batch, self.n_stems = n_fft, hop, batch, n_stems
@@ -52,6 +55,8 @@ class TrainStep:
             # bind_clips() re-pointed it at another resident batch -- a graph replay then reads that batch in place, no copy
             self.pcm_word = torch.full((1,), self.pcm.data_ptr(), dtype=torch.int64, device=dev)
             self._bound = self.pcm
+        self.gain = torch.ones((batch, n_stems + 1), dtype=torch.float32, device=dev) if track_gains and not self.from_features else None
+        self.normalize = bool(normalize)
         self.x = torch.empty((batch, n_stems, f, t), dtype=torch.float32, device=dev)
         self.gt = torch.empty((batch, f, t), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
@@ -90,13 +95,21 @@ class TrainStep:
         self.close()
         return False
 
+    # bit pattern the gradient bucket is poisoned with before the first eager step: a quiet NaN with a payload no arithmetic
+    # produces (hardware-generated NaNs are 0x7FC00000; an input's payload would have to be this very one), so a slice that
+    # still holds it was not written -- and a legitimately non-finite first gradient is not mistaken for a missing one
+    _SENTINEL = 0x7FDA4D17
+
     def _check_slots_written(self):
         """Overwrite semantics: a bound parameter that backward does not reach would keep the PREVIOUS step's gradient
-        (already summed by the all-reduce).  Checked once, on the first eager step: the bucket is poisoned before backward
-        and every parameter's slice must have been rewritten."""
-        bad = [i for i, p in enumerate(self.opt._params)
-               if not bool(torch.isfinite(self.opt._grad[self.opt._offsets[i]:self.opt._offsets[i + 1]]).all())]
-        if bad:
+        (already summed by the all-reduce).  Checked once, on the first eager step, BETWEEN backward and everything that
+        consumes the bucket (all-reduce, Adam): the bucket is poisoned before backward and no element of any parameter's
+        slice may still hold the poison.  Raising here leaves parameters and moments untouched."""
+        left = self.opt._grad.view(torch.int32) == self._SENTINEL
+        if bool(left.any()):
+            bad = [i for i in range(len(self.opt._params))
+                   if bool(left[self.opt._offsets[i]:self.opt._offsets[i + 1]].any())]
+            self.opt._grad.zero_()
             self.close()
             raise RuntimeError('TrainStep: backward wrote no gradient for parameter(s) %s of the optimizer -- bound gradient '
                                'slots need every parameter to receive a gradient each step' % bad[:8])
@@ -114,7 +127,8 @@ class TrainStep:
     def _front_end(self):
         if self.from_features:
             return
-        features.stft_logmag_clips(self.pcm, self.n_fft, self.hop, out_stems=self.x, out_mix=self.gt, pcm_word=self.pcm_word)
+        features.stft_logmag_clips(self.pcm, self.n_fft, self.hop, gain=self.gain, normalize=self.normalize, out_stems=self.x,
+                                   out_mix=self.gt, pcm_word=self.pcm_word)
 
     def _fwd_bwd(self):
         self._front_end()
@@ -156,21 +170,26 @@ class TrainStep:
     def _eager(self):
         first = not self._slots_checked and not torch.cuda.is_current_stream_capturing()
         if first:
-            self.opt._grad.fill_(float('nan'))
-        self._eager_body()
-        if first:
-            self._check_slots_written()
+            self.opt._grad.view(torch.int32).fill_(self._SENTINEL)
+        self._eager_body(self._check_slots_written if first else None)
 
-    def _eager_body(self):
+    def _eager_body(self, check=None):
+        """check (first eager step only): called when backward has filled the whole bucket and nothing has consumed it yet
+        -- the staged form then starts both all-reduces after it instead of overlapping the first with stage 2."""
         if self.staged:
             self._stage1()
-            w1 = self.opt.all_reduce_grads(1, async_op=True)
+            w1 = self.opt.all_reduce_grads(1, async_op=True) if check is None else None
             self._stage2()
+            if check is not None:
+                check()
+                w1 = self.opt.all_reduce_grads(1, async_op=True)
             w0 = self.opt.all_reduce_grads(0, async_op=True)
             w1.wait()
             w0.wait()
         else:
             self._fwd_bwd()
+            if check is not None:
+                check()
             self.opt.all_reduce_grads()
         self._update()
 
@@ -200,14 +219,22 @@ class TrainStep:
         self.pcm.copy_(clips, non_blocking=True)
         self._point_at(self.pcm)
 
-    def bind_clips(self, clips):
+    def bind_clips(self, clips, gain=None):
         """Zero-copy form of load_clips for a batch that is ALREADY on this device: the next steps read `clips`
         ([B, S+1, n, ch] float32, contiguous, mix last) in place -- only the front-end's 8-byte address word changes.
         The caller keeps `clips` alive and unmodified until those steps have run (a reference is held here until the
-        next load/bind)."""
+        next load/bind).  gain (track_gains steps): the batch's [B, S+1] per-track gains, copied into the static table
+        (None: ones)."""
         if clips.device != self.pcm.device or clips.dtype != self.pcm.dtype or tuple(clips.shape) != tuple(self.pcm.shape) \
                 or not clips.is_contiguous():
             raise ValueError('bind_clips: a contiguous %s %s tensor on %s' % (self.pcm.dtype, tuple(self.pcm.shape), self.pcm.device))
+        if gain is not None and self.gain is None:
+            raise ValueError('bind_clips(gain=): construct the step with track_gains=True')
+        if self.gain is not None:
+            if gain is None:
+                self.gain.fill_(1.0)
+            else:
+                self.gain.copy_(gain.reshape(self.gain.shape), non_blocking=True)
         self._point_at(clips)
 
     def capture(self, warmup=3):
@@ -222,28 +249,36 @@ class TrainStep:
         torch.cuda.synchronize(self.device)
         if not self.use_graph:
             return self
+        # Other threads keep talking to the GPU while this one captures (MultitrackAudioDataset.iter_batches' feeder: event
+        # waits, H2D copies, allocator misses, its own front-end launch on the copy stream).  In torch's default "global"
+        # capture mode any such call from ANY thread invalidates the capture; "thread_local" confines the check to this
+        # thread, whose calls are all capturable.  staging.capture_guard additionally keeps the feeder's GPU section and a
+        # capture from overlapping at all (the feeder takes it per batch).
+        from . import staging
+        mode = dict(capture_error_mode='thread_local')
         ga = torch.cuda.CUDAGraph()
-        if self.staged:
-            ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                self._stage1()
-            with torch.cuda.graph(ga2, pool=ga.pool()):
-                self._stage2()
-            with torch.cuda.graph(gb, pool=ga.pool()):
-                self._update()
-            self._graphs = (ga, ga2, gb)
-        elif self.opt.world_size > 1:
-            gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                self._fwd_bwd()
-            with torch.cuda.graph(gb, pool=ga.pool()):
-                self._update()
-            self._graphs = (ga, gb)
-        else:
-            with torch.cuda.graph(ga):
-                self._fwd_bwd()
-                self._update()
-            self._graphs = (ga,)
+        with staging.capture_guard:
+            if self.staged:
+                ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, **mode):
+                    self._stage1()
+                with torch.cuda.graph(ga2, pool=ga.pool(), **mode):
+                    self._stage2()
+                with torch.cuda.graph(gb, pool=ga.pool(), **mode):
+                    self._update()
+                self._graphs = (ga, ga2, gb)
+            elif self.opt.world_size > 1:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, **mode):
+                    self._fwd_bwd()
+                with torch.cuda.graph(gb, pool=ga.pool(), **mode):
+                    self._update()
+                self._graphs = (ga, gb)
+            else:
+                with torch.cuda.graph(ga, **mode):
+                    self._fwd_bwd()
+                    self._update()
+                self._graphs = (ga,)
         return self
 
     def exposed_wait_ms(self):

@@ -120,8 +120,8 @@ class SongMixer:
                 torch.cuda.current_stream(self.dev).wait_stream(s)
                 torch.cuda.synchronize(self.dev)
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._body()
+                with staging.capture_guard, torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                    self._body()           # (thread_local: other threads' GPU calls do not invalidate the capture)
             self._key = key
         self.graph.replay()
 

@@ -42,18 +42,21 @@ class ConvSpec:
         return ops.conv2d_fwd(x, self.packed(w), self.cout, self.k, self.k, self.stride, self.pad, self.dil,
                               bias=bias, in_nchw=self.in_nchw)
 
-    def fwd_conv(self, x, w, bn, training, bias=None, in_affine=None, fuse_stats=True):
+    def fwd_conv(self, x, w, bn, training, bias=None, in_affine=None, fuse_stats=True, finalize=True):
         """The convolution in front of a BatchNorm: (c, stats) with stats = (save_mean, save_invstd, scale, shift) when the
         conv launch produced the training-mode statistics itself (strip kernel epilogue), else None.  in_affine=(scale,
         shift): the input is relu(x*scale + shift), applied while the kernel loads x (the producer's BatchNorm + ReLU
-        never materialised)."""
+        never materialised).  finalize=False: stats is the un-merged (records, count) pair instead -- for a consumer that
+        merges them itself (ops.bn_finalize_apply)."""
         wp = self.packed(w)
         aff = {} if in_affine is None else dict(in_scale=in_affine[0], in_shift=in_affine[1], relu_in=True)
         if training and not self.in_nchw and fuse_stats:
             n16 = (self.cout + 15) // 16 * 16
             buf = ops.bn_partial_buffer(x.device, n16)
             c, parts, out4 = ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
-                                            bn_partial=buf, bn=_bn_args(bn, training), **aff)
+                                            bn_partial=buf, bn=_bn_args(bn, training), finalize=finalize, **aff)
+            if not finalize:
+                return c, ((buf, parts) if parts > 0 else None)
             return c, ((out4[0], out4[1], out4[2], out4[3]) if parts > 0 else None)
         return ops.conv2d_fwd(x, wp, self.cout, self.k, self.k, self.stride, self.pad, self.dil, bias=bias,
                               in_nchw=self.in_nchw, **aff), None
@@ -64,11 +67,19 @@ class ConvSpec:
         c, stats = self.fwd_conv(x, w, bn, training, bias=bias, in_affine=in_affine)
         return (c,) + tuple(stats if stats is not None else _bn_fwd_stats(c, bn, training))
 
-    def fwd_bn_apply(self, x, w, bn, training, in_affine=None, res=None, res_affine=None, sign_bits=False):
+    def fwd_bn_apply(self, x, w, bn, training, in_affine=None, res=None, res_affine=None, sign_bits=False, bias=None):
         """fwd_bn followed by out = relu(bn(c) + res [* res_scale + res_shift]): (c, save_mean, save_invstd, scale, shift, out);
-        with sign_bits the last item is (out, bits): see ops.bn_apply."""
+        with sign_bits the last item is (out, bits): see ops.bn_apply.  In training mode the statistics records (the
+        convolution epilogue's, or a partial pass over c) are merged INSIDE the apply launch (ops.bn_finalize_apply): no
+        finalize launch between the two."""
         rs, rh = res_affine if res_affine is not None else (None, None)
-        c, m, i, sc, sh = self.fwd_bn(x, w, bn, training, in_affine=in_affine)
+        if training and ops.FUSED_FINALIZE:
+            c, rec = self.fwd_conv(x, w, bn, training, bias=bias, in_affine=in_affine, finalize=False)
+            rec = rec if rec is not None else ops.bn_stats_partial(c)
+            (m, i, sc, sh), out = ops.bn_finalize_apply(rec[0], rec[1], _bn_args(bn, training), c, relu=True, res=res,
+                                                        res_scale=rs, res_shift=rh, sign_bits=sign_bits)
+            return c, m, i, sc, sh, out
+        c, m, i, sc, sh = self.fwd_bn(x, w, bn, training, bias=bias, in_affine=in_affine)
         return c, m, i, sc, sh, ops.bn_apply(c, sc, sh, relu=True, res=res, res_scale=rs, res_shift=rh, sign_bits=sign_bits)
 
     def wgrad(self, x, dy, in_affine=None, out=None):
@@ -251,8 +262,8 @@ class ConvBnReluFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, gamma, beta, spec, bn, training):
         if spec.nhwc16 is not None and not ctx.needs_input_grad[0]:
             spec, x = spec.nhwc16, ops.nchw_to_nhwc16(x)
-        c, mean, invstd, scale, shift = spec.fwd_bn(x, w.detach(), bn, training, None if bias is None else bias.detach())
-        a = ops.bn_apply(c, scale, shift, relu=True)
+        c, mean, invstd, scale, shift, a = spec.fwd_bn_apply(x, w.detach(), bn, training,
+                                                             bias=None if bias is None else bias.detach())
         ctx.save_for_backward(x, w, c, gamma, mean, invstd, scale, shift)
         ctx.up = a._dam_upstream = _UpstreamBn(c, mean, invstd, scale, shift) if ops.DGRAD_BN_SUMS else None
         ctx.spec, ctx.training, ctx.has_bias = spec, training, bias is not None

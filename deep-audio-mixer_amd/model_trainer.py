@@ -8,12 +8,18 @@ What is different underneath:
   * with ``criterion = nn.MSELoss()`` (what every notebook passes) loss and gradient come from the model's fused
     ``forward_mse`` (one pass over the features); any other criterion is applied to ``masked`` as in the reference;
   * the training loop body (model_trainer.py:30-37: zero_grad, forward, loss, backward, step) becomes ONE hipGraph replay
-    once it has proven static (and the per-batch ``loss.item()`` is read one batch late, see ``_run``): model, criterion
-    and optimizer are this package's own (``forward_mse`` + ``optim.Adam``)
+    once it has proven static (and the per-batch ``loss.item()`` is read one batch late, see ``_run``): the model is this
+    package's, the criterion ``nn.MSELoss()``, the optimizer this package's ``optim.Adam`` OR the plain
+    ``torch.optim.Adam(model.parameters(), weight_decay=1e-5)`` of training.ipynb cell 11 -- that one is ADOPTED (see
+    ``_adopt_torch_adam``: same hyper-parameter dict, its moments become views of the fused optimizer's buffers, so the
+    caller's object, its ``state_dict()`` and an LR scheduler attached to it keep working) --
     and the batch shape has repeated -- the first ``EAGER_BATCHES`` batches run the eager autograd sequence, the next one
-    captures ``engine.TrainStep(feature_shape=...)`` (its warm-up step is rolled back, so no extra optimizer step is
-    taken) and from then on a batch is a copy into the static inputs + a replay; batches of another shape (a ragged last
+    captures ``engine.TrainStep`` (its warm-up step is rolled back, so no extra optimizer step is
+    taken) and from then on a batch is a copy into the static inputs + a replay -- or, for the ``PcmBatch`` items of
+    ``MultitrackAudioDataset.batch_loader(pcm=True)``, no copy at all: the captured step contains the front-end and reads the
+    uploaded PCM in place; batches of another shape (a ragged last
     batch) run eagerly.  The reference's per-batch ``loss.item()`` and prints stay.  ``graph=False`` keeps everything eager;
+    when the captured path was wanted but cannot be taken (another criterion, another optimizer), ONE warning says why;
   * loaders without ``__len__`` (generators such as ``MultitrackAudioDataset.iter_batches``) are accepted: the epoch mean
     is taken over the batches seen;
   * like the reference, the trainer never switches the model between train and eval mode: validation runs
@@ -21,6 +27,7 @@ What is different underneath:
   * under ``torch.distributed`` only rank 0 prints and saves.
 """
 import os
+import warnings
 
 import torch
 
@@ -31,6 +38,43 @@ _CKPT_PATTERN = 'mixmodel_{}_1s_{:04d}_{:.4f}.pt'  # model_trainer.py:64
 def _rank0():
     dist = torch.distributed
     return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def _adopt_torch_adam(optimizer):
+    """training.ipynb cell 11 hands ModelTrainer a ``torch.optim.Adam(model.parameters(), weight_decay=1e-5)``.  Returns
+    (this package's fused Adam over the same parameters, None) when that optimizer is one the fused launch reproduces --
+    exactly torch.optim.Adam, one parameter group, L2 weight decay, no amsgrad / maximize / tensor lr, float32 CUDA
+    parameters, one common step count -- else (None, reason).  The adopted pair stays ONE optimizer to the caller:
+      * ``param_groups[0]`` is the SAME dict object in both, so ``optimizer.param_groups[0]['lr'] = ...`` or an LR scheduler
+        built on the caller's object reaches the fused launch (optim.Adam.sync_hyper reads the dict every step);
+      * the caller's per-parameter ``exp_avg`` / ``exp_avg_sq`` become views of the fused optimizer's flat buffers (after
+        its existing state has been loaded into them), so ``optimizer.state_dict()`` is always current; the per-parameter
+        step counts are written back at the end of every fit() and by close()."""
+    from .optim import Adam
+    if type(optimizer) is not torch.optim.Adam:
+        return None, 'the optimizer is %s, not torch.optim.Adam or this package\'s optim.Adam' % type(optimizer).__name__
+    if len(optimizer.param_groups) != 1:
+        return None, 'the optimizer has %d parameter groups' % len(optimizer.param_groups)
+    g = optimizer.param_groups[0]
+    for flag in ('amsgrad', 'maximize', 'differentiable', 'decoupled_weight_decay'):
+        if g.get(flag):
+            return None, 'torch.optim.Adam(%s=True) is not what the fused launch computes' % flag
+    if isinstance(g['lr'], torch.Tensor):
+        return None, 'a tensor learning rate'
+    params = [p for p in g['params'] if p.requires_grad]
+    if not params or any((not p.is_cuda) or p.dtype != torch.float32 for p in params):
+        return None, 'parameters that are not float32 CUDA tensors'
+    try:
+        saved = optimizer.state_dict() if optimizer.state else None
+        new = Adam(g['params'], lr=g['lr'], betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'])
+        if saved is not None:
+            new.load_state_dict(saved)
+    except (ValueError, RuntimeError) as e:
+        return None, str(e)
+    new.param_groups[0] = g
+    new._hyper_host = None
+    new.sync_hyper()
+    return new, None
 
 
 class ModelTrainer:
@@ -44,38 +88,99 @@ class ModelTrainer:
         fusable = type(criterion) is torch.nn.MSELoss and criterion.reduction == 'mean'
         self._fused = fusable and hasattr(model, 'forward_mse')
         from .optim import Adam
-        self._graphable = bool(graph) and self._fused and isinstance(optimizer, Adam)
+        self._adopted_from = None
+        why = None
+        if not self._fused:
+            why = 'the criterion is not nn.MSELoss() on a model of this package'
+        elif bool(graph) and not isinstance(optimizer, Adam):
+            fused_opt, why = _adopt_torch_adam(optimizer)
+            if fused_opt is not None:
+                self._adopted_from, self.optimizer = optimizer, fused_opt
+                self._push_adopted_state()
+        self._graphable = bool(graph) and self._fused and isinstance(self.optimizer, Adam)
+        if bool(graph) and not self._graphable:
+            warnings.warn('ModelTrainer: the training loop runs launch by launch (eager), not as a captured hipGraph: %s' % why,
+                          RuntimeWarning, stacklevel=2)
         self._step = self._shape = None
         self._seen = 0
         self.graph_steps = self.eager_steps = 0       # diagnostic: how the training batches were run
 
+    # ---- an adopted torch.optim.Adam stays usable by its owner
+    def _push_adopted_state(self):
+        """The caller's torch.optim.Adam sees the fused optimizer's moments (views) and step count."""
+        orig, opt = self._adopted_from, self.optimizer
+        if orig is None:
+            return
+        step = float(opt._step.item())
+        for i, p in enumerate(opt._params):
+            lo, hi = opt._offsets[i], opt._offsets[i + 1]
+            st = orig.state[p]
+            st['exp_avg'] = opt._exp_avg[lo:hi].view(p.shape)
+            st['exp_avg_sq'] = opt._exp_avg_sq[lo:hi].view(p.shape)
+            old = st.get('step')
+            st['step'] = torch.tensor(step, dtype=torch.float32, device=old.device if isinstance(old, torch.Tensor) else 'cpu')
+
+    def _pull_adopted_step(self):
+        """If the caller stepped its own optimizer between two fit() calls, the fused one continues from that count."""
+        orig, opt = self._adopted_from, self.optimizer
+        if orig is None:
+            return
+        steps = {int(st['step']) for st in orig.state.values() if 'step' in st}
+        if len(steps) == 1:
+            k = steps.pop()
+            if k != int(opt._step.item()):
+                opt._step.fill_(k)
+
     # ---- the captured step
-    def _capture(self, feats, target):
-        """Builds and captures engine.TrainStep for this batch shape.  Capturing needs one eager warm-up step through the
+    def _capture(self, feats, target, pcm=None):
+        """Builds and captures engine.TrainStep for this batch shape (pcm: a PcmBatch -- the step then starts from the
+        uploaded PCM and contains the front-end).  Capturing needs one eager warm-up step through the
         slot-bound path (it sizes the workspaces the graph will bake in); that step is rolled back -- parameters, Adam
-        moments and step count, BatchNorm running buffers -- so the trajectory is exactly the eager loop's."""
+        moments and step count, BatchNorm running buffers -- so the trajectory is exactly the eager loop's.  The rollback
+        also happens when the warm-up or the capture raises: a failed capture leaves the model as it found it."""
         from .engine import TrainStep
         opt, model = self.optimizer, self.model
-        B, S, F, T = feats.shape
-        step = TrainStep(model, opt, S, batch=B, feature_shape=(F, T), use_graph=True, device=feats.device)
-        step.load_features(feats, target)
+        if pcm is not None:
+            B, K, n, ch = pcm.clips.shape
+            step = TrainStep(model, opt, K - 1, n, ch, B, pcm.n_fft, pcm.hop, use_graph=True, device=pcm.clips.device,
+                             pcm_dtype=pcm.clips.dtype, track_gains=pcm.gain is not None, normalize=pcm.normalize)
+        else:
+            B, S, F, T = feats.shape
+            step = TrainStep(model, opt, S, batch=B, feature_shape=(F, T), use_graph=True, device=feats.device)
         keep = [t.clone() for t in (opt._flat, opt._exp_avg, opt._exp_avg_sq, opt._step)]
         bufs = [(b, b.clone()) for b in model.buffers()]
         training = model.training
-        step.capture(warmup=1)
-        for dst, src in zip((opt._flat, opt._exp_avg, opt._exp_avg_sq, opt._step), keep):
-            dst.copy_(src)
-        for b, saved in bufs:
-            b.copy_(saved)
-        model.train(training)
+        try:
+            if pcm is not None:
+                step.bind_clips(pcm.clips, pcm.gain)
+            else:
+                step.load_features(feats, target)
+            step.capture(warmup=1)
+        except BaseException:
+            step.close()
+            raise
+        finally:
+            for dst, src in zip((opt._flat, opt._exp_avg, opt._exp_avg_sq, opt._step), keep):
+                dst.copy_(src)
+            for b, saved in bufs:
+                b.copy_(saved)
+            model.train(training)
         return step
 
     def _train_batch(self, batch):
-        feats, target = (t.to(self.device) for t in batch)
-        shape = (tuple(feats.shape), tuple(target.shape), feats.dtype, self.model.training)
+        pcm = batch if hasattr(batch, 'clips') else None       # data.dataset.PcmBatch: uploaded PCM, front-end not run yet
+        if pcm is not None:
+            feats = target = None
+            shape = ('pcm', tuple(pcm.clips.shape), pcm.clips.dtype, pcm.gain is not None, pcm.normalize, pcm.n_fft, pcm.hop,
+                     self.model.training)
+        else:
+            feats, target = (t.to(self.device) for t in batch)
+            shape = (tuple(feats.shape), tuple(target.shape), feats.dtype, self.model.training)
         if self._graphable and shape == self._shape and (self._step is not None or self._seen >= self.EAGER_BATCHES):
             if self._step is None:
-                self._step = self._capture(feats, target)
+                self._step = self._capture(feats, target, pcm)
+            if pcm is not None:
+                self._step.bind_clips(pcm.clips, pcm.gain)       # an 8-byte address word (+ the gain table): no PCM / feature copy
             else:
                 self._step.load_features(feats, target)
             self.graph_steps += 1
@@ -85,19 +190,23 @@ class ModelTrainer:
         self._seen += shape == self._shape
         self.eager_steps += 1
         self.optimizer.zero_grad()
-        loss = self._batch_loss((feats, target))
+        loss = self._batch_loss(pcm.features() if pcm is not None else (feats, target))
         loss.backward()
         self.optimizer.step()
         return loss
 
     def close(self):
-        """Drops the captured step and gives the model's parameters back to ordinary autograd (.grad tensors)."""
+        """Drops the captured step and gives the model's parameters back to ordinary autograd (.grad tensors); an adopted
+        torch.optim.Adam gets its step counts."""
         if self._step is not None:
             self._step.close()
             self._step = None
+        self._push_adopted_state()
 
     # ---- one batch -> loss tensor (on the device)
     def _batch_loss(self, batch):
+        if hasattr(batch, 'clips'):
+            batch = batch.features()
         feats, target = (t.to(self.device) for t in batch)
         if self._fused:
             return self.model.forward_mse(feats, target)[0]
@@ -157,6 +266,7 @@ class ModelTrainer:
     def fit(self, train_loader, val_loader, start_epoch, num_epochs):
         history = {'train': [], 'val': []}
         talk = _rank0()
+        self._pull_adopted_step()
         for epoch in range(start_epoch, start_epoch + num_epochs):
             if talk:
                 print('Epoch {}/{}'.format(epoch, num_epochs - 1))
@@ -169,4 +279,5 @@ class ModelTrainer:
                 print('-' * 50)
                 name = _CKPT_PATTERN.format(self.model_name, epoch, history['train'][-1])
                 torch.save(self.model.state_dict(), os.path.join(self.weights_dir, name))
+        self._push_adopted_state()
         return history['train'], history['val']

@@ -51,6 +51,11 @@ _counters = {}
 INKERNEL_FINALIZE = False
 
 
+# Finalize inside the elementwise consumer (dam_bn_finalize_apply_f32; the backward entry points do the same internally):
+# DAM_BN_FUSED_FIN=0 keeps the separate finalize launches (A/B switch; the library reads the same variable)
+FUSED_FINALIZE = os.environ.get('DAM_BN_FUSED_FIN', '1') != '0'
+
+
 # BatchNorm-backward sums from the data-gradient epilogue (include/dam_hip.h: dam_bn_bwd_sums); DAM_NO_DGRAD_SUMS=1 keeps the
 # separate pass over dy and x (A/B switch)
 DGRAD_BN_SUMS = not os.environ.get('DAM_NO_DGRAD_SUMS')
@@ -97,7 +102,7 @@ def _tapgrid(x, B, H, W, C, in_nchw, wp, k_chunks, n_out, bias, in_scale, in_shi
 
 
 def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale=None, in_shift=None,
-               relu_in=False, in_nchw=False, bn_partial=None, bn=None, res=None, relu_out=False):
+               relu_in=False, in_nchw=False, bn_partial=None, bn=None, res=None, relu_out=False, finalize=True):
     """x: NHWC [B,H,W,C] (C % 16 == 0), or NCHW [B,C,H,W] with C <= 16 if in_nchw.  Returns NHWC
     [B,Ho,Wo,n_out] with n_out rounded up to a multiple of 16 (extra channels are zero).
     res (same shape as the result) is added, relu_out applies max(., 0) last: with an eval-mode BatchNorm folded into
@@ -124,9 +129,10 @@ def conv2d_fwd(x, wp, n_out, kh, kw, stride=1, pad=0, dil=1, bias=None, in_scale
                      1, 0, 0, stride, kh, kw, -pad, dil, -pad, dil, 0, kw, 1, res=res, bn_partial=bn_partial, bn_fin=fin,
                      relu_out=relu_out)
     if bn is not None and bn_partial is not None:
-        if parts > 0 and fin is None:      # two-launch form: merge the records with the finalize kernel
+        if parts > 0 and fin is None and finalize:      # two-launch form: merge the records with the finalize kernel
             out4 = bn_finalize(bn_partial, parts, *bn)
-        return y, parts, out4    # parts == 0: no statistics from this launch (out4 is then unset)
+        return y, parts, out4    # parts == 0: no statistics from this launch (out4 is then unset); finalize=False: the caller
+        #                          hands (bn_partial, parts) to bn_finalize_apply
     if bn_partial is not None:
         return y, parts          # parts == 0: the launch could not produce the statistics
     return y
@@ -408,6 +414,32 @@ def bn_stats(x, gamma, beta, running_mean, running_var, num_batches_tracked, mom
                                            _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
                                            _lib.ptr(ws), _lib.ptr(arrival_counter(x.device)), _lib.stream()), 'dam_bn_stats_f32')
     return out[0], out[1], out[2], out[3]
+
+
+def bn_stats_partial(x):
+    """The partial statistics records of NHWC x alone: (records, count) for bn_finalize_apply / bn_finalize."""
+    _lib.require_cuda(x)
+    C = x.shape[-1]
+    ws = bn_partial_buffer(x.device, C)
+    parts = ctypes.c_int(0)
+    _lib.check(_lib.lib().dam_bn_stats_partial_f32(_lib.ptr(x), x.numel() // C, C, _lib.ptr(ws), ctypes.byref(parts), _lib.stream()),
+               'dam_bn_stats_partial_f32')
+    return ws, parts.value
+
+
+def bn_finalize_apply(partial, parts, bn, x, relu=True, res=None, res_scale=None, res_shift=None, sign_bits=False):
+    """bn_finalize + bn_apply in ONE launch (dam_bn_finalize_apply_f32): bn = (gamma, beta, running_mean, running_var,
+    num_batches_tracked, momentum, eps).  Returns ((save_mean, save_invstd, scale, shift), y or (y, bits))."""
+    _lib.require_cuda(partial, x)
+    C = x.shape[-1]
+    out4 = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    fin = _bn_fin_struct(bn, out4, x.device)
+    y = torch.empty_like(x)
+    bits = torch.empty(x.shape[:-1] + (C // 4,), dtype=torch.uint8, device=x.device) if sign_bits else None
+    _lib.check(_lib.lib().dam_bn_finalize_apply_f32(_lib.ptr(partial), int(parts), C, ctypes.byref(fin), _lib.ptr(x), x.numel() // C,
+                                                    _lib.ptr(res), _lib.ptr(res_scale), _lib.ptr(res_shift), 1 if relu else 0,
+                                                    _lib.ptr(y), _lib.ptr(bits), _lib.stream()), 'dam_bn_finalize_apply_f32')
+    return (out4[0], out4[1], out4[2], out4[3]), ((y, bits) if sign_bits else y)
 
 
 def bn_partial_buffer(device, C):

@@ -7,10 +7,17 @@ engine moves buffer k on a dedicated copy stream, and the compute stream only wa
 reverse brings results back.  PyTorch supplies the page-locked memory, the streams and the events; nothing is
 computed here.
 """
+import threading
+
 import numpy as np
 import torch
 
 PIECE_BYTES = 32 << 20
+
+# Held by whoever captures a hipGraph (engine.TrainStep.capture, inference_utils.SongMixer) and, per batch, by background threads
+# around their GPU calls (MultitrackAudioDataset.iter_batches' feeder): a capture and a background thread's event waits / H2D copies /
+# allocator misses then never overlap.  Captures also run in torch's "thread_local" error mode, so this is the second fence.
+capture_guard = threading.RLock()
 
 
 _copy_pool = None

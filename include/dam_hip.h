@@ -50,7 +50,7 @@ struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 /* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
  * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
  * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
-#define DAM_ABI_VERSION 7
+#define DAM_ABI_VERSION 8
 const char* dam_arch(void);
 int dam_abi_version(void);
 
@@ -258,6 +258,20 @@ int dam_bn_finalize_f32(const float* partial, int parts, int C, const float* gam
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
                         float* shift, void* stream);
+
+/* First half of dam_bn_stats_f32 on its own: the partial records [*parts_host][C][3] (a HOST int receives the count), sized
+ * for dam_bn_finalize_apply_f32 (or dam_bn_finalize_f32).  workspace: dam_bn_workspace_floats(C) floats. */
+int dam_bn_stats_partial_f32(const float* x, int64_t n_pixels, int C, float* workspace, int* parts_host, void* stream);
+
+/* dam_bn_finalize_f32 + dam_bn_apply_f32 in ONE launch (relu(bn2(conv2(..)) + shortcut), models/model_resnet.py:26-27; the stem's
+ * and ConvBlock2d's relu(bn(conv(x))), models/model_resnet.py:97, models/model_scalar_1s.py:184-186): every workgroup merges the
+ * records of the 16 or 32 channels it applies in its prologue -- no finalize launch (4.6-5 us each, whatever it does).
+ * fin: the BatchNorm's parameters and outputs as dam_bn_finalize_f32 takes them (all four outputs and the running statistics
+ * are written; `counter` is ignored); the remaining arguments as dam_bn_apply_f32.  DAM_BN_FUSED_FIN=0 in the environment
+ * makes this (and the backward entry points below) run the separate launches instead (A/B switch). */
+int dam_bn_finalize_apply_f32(const float* partial, int parts, int C, const struct dam_bn_fin* fin, const float* x,
+                              int64_t n_pixels, const float* res, const float* res_scale, const float* res_shift, int relu,
+                              float* y, uint8_t* sign_bits, void* stream);
 
 /* Eval-mode equivalent: the same four outputs from the running statistics. */
 int dam_bn_eval_affine_f32(int C, const float* gamma, const float* beta, const float* running_mean,

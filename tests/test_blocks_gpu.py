@@ -256,3 +256,69 @@ def test_upstream_sums_are_dropped_when_the_activation_has_a_second_consumer(dam
         results.append([p.grad.clone() for p in list(stem.parameters()) + list(blk.parameters())])
     for a, c in zip(*results):
         assert float((a - c).norm()) <= 1e-6 * float(c.norm()) + 1e-12
+
+
+# ---- the scalar models' ConvBlock2d at BASELINE config C2's shapes (model_scalar_2s, 4 stems, 1025x130, batch 4) ------------
+SCALAR_BLOCKS = [  # name, cin, cout, k, stride, dilation, input H, W, NCHW input   ("2s C2")
+    ('conv_b1', 4, 16, 3, 2, 2, 1025, 130, True), ('conv_b2', 16, 32, 5, 1, 1, 511, 63, False),
+    ('conv_b3', 32, 48, 5, 1, 1, 507, 59, False), ('conv_b4', 48, 64, 7, 1, 1, 503, 55, False),
+    ('conv_b5', 64, 128, 9, 1, 1, 497, 49, False)]
+
+
+@pytest.mark.parametrize('name,cin,cout,k,stride,dil,H,W,nchw', SCALAR_BLOCKS, ids=[b[0] for b in SCALAR_BLOCKS])
+@pytest.mark.parametrize('slotted', [False, True], ids=['grad', 'slots'])
+def test_conv_block2d_c2_batch4(dam, name, cin, cout, k, stride, dil, H, W, nchw, slotted):
+    """models/model_scalar_2s.py:9-47 / model_scalar_1s.py:151-190 (valid convolution with bias -> BatchNorm eps 1e-3,
+    momentum 0.9 -> ReLU; dropout off) at C2's five block shapes and batch 4: forward, dx, dW, dbias, dgamma, dbeta within
+    2e-5 of the float64 oracle block that takes the device's ReLU decisions (same construction as the BasicBlock tests)."""
+    layers, ops = dam
+    Bs = 4
+    gen = torch.Generator().manual_seed(70 + [b[0] for b in SCALAR_BLOCKS].index(name))
+    blk = _randomize(layers.ConvBlock2d(cin, cout, k, stride=stride, dilation=dil, dropout_p=-1.0, in_nchw=nchw), gen)
+    with torch.no_grad():
+        blk.conv.bias.copy_(0.1 * torch.randn(blk.conv.bias.shape, generator=gen))
+    ref = models_ref.RefConvBlock2d(cin, cout, k, stride, dil, -1.0).double().train()
+    ref.load_state_dict({kk: v.double() for kk, v in blk.state_dict().items()})
+    blk = blk.cuda().train()
+    Ho, Wo = (H - dil * (k - 1) - 1) // stride + 1, (W - dil * (k - 1) - 1) // stride + 1
+    n16 = (cout + 15) // 16 * 16
+    if nchw:      # the stem reads the dB feature stack itself
+        x = -20.0 + 15.0 * torch.randn((Bs, cin, H, W), generator=gen)
+        x_ref = x.double().requires_grad_(True)
+    else:
+        x = torch.relu(torch.randn((Bs, H, W, cin), generator=gen))
+        x_ref = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    dout = torch.randn((Bs, Ho, Wo, n16), generator=gen)
+    dout[..., cout:] = 0
+    params = list(blk.parameters())
+    if slotted:
+        _bind_slots(params)
+    xc = x.cuda().requires_grad_(not nchw)
+    out = blk(xc)
+    assert tuple(out.shape) == (Bs, Ho, Wo, n16)
+    mask = (out[..., :cout] > 0).permute(0, 3, 1, 2).cpu()
+    out.backward(dout.cuda())
+    ops.wgrad_flush()
+    torch.cuda.synchronize()
+    a_r, v = models_ref.stem_forward_masked(ref.conv, ref.batch_norm, x_ref, mask)
+    flips = _check_masks(name, v, mask)
+    a_r.backward(dout[..., :cout].permute(0, 3, 1, 2).double())
+    e_out = _rel(_nchw(out[..., :cout]), a_r.detach())
+    assert e_out <= TOL, ('forward', e_out)
+    report = []
+    pairs = [] if nchw else [('dx', _nchw(xc.grad), x_ref.grad)]
+    for (n_, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        g = p._dam_grad if slotted else p.grad
+        if n_ == 'conv.bias':
+            # exactly zero in exact arithmetic (the BatchNorm subtracts the mean again): rounding noise on both sides, measured
+            # against the scale of the weight gradient
+            wscale = float(ref.conv.weight.grad.norm())
+            assert float(g.double().norm()) <= 1e-4 * wscale and float(q.grad.norm()) <= 1e-9 * wscale
+            continue
+        pairs.append((n_, g, q.grad))
+    bad = _compare_grads(pairs, report)
+    print('%s B=%d: forward %.1e, %d rounding-level ReLU decisions taken from the device; worst gradient %s'
+          % (name, Bs, e_out, flips, max(report, key=lambda r: r[1])))
+    np.testing.assert_allclose(blk.batch_norm.running_var.cpu().numpy(), ref.batch_norm.running_var.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(blk.batch_norm.running_mean.cpu().numpy(), ref.batch_norm.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    assert not bad, bad

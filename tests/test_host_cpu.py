@@ -306,7 +306,8 @@ def test_bench_refuses_to_run_fewer_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
-    if torch.cuda.device_count() >= 2:
+    import bench
+    if (bench.visible_gpu_count() or 0) >= 2:        # counted from sysfs: this process never initialises a GPU runtime
         pytest.skip('multi-GPU host: the spawn path would run for real')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
                        capture_output=True, text=True, timeout=120)

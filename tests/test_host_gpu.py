@@ -47,9 +47,13 @@ def test_dataset_items_match_oracle(dam):
     assert f.shape == (1025, 16)
 
 
-def test_trainer_matches_reference_run(dam, golden_dir, tmp_path, capsys, monkeypatch):
+@pytest.mark.parametrize('opt_kind', ['own', 'torch'])
+def test_trainer_matches_reference_run(dam, golden_dir, tmp_path, capsys, monkeypatch, opt_kind):
     """tests/golden/trainer.json was recorded from the reference's ModelTrainer.fit (CPU, torch Adam) on the same
-    seeded batches and the same parameter fill: same stdout format, same checkpoint names, same loss trajectory."""
+    seeded batches and the same parameter fill: same stdout format, same checkpoint names, same loss trajectory.
+    opt_kind 'torch': the notebook cell as written (training.ipynb cell 11) -- a plain torch.optim.Adam is handed to
+    ModelTrainer, which adopts it into the fused launch: the captured path is taken and the caller's optimizer object
+    stays current (moments, step counts, shared hyper-parameter dict)."""
     from deep_audio_mixer_amd.model_trainer import ModelTrainer
     from deep_audio_mixer_amd.models.model_resnet import ResNet18
     from deep_audio_mixer_amd.optim import Adam
@@ -62,9 +66,23 @@ def test_trainer_matches_reference_run(dam, golden_dir, tmp_path, capsys, monkey
     train, val = batches[:2], batches[2:]
     monkeypatch.chdir(tmp_path)
     os.mkdir('weights')
-    opt = Adam(model.parameters(), lr=g['lr'], weight_decay=1e-5)
+    if opt_kind == 'own':
+        opt = Adam(model.parameters(), lr=g['lr'], weight_decay=1e-5)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=g['lr'], weight_decay=1e-5)
     trainer = ModelTrainer(model, torch.nn.MSELoss(), opt, torch.device('cuda'), model_name='resnet')
     tl, vl = trainer.fit(train, val, g['start_epoch'], g['num_epochs'])
+    n_steps = g['num_epochs'] * len(train)
+    assert trainer.graph_steps == n_steps - trainer.EAGER_BATCHES and trainer.eager_steps == trainer.EAGER_BATCHES
+    if opt_kind == 'torch':
+        assert trainer._adopted_from is opt and isinstance(trainer.optimizer, Adam)
+        assert trainer.optimizer.param_groups[0] is opt.param_groups[0]        # an LR scheduler on `opt` reaches the launch
+        sd = opt.state_dict()                                                  # the caller's object is current
+        assert len(sd['state']) == len(list(model.parameters()))
+        assert all(float(st['step']) == n_steps for st in sd['state'].values())
+        p0 = next(model.parameters())
+        assert torch.equal(opt.state[p0]['exp_avg'], trainer.optimizer.state_dict()['state'][0]['exp_avg'])
+        assert float(opt.state[p0]['exp_avg'].abs().max()) > 0
     out = capsys.readouterr().out.splitlines()
     assert len(out) == len(g['stdout'])
     for got, want in zip(out, g['stdout']):
@@ -437,16 +455,14 @@ def test_trainer_captured_step_equals_eager_loop(dam, tmp_path, monkeypatch, cap
     capsys.readouterr()
 
 
-def test_bench_two_rank_spawn_path_gloo_rehearsal(dam):
-    """`python bench.py --gpus 2` as a fresh process: the parent counts GPUs from sysfs, starts two ranks itself
-    (torch.distributed.run), the ranks run the staged step (graphs A1 / A2 / B, two async buckets) and rank 0 prints ONE line.
-    gloo carries the buckets because this box has one GPU (DAM_DIST_BACKEND=gloo lets two ranks share it); with RCCL the same
-    code path runs one rank per GPU.  Not a scaling number -- the line's shape and the staged schedule are what is checked."""
+def _bench_two_ranks(backend):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
-    env.update(DAM_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'DAM_DIST_BACKEND')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if backend != 'nccl':
+        env.update(DAM_DIST_BACKEND=backend)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
                         '--no-cpu-baseline', '--no-roofline', '--no-host-stream', '--repeat', '1'],
                        env=env, capture_output=True, text=True, timeout=600)
@@ -456,9 +472,141 @@ def test_bench_two_rank_spawn_path_gloo_rehearsal(dam):
     out = json.loads(lines[0])
     cfg = out['config']
     assert out['n_gpus'] == 2 and cfg['world_size'] == 2 and cfg['grad_buckets'] == 2 and cfg['allreduce_overlap'] is True
-    assert cfg['dist_backend'] == 'gloo' and cfg['global_batch'] == 16 and cfg['sync_per_step'] is False
+    assert cfg['dist_backend'] == backend and cfg['global_batch'] == 16 and cfg['sync_per_step'] is False
     assert np.isfinite(cfg['final_loss']) and out['value'] > 0 and out['steps'] == 3
     pr = out['per_rank']
     assert len(pr['ms_per_step']) == 2 and pr['ms_per_step_min'] <= pr['ms_per_step_max']
     assert all(w is not None and w >= 0 for w in pr['exposed_allreduce_wait_ms'])
     assert out['repeat']['regions'] == 1
+    # the two replicas trained on DIFFERENT clips (seed 1234 + rank) and still hold bit-identical parameters: every step's
+    # gradient buckets were summed over both ranks
+    assert cfg['replicas_in_sync'] is True and len(cfg['replica_checksums']['flat_params_weighted']) == 2
+    assert len(cfg['rank_devices']) == 2
+    return out
+
+
+def test_bench_two_rank_spawn_path_gloo_rehearsal(dam):
+    """`python bench.py --gpus 2` as a fresh process: the parent counts GPUs from sysfs, starts two ranks itself
+    (torch.distributed.run), the ranks run the staged step (graphs A1 / A2 / B, two async buckets) and rank 0 prints ONE line.
+    gloo carries the buckets because this box has one GPU (DAM_DIST_BACKEND=gloo lets two ranks share it); with RCCL the same
+    code path runs one rank per GPU.  Not a scaling number -- the line's shape, the staged schedule and the replicas staying
+    in sync are what is checked."""
+    out = _bench_two_ranks('gloo')
+    assert out['config']['rccl_version'] is None
+
+
+def test_bench_two_rank_spawn_path_rccl(dam):
+    """The same spawn path on the DEFAULT backend (RCCL, one rank per GPU) -- runs on the first box that shows two GPUs
+    (the count comes from sysfs, bench.visible_gpu_count(): this process starts no second GPU runtime for it).  Checks what
+    a SCALE record must show: RCCL saw two ranks on two distinct devices, both buckets travelled, and the replicas --
+    fed different clips -- hold bit-identical parameters after the steps."""
+    import bench
+    n = bench.visible_gpu_count() or 0
+    if n < 2:
+        pytest.skip('RCCL needs one GPU per rank: %d visible here' % n)
+    out = _bench_two_ranks('nccl')
+    cfg = out['config']
+    assert cfg['rccl_version'] and len({d['device_index'] for d in cfg['rank_devices']}) == 2
+
+
+def test_trainer_warns_once_when_it_cannot_capture(dam):
+    """A criterion or optimizer the captured step does not reproduce falls back to the eager loop -- loudly."""
+    from deep_audio_mixer_amd.model_trainer import ModelTrainer
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    model = ResNet18(n_stems=2, input_shape=(1025, 17)).cuda()
+    with pytest.warns(RuntimeWarning, match='eager'):
+        ModelTrainer(model, torch.nn.MSELoss(), torch.optim.SGD(model.parameters(), lr=1e-3), torch.device('cuda'))
+    with pytest.warns(RuntimeWarning, match='amsgrad'):
+        ModelTrainer(model, torch.nn.MSELoss(), torch.optim.Adam(model.parameters(), amsgrad=True), torch.device('cuda'))
+    with pytest.warns(RuntimeWarning, match='criterion'):
+        ModelTrainer(model, torch.nn.L1Loss(), torch.optim.Adam(model.parameters()), torch.device('cuda'))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        ModelTrainer(model, torch.nn.L1Loss(), torch.optim.Adam(model.parameters()), torch.device('cuda'), graph=False)
+        ModelTrainer(model, torch.nn.MSELoss(), torch.optim.Adam(model.parameters()), torch.device('cuda'))
+
+
+def test_trainer_pcm_loader_slow_reader_augmentation_torch_adam(dam, tmp_path, monkeypatch, capsys):
+    """ModelTrainer.fit over MultitrackAudioDataset.batch_loader(pcm=True) with augment_data=True, a torch.optim.Adam and an
+    artificially SLOW reader: the feeder thread's GPU calls (event waits, uploads, the augmentation draw's H2D copy, allocator
+    misses) overlap the window in which the trainer captures its step -- captures are thread-local and fenced by
+    staging.capture_guard.  The captured, PCM-fed run (front-end inside the graph, gains through the static table) must
+    reproduce the all-eager, feature-fed run batch for batch: same augmentation draws (seeded), same losses.  (The eager run
+    is handed this package's optim.Adam: both runs then update through the same fused launch -- torch's own foreach Adam
+    rounds differently at the 1e-7 level, which lr 1e-3 sign-like first steps amplify to 1e-3 within three batches.)"""
+    import time
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    from deep_audio_mixer_amd.model_trainer import ModelTrainer
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    monkeypatch.chdir(tmp_path)
+    os.mkdir('weights')
+    sr, tracks = 16384, ['a', 'b', 'mix']
+    rng = np.random.default_rng(11)
+    songs = {}
+    for j, chunks in enumerate((7, 6)):
+        stems = [(0.1 * rng.standard_normal((chunks * sr, 2))).astype(np.float32) for _ in range(2)]
+        songs['s%d' % j] = dict(zip(tracks, stems + [0.7 * stems[0] + 1.2 * stems[1]]))
+    runs = []
+    for graph in (False, True):
+        ds = MultitrackAudioDataset.from_arrays({k: dict(v) for k, v in songs.items()}, chunk_length=1, sr=sr, tracklist=tracks,
+                                                seed=5, augment_data=True)
+        if graph:
+            slow = ds._read_chunk_into
+
+            def slow_read(*a, _real=slow, **k):
+                time.sleep(0.01)
+                return _real(*a, **k)
+            ds._read_chunk_into = slow_read
+        train = ds.batch_loader(2, workers=3, pcm=graph)                # 13 items -> 6 full batches + a ragged one
+        val = ds.batch_loader(2, indices=[0, 1], workers=2, pcm=graph)
+        torch.manual_seed(3)
+        model = ResNet18(n_stems=2, input_shape=(1025, 17)).cuda().train()
+        opt = (torch.optim.Adam if graph else Adam)(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr = ModelTrainer(model, torch.nn.MSELoss(), opt, torch.device('cuda'), model_name='p', graph=graph)
+        assert (tr._adopted_from is opt) == graph
+        per_batch = []
+        real = tr._train_batch
+        tr._train_batch = lambda b, real=real, acc=per_batch: acc.append(real(b).item()) or torch.tensor(acc[-1])
+        tl, vl = tr.fit(train, val, 0, 2)
+        if graph:
+            assert (tr.graph_steps, tr.eager_steps) == (10, 4)
+            assert tr._step is not None and tr._step.gain is not None and not tr._step.from_features
+        runs.append((per_batch, tl, vl))
+        tr.close()
+    np.testing.assert_allclose(runs[1][0], runs[0][0], rtol=2e-5)
+    np.testing.assert_allclose(runs[1][1], runs[0][1], rtol=2e-5)
+    # (the validation pass re-reads items 0 and 1: a fresh augmentation draw per read, the same in both runs)
+    np.testing.assert_allclose(runs[1][2], runs[0][2], rtol=2e-5)
+    capsys.readouterr()
+
+
+def test_train_step_missing_gradient_raises_before_the_update(dam):
+    """A bound parameter that backward never reaches: the first eager step raises BEFORE the all-reduce / Adam launch, so
+    parameters and moments are untouched (the poison used to reach Adam), the slots are unbound again, and a
+    genuinely non-finite gradient is not mistaken for a missing one."""
+    from deep_audio_mixer_amd.engine import TrainStep
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    torch.manual_seed(0)
+    model = ResNet18(n_stems=2, input_shape=(1025, 17)).cuda().train()
+    orphan = torch.nn.Parameter(torch.ones(5, device='cuda'))
+    opt = Adam(list(model.parameters()) + [orphan], lr=1e-3)
+    before = opt._flat.clone()
+    step = TrainStep(model, opt, 2, batch=2, feature_shape=(1025, 17), use_graph=False)
+    x, gt = (torch.from_numpy(a).cuda() for a in model_input(2, 2, 1025, 17, seed=1))
+    step.load_features(x, gt)
+    with pytest.raises(RuntimeError, match='wrote no gradient'):
+        step.capture(warmup=1)
+    assert torch.equal(opt._flat, before) and int(opt._step.item()) == 0
+    assert float(opt._exp_avg.abs().max()) == 0.0 and not hasattr(orphan, '_dam_grad')
+    # a NaN that backward itself produced is a gradient, not a missing slot
+    model2 = ResNet18(n_stems=2, input_shape=(1025, 17)).cuda().train()
+    opt2 = Adam(model2.parameters(), lr=1e-3)
+    step2 = TrainStep(model2, opt2, 2, batch=2, feature_shape=(1025, 17), use_graph=False)
+    bad = x.clone()
+    bad[0, 0, 0, 0] = float('nan')
+    step2.load_features(bad, gt)
+    step2.capture(warmup=1)            # must not raise 'wrote no gradient'
+    step2.close()
