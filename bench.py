@@ -619,6 +619,8 @@ def run_via_trainer(name, cfg, args):
             with contextlib.redirect_stdout(io.StringIO()):
                 trainer.fit(train, val, 0, 1)                    # epoch 0: two eager batches, the capture, replays
                 n_epochs = max(1, args.steps // len(train))
+                for k in trainer.host_times:
+                    trainer.host_times[k] = 0.0
                 t0 = time.perf_counter()
                 tl, vl = trainer.fit(train, val, 1, n_epochs)
                 torch.cuda.synchronize()
@@ -638,7 +640,8 @@ def run_via_trainer(name, cfg, args):
                    'decode_threads': args.workers, 'pcm': 'float32' if args.float_pcm else 'int16 (16-bit PCM)',
                    'optimizer_passed': 'deep_audio_mixer_amd.optim.Adam' if args.own_adam else 'torch.optim.Adam (adopted by ModelTrainer)',
                    'loader': 'PcmBatch (front-end inside the captured step)' if pcm_fed else 'features (front-end per batch on the copy stream)',
-                   'graph_steps': trainer.graph_steps,
+                   'graph_steps': trainer.graph_steps, 'epoch_s': epoch_s[1:],
+                   'host_ms_per_step': {k: 1e3 * v / steps for k, v in trainer.host_times.items()},
                    'eager_steps': trainer.eager_steps, 'epochs_timed': n_epochs, 'batches_per_epoch': len(train),
                    'ms_per_step_incl_validation_and_checkpoint': 1e3 * fit_s / steps, 'final_train_loss': tl[-1]}}), flush=True)
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     'dam_bn_workspace_floats': (c_i64, [c_i]),
     'dam_bn_stats_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_finalize_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    'dam_strip_diag_counters': (c_i, [c_p, c_i]),
     'dam_bn_stats_partial_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p]),
     'dam_bn_finalize_apply_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     'dam_bn_eval_affine_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),

@@ -34,7 +34,15 @@ inline BnLaunch bn_plan(int64_t P, int C, int max_parts = BN_MAX_PARTS) {
     if (l.r < 1) l.r = 1;
     l.threads = l.q * l.r;
     int64_t parts = cdiv(P, (int64_t)l.r * 16);          // ~16 pixels (two batches of 8 loads) per thread
-    if (parts > max_parts) parts = max_parts;
+    if (parts > max_parts) {
+        // a consumer that merges the records itself wants few of them (fa_max_parts): the workgroups grow instead, so that the
+        // pass still has >= 2048 waves to cover the memory latency (170 workgroups of 4 waves ran a 34 MB pair pass 8 us slower)
+        parts = max_parts;
+        while (l.threads < 1024 && parts * l.threads < 131072 && (size_t)(l.r * 2) * C * 3 * sizeof(float) <= 48 * 1024) {
+            l.r *= 2;
+            l.threads *= 2;
+        }
+    }
     if (parts < 1) parts = 1;
     l.ppb = cdiv(P, parts);
     l.parts = (int)cdiv(P, l.ppb);
@@ -623,37 +631,50 @@ __global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const float* _
 // ================================================================================================================================
 #define DAM_Z4 make_float4(0.f, 0.f, 0.f, 0.f)
 constexpr int FA_THREADS = 256;
-constexpr int FA_U = 4;                 // pixel pieces in flight per thread and stream
+constexpr int FA_U = 4;                 // pixel pieces per thread, stream and register set (two sets: the next batch's loads are
+                                        // requested before the current batch is computed and stored)
 
 struct FaPlan { int cs, nslices, nranges, q, ppi; int64_t ppr; };
 
 // CS: the whole row for thin layers (one 128-byte line per pixel at 32 channels), 16-channel slices above that (64-byte pieces:
 // the wide layers' tensors are small and L2 resident; what matters there is the table a workgroup has to merge)
-inline FaPlan fa_plan(int64_t P, int C, int parts, int rec_floats) {
+inline int fa_cs(int C) { return C <= 32 ? C : 16; }
+inline FaPlan fa_plan(int64_t P, int C) {
     FaPlan f;
-    f.cs = C <= 32 ? C : 16;
-    // a slice table beyond ~96 KB costs more to read than it saves: narrower slices are not possible (16 = one MFMA block of
-    // channels everywhere else in this library), so callers keep `parts` bounded (dam_bn_backward_f32 caps its own partial pass)
-    (void)parts; (void)rec_floats;
+    f.cs = fa_cs(C);
     f.nslices = C / f.cs;
     f.q = f.cs / 4;
     f.ppi = FA_THREADS / f.q;
+    static const int wgs = [] { const char* e = getenv("DAM_BN_FA_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
     int64_t want = P / ((int64_t)f.ppi * FA_U * 2);       // >= two batches of loads per thread
-    const int64_t cap = 512 / f.nslices > 0 ? 512 / f.nslices : 1;
+    const int64_t cap = wgs / f.nslices > 0 ? wgs / f.nslices : 1;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     f.ppr = cdiv(P, want);
     f.nranges = (int)cdiv(P, f.ppr);
     return f;
 }
+// a slice table beyond this costs a workgroup more to read than the finalize launch it replaces (measured: 110 KB tables made the
+// 129 x 17 stage's fused launch 5 us slower than finalize + apply, 74 KB ones broke even)
+constexpr int FA_TABLE_BYTES_MAX = 80 * 1024;
+inline bool fa_table_ok(int C, int parts, int rec_floats) { return (int64_t)parts * fa_cs(C) * rec_floats * 4 <= FA_TABLE_BYTES_MAX; }
+// The FORWARD form pays more per record (12 bytes, a divide-free but longer merge, sqrt) and its launches on the full-resolution
+// stages measured 2-3 us SLOWER than finalize + apply (48 KB tables x 512 workgroups = 24 MB of table reads in front of a 35 us
+// stream), the small stages' about equal: it is taken only for tables up to DAM_BN_FUSED_FWD_KB (default 24) KB per workgroup --
+// the backward forms win 1.5-2.5 us per launch on every stage and are taken up to FA_TABLE_BYTES_MAX.
+inline bool fa_fwd_table_ok(int C, int parts) {
+    static const int kb = [] { const char* e = getenv("DAM_BN_FUSED_FWD_KB"); const int v = e ? atoi(e) : -1; return v >= 0 ? v : 24; }();
+    return fa_table_ok(C, parts, 3) && (int64_t)parts * fa_cs(C) * 12 <= (int64_t)kb * 1024;
+}
 
-// Sums NV per-record values over the slice's records: thread (c = tid % CS, i = tid / CS) takes records i, i + TPC, ...;
-// tid < CS ends up with the channel's totals in acc[].  `term(rec, v)` turns one record (NR floats) into its NV addends.
+// Sums NV per-record values over the slice's records: thread (c = tid % CS, i = tid / CS) takes records i, i + TPC, ...; every
+// record of a thread is requested before the first is used (<= 16 per thread and round: one round trip for tables up to 256
+// records of 16 channels); tid < CS ends up with the channel's totals in acc[].  `term(rec, v)`: one record (NR floats) -> NV addends.
 template <int NR, int NV, typename F>
 __device__ __forceinline__ void fa_slice_sums(const float* __restrict__ partial, int parts, int C, int ch, int CS, double* red,
                                               double (&acc)[NV], F term) {
     const int tid = threadIdx.x, TPC = FA_THREADS / CS, i0 = tid / CS;
-    constexpr int RU = 8;
+    constexpr int RU = 16;
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0;
     for (int p0 = i0; p0 < parts; p0 += TPC * RU) {
@@ -683,6 +704,19 @@ __device__ __forceinline__ void fa_slice_sums(const float* __restrict__ partial,
             for (int k = 0; k < NV; ++k) acc[k] += red[(tid + i * CS) * NV + k];
 }
 
+// Two register sets alternate: LOAD(set, p0) requests a batch, EMIT(set, p0) computes and stores it.
+#define DAM_FA_STREAM(LOAD_, EMIT_, STEP_)                                                                                     \
+    for (int64_t p0 = lo + tp;;) {                                                                                            \
+        if (p0 + (STEP_) < hi) { LOAD_(1, p0 + (STEP_)); }                                                                    \
+        EMIT_(0, p0);                                                                                                         \
+        p0 += (STEP_);                                                                                                        \
+        if (p0 >= hi) break;                                                                                                  \
+        if (p0 + (STEP_) < hi) { LOAD_(0, p0 + (STEP_)); }                                                                    \
+        EMIT_(1, p0);                                                                                                         \
+        p0 += (STEP_);                                                                                                        \
+        if (p0 >= hi) break;                                                                                                  \
+    }
+
 __global__ __launch_bounds__(FA_THREADS) void bn_fin_apply_kernel(const float* __restrict__ partial, int parts, int C, int CS,
                                                                    const BnFinArgs fin, const float* __restrict__ x, int64_t P,
                                                                    int64_t ppr, const float* __restrict__ res,
@@ -693,14 +727,16 @@ __global__ __launch_bounds__(FA_THREADS) void bn_fin_apply_kernel(const float* _
     const int tid = threadIdx.x, slice = blockIdx.y, q = CS / 4, tq = tid % q, tp = tid / q, ppi = FA_THREADS / q;
     const int Q = C / 4, cq = slice * q + tq;
     const int64_t lo = blockIdx.x * ppr, hi = (lo + ppr < P) ? lo + ppr : P;
-    // the first pieces are requested before the records: the table's round trip hides behind them
-    float4 xv[FA_U], rv[FA_U];
-#pragma unroll
-    for (int u = 0; u < FA_U; ++u) {
-        const int64_t p = lo + tp + (int64_t)u * ppi;
-        xv[u] = p < hi ? reinterpret_cast<const float4*>(x)[p * Q + cq] : DAM_Z4;
-        rv[u] = (res && p < hi) ? reinterpret_cast<const float4*>(res)[p * Q + cq] : DAM_Z4;
+    const int64_t step = (int64_t)ppi * FA_U;
+    float4 xv[2][FA_U], rv[2][FA_U];
+#define DAM_FA_LOAD(S_, P0_)                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < FA_U; ++u) {                                                                        \
+        const int64_t p = (P0_) + (int64_t)u * ppi;                                                                           \
+        xv[S_][u] = p < hi ? reinterpret_cast<const float4*>(x)[p * Q + cq] : DAM_Z4;                                         \
+        if (res) rv[S_][u] = p < hi ? reinterpret_cast<const float4*>(res)[p * Q + cq] : DAM_Z4;                              \
     }
+    // the first pieces are requested before the records: the table's round trip hides behind them
+    DAM_FA_LOAD(0, lo + tp)
     float4 ra = make_float4(1.f, 1.f, 1.f, 1.f), rb = DAM_Z4;
     if (rscale) { ra = reinterpret_cast<const float4*>(rscale)[cq]; rb = reinterpret_cast<const float4*>(rshift)[cq]; }
     {
@@ -734,31 +770,26 @@ __global__ __launch_bounds__(FA_THREADS) void bn_fin_apply_kernel(const float* _
         __syncthreads();
     }
     const float4 sc = *reinterpret_cast<const float4*>(tab + tq * 4), sh = *reinterpret_cast<const float4*>(tab + CS + tq * 4);
-    for (int64_t p0 = lo + tp;;) {
-#pragma unroll
-        for (int u = 0; u < FA_U; ++u) {
-            const int64_t p = p0 + (int64_t)u * ppi;
-            if (p >= hi) continue;
-            const float4 v = xv[u];
-            float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-            if (res) {
-                float4 r = rv[u];
-                if (rscale) r = make_float4(fmaf(r.x, ra.x, rb.x), fmaf(r.y, ra.y, rb.y), fmaf(r.z, ra.z, rb.z), fmaf(r.w, ra.w, rb.w));
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            }
-            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            reinterpret_cast<float4*>(y)[p * Q + cq] = o;
-            if (sign_bits) sign_bits[p * Q + cq] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
-        }
-        p0 += (int64_t)ppi * FA_U;
-        if (p0 >= hi) break;
-#pragma unroll
-        for (int u = 0; u < FA_U; ++u) {
-            const int64_t p = p0 + (int64_t)u * ppi;
-            xv[u] = p < hi ? reinterpret_cast<const float4*>(x)[p * Q + cq] : DAM_Z4;
-            rv[u] = (res && p < hi) ? reinterpret_cast<const float4*>(res)[p * Q + cq] : DAM_Z4;
-        }
+#define DAM_FA_EMIT(S_, P0_)                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < FA_U; ++u) {                                                                        \
+        const int64_t p = (P0_) + (int64_t)u * ppi;                                                                           \
+        if (p < hi) {                                                                                                         \
+            const float4 v = xv[S_][u];                                                                                       \
+            float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)); \
+            if (res) {                                                                                                        \
+                float4 r = rv[S_][u];                                                                                         \
+                if (rscale) r = make_float4(fmaf(r.x, ra.x, rb.x), fmaf(r.y, ra.y, rb.y), fmaf(r.z, ra.z, rb.z), fmaf(r.w, ra.w, rb.w)); \
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;                                                               \
+            }                                                                                                                 \
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }         \
+            reinterpret_cast<float4*>(y)[p * Q + cq] = o;                                                                     \
+            if (sign_bits)                                                                                                    \
+                sign_bits[p * Q + cq] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3)); \
+        }                                                                                                                     \
     }
+    DAM_FA_STREAM(DAM_FA_LOAD, DAM_FA_EMIT, step)
+#undef DAM_FA_LOAD
+#undef DAM_FA_EMIT
 }
 
 // Backward: records [parts][C][2] = (sum dz, sum dz * xhat) -> dgamma / dbeta (range 0 writes them) and dx = c1 dz + c2 x + c3.
@@ -776,17 +807,19 @@ __global__ __launch_bounds__(FA_THREADS) void bn_bwd_fin_apply_kernel(const floa
     const int tid = threadIdx.x, slice = blockIdx.y, q = CS / 4, tq = tid % q, tp = tid / q, ppi = FA_THREADS / q;
     const int Q = C / 4, cq = slice * q + tq;
     const int64_t lo = blockIdx.x * ppr, hi = (lo + ppr < P) ? lo + ppr : P;
-    float4 gv[FA_U], xv[FA_U], mv[FA_U];
-#define DAM_FA_BWD_LOAD(P0_)                                                                                                  \
-    _Pragma("unroll") for (int u = 0; u < FA_U; ++u) {                                                                        \
+    constexpr int UB = 3;               // three streams: three pieces each per register set
+    const int64_t step = (int64_t)ppi * UB;
+    float4 gv[2][UB], xv[2][UB], mv[2][UB];
+#define DAM_FA_LOAD(S_, P0_)                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < UB; ++u) {                                                                          \
         const int64_t p = (P0_) + (int64_t)u * ppi;                                                                           \
         const bool ok = p < hi;                                                                                               \
-        gv[u] = ok ? reinterpret_cast<const float4*>(dy)[p * Q + cq] : DAM_Z4;                                                    \
-        xv[u] = ok ? reinterpret_cast<const float4*>(x)[p * Q + cq] : DAM_Z4;                                                     \
-        if (MASK == 1) mv[u] = ok ? reinterpret_cast<const float4*>(y_mask)[p * Q + cq] : DAM_Z4;                                 \
-        if (MASK == 3) mv[u] = sign_quad(ok ? reinterpret_cast<const unsigned char*>(y_mask)[p * Q + cq] : 0);                \
+        gv[S_][u] = ok ? reinterpret_cast<const float4*>(dy)[p * Q + cq] : DAM_Z4;                                            \
+        xv[S_][u] = ok ? reinterpret_cast<const float4*>(x)[p * Q + cq] : DAM_Z4;                                             \
+        if (MASK == 1) mv[S_][u] = ok ? reinterpret_cast<const float4*>(y_mask)[p * Q + cq] : DAM_Z4;                         \
+        if (MASK == 3) mv[S_][u] = sign_quad(ok ? reinterpret_cast<const unsigned char*>(y_mask)[p * Q + cq] : 0);            \
     }
-    DAM_FA_BWD_LOAD(lo + tp)
+    DAM_FA_LOAD(0, lo + tp)
     float4 msc = DAM_Z4, msh = DAM_Z4;
     if (MASK == 2) { msc = reinterpret_cast<const float4*>(mscale)[cq]; msh = reinterpret_cast<const float4*>(mshift)[cq]; }
     {
@@ -806,28 +839,26 @@ __global__ __launch_bounds__(FA_THREADS) void bn_bwd_fin_apply_kernel(const floa
     }
     const float4 c1 = *reinterpret_cast<const float4*>(tab + tq * 4), c2 = *reinterpret_cast<const float4*>(tab + CS + tq * 4),
                  c3 = *reinterpret_cast<const float4*>(tab + 2 * CS + tq * 4);
-    for (int64_t p0 = lo + tp;;) {
-#pragma unroll
-        for (int u = 0; u < FA_U; ++u) {
-            const int64_t p = p0 + (int64_t)u * ppi;
-            if (p >= hi) continue;
-            float4 g = gv[u];
-            const float4 v = xv[u];
-            if (MASK != 0) {
-                float4 m = mv[u];
-                if (MASK == 2) m = make_float4(fmaf(v.x, msc.x, msh.x), fmaf(v.y, msc.y, msh.y), fmaf(v.z, msc.z, msh.z), fmaf(v.w, msc.w, msh.w));
-                g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
-            }
-            float4 o;
-            o.x = fmaf(c1.x, g.x, fmaf(c2.x, v.x, c3.x)); o.y = fmaf(c1.y, g.y, fmaf(c2.y, v.y, c3.y));
-            o.z = fmaf(c1.z, g.z, fmaf(c2.z, v.z, c3.z)); o.w = fmaf(c1.w, g.w, fmaf(c2.w, v.w, c3.w));
-            reinterpret_cast<float4*>(dx)[p * Q + cq] = o;
-        }
-        p0 += (int64_t)ppi * FA_U;
-        if (p0 >= hi) break;
-        DAM_FA_BWD_LOAD(p0)
+#define DAM_FA_EMIT(S_, P0_)                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < UB; ++u) {                                                                          \
+        const int64_t p = (P0_) + (int64_t)u * ppi;                                                                           \
+        if (p < hi) {                                                                                                         \
+            float4 g = gv[S_][u];                                                                                             \
+            const float4 v = xv[S_][u];                                                                                       \
+            if (MASK != 0) {                                                                                                  \
+                float4 m = mv[S_][u];                                                                                         \
+                if (MASK == 2) m = make_float4(fmaf(v.x, msc.x, msh.x), fmaf(v.y, msc.y, msh.y), fmaf(v.z, msc.z, msh.z), fmaf(v.w, msc.w, msh.w)); \
+                g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f; \
+            }                                                                                                                 \
+            float4 o;                                                                                                         \
+            o.x = fmaf(c1.x, g.x, fmaf(c2.x, v.x, c3.x)); o.y = fmaf(c1.y, g.y, fmaf(c2.y, v.y, c3.y));                       \
+            o.z = fmaf(c1.z, g.z, fmaf(c2.z, v.z, c3.z)); o.w = fmaf(c1.w, g.w, fmaf(c2.w, v.w, c3.w));                       \
+            reinterpret_cast<float4*>(dx)[p * Q + cq] = o;                                                                    \
+        }                                                                                                                     \
     }
-#undef DAM_FA_BWD_LOAD
+    DAM_FA_STREAM(DAM_FA_LOAD, DAM_FA_EMIT, step)
+#undef DAM_FA_LOAD
+#undef DAM_FA_EMIT
 }
 
 // The pair form (a residual block's bn2 and its shortcut BatchNorm): records [parts][C][3] = (sum dz, sum dz xhat_a, sum dz xhat_b).
@@ -843,19 +874,20 @@ __global__ __launch_bounds__(FA_THREADS) void bn_bwd_fin_apply_pair_kernel(const
     const int tid = threadIdx.x, slice = blockIdx.y, q = CS / 4, tq = tid % q, tp = tid / q, ppi = FA_THREADS / q;
     const int Q = C / 4, cq = slice * q + tq;
     const int64_t lo = blockIdx.x * ppr, hi = (lo + ppr < P) ? lo + ppr : P;
-    constexpr int UP = 2;               // four streams: two pieces each in flight
-    float4 gv[UP], va[UP], vb[UP], mv[UP];
-#define DAM_FA_PAIR_LOAD(P0_)                                                                                                 \
+    constexpr int UP = 2;               // four streams: two pieces each per register set
+    const int64_t step = (int64_t)ppi * UP;
+    float4 gv[2][UP], va[2][UP], vb[2][UP], mv[2][UP];
+#define DAM_FA_LOAD(S_, P0_)                                                                                                  \
     _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                                          \
         const int64_t p = (P0_) + (int64_t)u * ppi;                                                                           \
         const bool ok = p < hi;                                                                                               \
-        gv[u] = ok ? reinterpret_cast<const float4*>(dy)[p * Q + cq] : DAM_Z4;                                                    \
-        va[u] = ok ? reinterpret_cast<const float4*>(xa)[p * Q + cq] : DAM_Z4;                                                    \
-        vb[u] = ok ? reinterpret_cast<const float4*>(xb)[p * Q + cq] : DAM_Z4;                                                    \
-        if (BITS) mv[u] = sign_quad(ok ? reinterpret_cast<const unsigned char*>(y_mask)[p * Q + cq] : 0);                     \
-        else mv[u] = ok ? reinterpret_cast<const float4*>(y_mask)[p * Q + cq] : DAM_Z4;                                           \
+        gv[S_][u] = ok ? reinterpret_cast<const float4*>(dy)[p * Q + cq] : DAM_Z4;                                            \
+        va[S_][u] = ok ? reinterpret_cast<const float4*>(xa)[p * Q + cq] : DAM_Z4;                                            \
+        vb[S_][u] = ok ? reinterpret_cast<const float4*>(xb)[p * Q + cq] : DAM_Z4;                                            \
+        if (BITS) mv[S_][u] = sign_quad(ok ? reinterpret_cast<const unsigned char*>(y_mask)[p * Q + cq] : 0);                 \
+        else mv[S_][u] = ok ? reinterpret_cast<const float4*>(y_mask)[p * Q + cq] : DAM_Z4;                                   \
     }
-    DAM_FA_PAIR_LOAD(lo + tp)
+    DAM_FA_LOAD(0, lo + tp)
     {
         const int cl = tid % CS, ch = slice * CS + cl;
         const float ga_ = gamma_a[ch], ia = invstd_a[ch], ma = mean_a[ch], gb_ = gamma_b[ch], ib = invstd_b[ch], mb = mean_b[ch];
@@ -881,29 +913,27 @@ __global__ __launch_bounds__(FA_THREADS) void bn_bwd_fin_apply_pair_kernel(const
     float4 k[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) k[i] = *reinterpret_cast<const float4*>(tab + i * CS + tq * 4);
-    for (int64_t p0 = lo + tp;;) {
-#pragma unroll
-        for (int u = 0; u < UP; ++u) {
-            const int64_t p = p0 + (int64_t)u * ppi;
-            if (p >= hi) continue;
-            float4 g = gv[u];
-            const float4 m = mv[u], v = va[u], w = vb[u];
-            g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
-            float4 o, r;
-            o.x = fmaf(k[0].x, g.x, fmaf(k[1].x, v.x, k[2].x)); o.y = fmaf(k[0].y, g.y, fmaf(k[1].y, v.y, k[2].y));
-            o.z = fmaf(k[0].z, g.z, fmaf(k[1].z, v.z, k[2].z)); o.w = fmaf(k[0].w, g.w, fmaf(k[1].w, v.w, k[2].w));
-            r.x = fmaf(k[3].x, g.x, fmaf(k[4].x, w.x, k[5].x)); r.y = fmaf(k[3].y, g.y, fmaf(k[4].y, w.y, k[5].y));
-            r.z = fmaf(k[3].z, g.z, fmaf(k[4].z, w.z, k[5].z)); r.w = fmaf(k[3].w, g.w, fmaf(k[4].w, w.w, k[5].w));
-            reinterpret_cast<float4*>(dxa)[p * Q + cq] = o;
-            reinterpret_cast<float4*>(dxb)[p * Q + cq] = r;
-        }
-        p0 += (int64_t)ppi * UP;
-        if (p0 >= hi) break;
-        DAM_FA_PAIR_LOAD(p0)
+#define DAM_FA_EMIT(S_, P0_)                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                                          \
+        const int64_t p = (P0_) + (int64_t)u * ppi;                                                                           \
+        if (p < hi) {                                                                                                         \
+            float4 g = gv[S_][u];                                                                                             \
+            const float4 m = mv[S_][u], v = va[S_][u], w = vb[S_][u];                                                         \
+            g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f; g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f; \
+            float4 o, r;                                                                                                      \
+            o.x = fmaf(k[0].x, g.x, fmaf(k[1].x, v.x, k[2].x)); o.y = fmaf(k[0].y, g.y, fmaf(k[1].y, v.y, k[2].y));           \
+            o.z = fmaf(k[0].z, g.z, fmaf(k[1].z, v.z, k[2].z)); o.w = fmaf(k[0].w, g.w, fmaf(k[1].w, v.w, k[2].w));           \
+            r.x = fmaf(k[3].x, g.x, fmaf(k[4].x, w.x, k[5].x)); r.y = fmaf(k[3].y, g.y, fmaf(k[4].y, w.y, k[5].y));           \
+            r.z = fmaf(k[3].z, g.z, fmaf(k[4].z, w.z, k[5].z)); r.w = fmaf(k[3].w, g.w, fmaf(k[4].w, w.w, k[5].w));           \
+            reinterpret_cast<float4*>(dxa)[p * Q + cq] = o;                                                                   \
+            reinterpret_cast<float4*>(dxb)[p * Q + cq] = r;                                                                   \
+        }                                                                                                                     \
     }
-#undef DAM_FA_PAIR_LOAD
+    DAM_FA_STREAM(DAM_FA_LOAD, DAM_FA_EMIT, step)
+#undef DAM_FA_LOAD
+#undef DAM_FA_EMIT
 }
-
+#undef DAM_FA_STREAM
 #undef DAM_Z4
 inline int elt_blocks(int64_t n) {
     int64_t b = cdiv(n, 256);
@@ -918,8 +948,7 @@ inline bool fa_enabled() {
 
 // records a partial pass may leave for a fused consumer: a workgroup's slice table stays <= 64 KB
 inline int fa_max_parts(int C, int rec_floats) {
-    const int cs = C <= 32 ? C : 16;
-    int m = 65536 / (cs * rec_floats * 4);
+    int m = 65536 / (fa_cs(C) * rec_floats * 4);
     if (m > BN_MAX_PARTS) m = BN_MAX_PARTS;
     return m < 64 ? 64 : m;
 }
@@ -955,14 +984,14 @@ extern "C" int dam_bn_finalize_apply_f32(const float* partial, int parts, int C,
     if (res_scale && (!res || !res_shift)) return DAM_ERR_BAD_ARG;
     if (C % 16 || C > 1024) return DAM_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (!fa_enabled()) {
+    if (!fa_enabled() || !fa_fwd_table_ok(C, parts)) {
         int rc = dam_bn_finalize_f32(partial, parts, C, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
                                      fin->num_batches_tracked, fin->momentum, fin->eps, fin->save_mean, fin->save_invstd, fin->scale,
                                      fin->shift, stream);
         if (rc != DAM_OK) return rc;
         return dam_bn_apply_f32(x, n_pixels, C, fin->scale, fin->shift, res, res_scale, res_shift, relu, y, sign_bits, stream);
     }
-    const FaPlan f = fa_plan(n_pixels, C, parts, 3);
+    const FaPlan f = fa_plan(n_pixels, C);
     const BnFinArgs a{fin->gamma, fin->beta, fin->running_mean, fin->running_var, (long long*)fin->num_batches_tracked, fin->momentum,
                       fin->eps, fin->save_mean, fin->save_invstd, fin->scale, fin->shift, nullptr};
     hipLaunchKernelGGL(bn_fin_apply_kernel, dim3(f.nranges, f.nslices), dim3(FA_THREADS), 0, st, partial, parts, C, f.cs, a, x,
@@ -1070,6 +1099,7 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
     BnLaunch l = bn_plan(n_pixels, C, fused ? fa_max_parts(C, 2) : BN_MAX_PARTS);
     if (partials_given < 0 || partials_given > BN_MAX_PARTS) return DAM_ERR_BAD_ARG;
     if (partials_given) { l.parts = partials_given; counter = nullptr; }       // records from a data-gradient epilogue
+    const bool fuse_now = fused && fa_table_ok(C, l.parts, 2);
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + (size_t)BN_MAX_PARTS * C * 2;    // workspace holds [parts][C][2] then [3][C]
     const int mask = mask_bits ? 3 : (y_mask ? 1 : (mask_scale ? 2 : 0));
@@ -1081,8 +1111,8 @@ extern "C" int dam_bn_backward_f32(const float* dy, const float* y_mask, const f
     else if (mask == 1) DAM_BN_PARTIAL(1); else if (mask == 2) DAM_BN_PARTIAL(2); else if (mask == 3) DAM_BN_PARTIAL(3); else DAM_BN_PARTIAL(0);
 #undef DAM_BN_PARTIAL
     DAM_CHECK_LAUNCH();
-    if (fused) {        // finalize inside the apply launch (bn_bwd_fin_apply_kernel)
-        const FaPlan f = fa_plan(n_pixels, C, l.parts, 2);
+    if (fuse_now) {     // finalize inside the apply launch (bn_bwd_fin_apply_kernel)
+        const FaPlan f = fa_plan(n_pixels, C);
 #define DAM_BN_FA(M_)                                                                                                        \
     hipLaunchKernelGGL(bn_bwd_fin_apply_kernel<M_>, dim3(f.nranges, f.nslices), dim3(FA_THREADS), 0, st, workspace, l.parts, C, \
                        f.cs, (double)n_pixels, gamma, save_mean, save_invstd, training, dgamma, dbeta, dy, y_mask, x, n_pixels, \
@@ -1135,7 +1165,7 @@ extern "C" int dam_bn_backward_pair_f32(const float* dy, const float* y_mask, co
                            dy, y_mask, x_a, x_b, n_pixels, C, l.q, l.r, l.ppb, mean_a, invstd_a, mean_b, invstd_b, workspace);
     DAM_CHECK_LAUNCH();
     if (fused) {
-        const FaPlan f = fa_plan(n_pixels, C, l.parts, 3);
+        const FaPlan f = fa_plan(n_pixels, C);
         if (bits)
             hipLaunchKernelGGL(bn_bwd_fin_apply_pair_kernel<true>, dim3(f.nranges, f.nslices), dim3(FA_THREADS), 0, st, workspace, l.parts,
                                C, f.cs, (double)n_pixels, gamma_a, mean_a, invstd_a, gamma_b, mean_b, invstd_b, training, dgamma_a,

@@ -636,8 +636,12 @@ int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
         const int64_t parts = (int64_t)g.B * g.tiles_m * (4 / KS);
         mode = bwd.x ? 2 : 1;
         // one channel-block group per unit row (every unit has all the layer's channels: the 1 x 4 tile of a 64-channel stage):
-        // the workgroups accumulate over their units and leave ONE record each (kernel: stats_acc)
-        static const bool acc_ok = [] { const char* e = getenv("DAM_PIPE_STATS_ACC"); return !(e && e[0] == '0'); }();
+        // the workgroups accumulate over their units and leave ONE record each (kernel: stats_acc).  BUILT, PARITY-GREEN, MEASURED
+        // SLOWER, OFF (DAM_PIPE_STATS_ACC=1 turns it on for the A/B): it removes the 257 x 33 stage's five separate statistics /
+        // backward-sums passes (3 x 8.6 + 2 x 11 us), but the 1 x 4 tile's instantiations WITH an epilogue run 61.9 us (forward
+        // statistics, 512 workgroups) and 73.8 us (backward sums: 256 workgroups, the register budget of two per CU is gone)
+        // against 52.6 us without -- C3 step 4.456 -> 4.483 ms on one box (gpurun_out/r4, profiles/r04_pipe_stats_acc_ab.txt)
+        static const bool acc_ok = [] { const char* e = getenv("DAM_PIPE_STATS_ACC"); return e && e[0] == '1'; }();
         if (acc_ok && g.N == 16 * NB && g.N <= PIPE_THREADS - PIPE_LT) acc = 1;
         else if (parts > (bwd.x ? BN_BWD_RECORDS_MAX : BN_RECORDS_MAX)) { stats = nullptr; mode = 0; }   // the caller runs the separate pass
         else if (stats_parts) *stats_parts = (int)parts;

@@ -34,6 +34,16 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Diagnostic build only (-DDAM_STRIP_DIAG_TAGS, libdam_hip_diag.so; tests/test_strip_diag_gpu.py): every geometry-table entry the
+// loader waves of the self-overlapped form write carries the index of the tile it describes, and every compute wave checks, for
+// every pixel block of every tile, that the entry it is about to turn into addresses carries the tile it is about to compute.
+// {checks made, mismatches seen}, read and reset by dam_strip_diag_counters().
+#ifdef DAM_STRIP_DIAG_TAGS
+}  // namespace
+__device__ unsigned strip_diag_counters[2];
+namespace {
+#endif
+
 // Diagnostic build only (-DDAM_STAMPS): the `stats` buffer receives s_memtime stamps of phase boundaries instead.
 #ifdef DAM_STAMPS
 #define DAM_STAMP(slot)                                                                                   \
@@ -381,7 +391,32 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     // write tile s+2 during slot s while the compute waves read tile s+1 -- and tile 0 BEFORE slot 0, beside the loaders' first
     // write (with two buffers that write landed in tile 0's entries: a late compute wave, e.g. on a cold instruction cache,
     // read tile 2's geometry for its first tile -- single pixel blocks wrong on first launches).
+    //
+    // WHY `tile & 3` CANNOT ALIAS (the slip bound).  Every wave of the workgroup executes the SAME sequence of workgroup barriers:
+    // the two __syncthreads() of the prologue (P1 behind the ring clear / weight copy, P2 behind the first tile's rows and the
+    // tables of tiles 0 and 1), then exactly ONE raw s_barrier per slot -- the loaders' paired loop runs n_slots of them, a
+    // compute wave n_tiles SO_SLOTs / SO_LAST plus the padding barriers up to n_slots.  A wave leaves barrier k only when all
+    // eight have arrived at it, so at any instant all waves are inside the same slot sigma (between slot barrier sigma - 1 and
+    // sigma, P2 counting as barrier -1) or have finished it and wait at its barrier: NO wave is ever a slot ahead of another.
+    // Every wave drains its LDS traffic (s_waitcnt lgkmcnt(0)) in front of each barrier, so a table read or write belongs
+    // entirely to the slot it was issued in.  Inside slot sigma:
+    //     the loader paired with compute wave cw WRITES the entry of tile sigma + 2           (SO_TABLE(s + 2) / SO_TABLE(s + 3)),
+    //     compute wave cw READS the entry of tile sigma + 1 (fillers: SO_TABREAD(sa_ + 1)) and, in slot 0 only, of tile 0
+    //     (the SO_TABREAD(0, mb) in front of the first SO_SLOT; tiles 0 and 1 were written before P2).
+    // Concurrent accesses therefore touch tiles {sigma + 2} and {sigma + 1} (+ {0} when sigma = 0): three distinct values mod 4
+    // in slot 0, two in every other slot -- never the same buffer.  With TWO buffers slot 0's write of tile 2 hit tile 0's entry
+    // while a compute wave that left P2 late (cold instruction cache on a first launch) had not read it yet: the failure of
+    // round 3 (gpurun_out/r3_t8.log); three buffers would do, four keep the index a mask.  The loaders' row REQUESTS for tiles
+    // 1 and 2 in the prologue are register loads from the read-only input: they write no LDS, so their being early changes when
+    // data travels, not what any wave reads -- the ring writes (commits) of tile sigma + 1 stay in slot sigma, where the host's
+    // ring sizing (StripGeo::NR: the rows of two consecutive tiles never alias) covers them exactly as in the ping-pong form.
+    // tests/test_strip_diag_gpu.py runs the layer1 / layer2 shapes of the C3 step through a build that checks this on the device.
     const int tab_base = CHB * g.nchunks + 9 * g.nchunks * NB * 1024;
+#ifdef DAM_STRIP_DIAG_TAGS
+#define SO_TAG(T_) ((((T_) + 1) & 0x7fff) << 16)       /* rides in the upper half of the lanes-on-this-row field (< 2^16) */
+#else
+#define SO_TAG(T_) 0
+#endif
 #define SO_TABLE(T_)                                                                                                      \
     do {                                                                                                                  \
         if (lane < 8 * MB) {                                                                                              \
@@ -393,7 +428,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             const int rr_ = oh_ * g.s + sg.ring_off + g.off_h + a_ * g.step_h + (k1_ ? g.s : 0);                          \
             const int kv_ = (rr_ & (sg.NR - 1)) * RB + (ow_ + g.off_w - g.c0 - (k1_ ? g.Wo : 0)) * 64;                    \
             const int so_ = oh_ * (g.os * g.OWt * g.N * 4) + ow_ * (g.os * g.N * 4);                                      \
-            const int val_ = f_ == 0 ? so_ : (f_ == 1 ? g.Wo - ow_ : kv_);                                                \
+            const int val_ = f_ == 0 ? so_ : (f_ == 1 ? ((g.Wo - ow_) | SO_TAG(T_)) : kv_);                               \
             *reinterpret_cast<int*>(smem + tab_base + ((((wave & 3) * 4 + ((T_) & 3)) * MB * 8 + lane) << 2)) = val_;     \
         }                                                                                                                 \
     } while (0)
@@ -804,15 +839,33 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             // broadcast reads, placed a few items ahead of their use), SO_GEOM turns them into per-lane offsets: one compare and
             // eight select / add instructions, no scalar arithmetic
             v4i tq[MB][2];
+#ifdef DAM_STRIP_DIAG_TAGS
+            int tq_want[MB];                // the tag the entry requested by SO_TABREAD must carry
+#define SO_TAG_EXPECT(T_, MBI_) tq_want[MBI_] = SO_TAG(T_)
+#define SO_TAG_CHECK(QA_, MBI_)                                                                                           \
+    do {                                                                                                                  \
+        if (lane == 0) {                                                                                                  \
+            atomicAdd(&strip_diag_counters[0], 1u);                                                                       \
+            if (((QA_).y & 0x7fff0000) != tq_want[MBI_]) atomicAdd(&strip_diag_counters[1], 1u);                          \
+        }                                                                                                                 \
+        (QA_).y &= 0xffff;                                                                                                \
+    } while (0)
+#else
+#define SO_TAG_EXPECT(T_, MBI_) do { } while (0)
+#define SO_TAG_CHECK(QA_, MBI_) do { } while (0)
+#endif
 #define SO_TABREAD(T_, MBI_)                                                                                              \
     do {                                                                                                                  \
         const int ta_ = tab_base + ((cw * 4 + ((T_) & 3)) * MB + (MBI_)) * 32;                                            \
         tq[MBI_][0] = *reinterpret_cast<const v4i*>(smem + ta_);                                                          \
         tq[MBI_][1] = *reinterpret_cast<const v4i*>(smem + ta_ + 16);                                                     \
+        SO_TAG_EXPECT(T_, MBI_);                                                                                          \
     } while (0)
 #define SO_GEOM(P_, MBI_)                                                                                                 \
     do {                                                                                                                  \
-        const v4i qa_ = tq[MBI_][0], qb_ = tq[MBI_][1];                                                                   \
+        v4i qa_ = tq[MBI_][0];                                                                                            \
+        const v4i qb_ = tq[MBI_][1];                                                                                      \
+        SO_TAG_CHECK(qa_, MBI_);                                                                                          \
         const bool nx_ = j >= qa_.y;                                                                                      \
         voffX[P_][MBI_] = (nx_ ? lane_oD : lane_o) + qa_.x;                                                               \
         baseX[P_][0][MBI_] = lane_x + (nx_ ? qb_.y : qa_.z);                                                              \
@@ -1016,6 +1069,8 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             }
 #undef SO_GEOM
 #undef SO_TABREAD
+#undef SO_TAG_EXPECT
+#undef SO_TAG_CHECK
 #undef SO_LOAD
 #undef SO_MFMA
 #undef SO_PREFETCH
@@ -1029,6 +1084,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     }
 
 #undef SO_TABLE
+#undef SO_TAG
 #undef DAM_STRIP_GEOM
 #ifdef DAM_STAMPS
     DAM_STAMP(8);
@@ -1289,3 +1345,23 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
 }
 
 }  // namespace dam
+
+// include/dam_hip.h: {checks, mismatches} of the geometry-table tags since the last reset -- diagnostic builds
+// (-DDAM_STRIP_DIAG_TAGS) only, DAM_ERR_UNSUPPORTED in the shipped library.  Synchronises the device.
+extern "C" int dam_strip_diag_counters(uint32_t* out2_host, int reset) {
+#ifdef DAM_STRIP_DIAG_TAGS
+    if (!out2_host) return DAM_ERR_BAD_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return DAM_ERR_LAUNCH;
+    unsigned v[2] = {0, 0};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(dam::strip_diag_counters), sizeof(v)) != hipSuccess) return DAM_ERR_LAUNCH;
+    out2_host[0] = v[0]; out2_host[1] = v[1];
+    if (reset) {
+        const unsigned z[2] = {0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dam::strip_diag_counters), z, sizeof(z)) != hipSuccess) return DAM_ERR_LAUNCH;
+    }
+    return DAM_OK;
+#else
+    (void)out2_host; (void)reset;
+    return DAM_ERR_UNSUPPORTED;
+#endif
+}

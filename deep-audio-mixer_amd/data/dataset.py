@@ -240,14 +240,21 @@ class MultitrackAudioDataset(data.Dataset):
             dev = [torch.empty((batch_size, K, n, ch), dtype=tdt, device=self._device) for _ in range(NS)]
             busy = _th.Lock()
             self._staging_cache = (key, host, dev, busy)
+        import threading
         busy.acquire()
         cached_files_begin()
         uploaded = [torch.cuda.Event() for _ in range(NS)]
-        consumed = [torch.cuda.Event() for _ in range(NS)]     # pcm=True: what the consumer enqueued on dev[slot] has run
+        # pcm=True: the consumer's step reads dev[slot] in place.  The HOST half of a slot is free as soon as its upload has left it
+        # (the feeder reads the next batch into it at once, as in feature mode); only the upload INTO dev[slot] waits -- on the
+        # device, not on the host -- for what the consumer enqueued on it: consumed[slot] is recorded when the consumer comes back
+        # for its next batch, and consumed_set[slot] tells the feeder that this recording has happened
+        consumed = [torch.cuda.Event() for _ in range(NS)]
+        consumed_set = [threading.Event() for _ in range(NS)]
+        for ev in consumed_set:
+            ev.set()
         copy_stream = torch.cuda.Stream(device=self._device)
 
         import queue
-        import threading
         ready, free, stop = queue.Queue(), threading.Semaphore(NS), threading.Event()
 
         def feeder(pool):
@@ -290,6 +297,11 @@ class MultitrackAudioDataset(data.Dataset):
                     # computed while the consumer's step on batch j runs -- nothing of it is left on the consumer's
                     # critical path (with a per-step loss.item() the device idles for every host call in between).
                     # capture_guard: never while the consumer captures its step into a hipGraph (ModelTrainer, third batch)
+                    if pcm:
+                        while not consumed_set[slot].wait(0.05):                    # (normally set long ago: three batches back)
+                            if stop.is_set():
+                                return
+                        consumed_set[slot].clear()
                     with staging.capture_guard, torch.cuda.device(self._device), torch.cuda.stream(copy_stream):
                         if pcm:                                                     # the consumer's step read dev[slot] in place
                             copy_stream.wait_event(consumed[slot])
@@ -337,11 +349,14 @@ class MultitrackAudioDataset(data.Dataset):
                         if pcm:
                             if payload.gain is not None:
                                 payload.gain.record_stream(cur)
-                            yield payload
-                            # back here the consumer has enqueued everything that reads this batch (ModelTrainer: the step's
-                            # graph replay): the slot's next upload waits for that work, not for the host
-                            consumed[slot].record(torch.cuda.current_stream(self._device))
-                            free.release()
+                            free.release()                  # the host half of the slot: its upload has been enqueued
+                            try:
+                                yield payload
+                            finally:
+                                # back here the consumer has enqueued everything that reads this batch (ModelTrainer: the
+                                # step's graph replay): the slot's next upload waits for that work on the device
+                                consumed[slot].record(torch.cuda.current_stream(self._device))
+                                consumed_set[slot].set()
                             continue
                         x, gt = payload
                         x.record_stream(cur)            # allocated on the copy stream, used on the consumer's

@@ -27,6 +27,7 @@ What is different underneath:
   * under ``torch.distributed`` only rank 0 prints and saves.
 """
 import os
+import time
 import warnings
 
 import torch
@@ -104,6 +105,9 @@ class ModelTrainer:
         self._step = self._shape = None
         self._seen = 0
         self.graph_steps = self.eager_steps = 0       # diagnostic: how the training batches were run
+        # diagnostic: where the HOST spent a training epoch's wall time (seconds, summed over fit()): waiting for the loader,
+        # enqueuing the batch's work, waiting for the previous batch's loss
+        self.host_times = {'loader': 0.0, 'enqueue': 0.0, 'loss_wait': 0.0}
 
     # ---- an adopted torch.optim.Adam stays usable by its owner
     def _push_adopted_state(self):
@@ -238,8 +242,20 @@ class ModelTrainer:
             total += value
 
         step = 0
-        for step, batch in enumerate(loader, start=1):
+        ht, clock = self.host_times, time.perf_counter
+        it = iter(loader)
+        while True:
+            t0 = clock()
+            try:
+                batch = next(it)
+            except StopIteration:
+                break
+            step += 1
+            t1 = clock()
             loss = self._train_batch(batch) if train else self._batch_loss(batch)
+            if train:
+                ht['loader'] += t1 - t0
+                ht['enqueue'] += clock() - t1
             if not on_gpu or not loss.is_cuda:
                 value = loss.item()
                 if train and step % _LOG_EVERY == 0 and not quiet:
@@ -251,7 +267,10 @@ class ModelTrainer:
             self._loss_ev[slot].record()
             pending.append((step, slot))
             if len(pending) > 1:
+                t2 = clock()
                 flush()
+                if train:
+                    ht['loss_wait'] += clock() - t2
         while pending:
             flush()
         return total / (n if n is not None else step)

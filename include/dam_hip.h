@@ -198,6 +198,12 @@ int dam_wgrad_queue_init(void* queue);
 int dam_wgrad_queue_pending(const void* queue);     /* recorded, not yet flushed; -1: not an initialised queue */
 int dam_wgrad_queue_flush(void* queue, void* stream);
 
+/* Diagnostic builds of the library only (libdam_hip_diag.so: dam_conv_strip.hip compiled with -DDAM_STRIP_DIAG_TAGS): the row-ring
+ * convolution's loader waves tag every geometry-table entry with the tile it describes and its compute waves check the tag of every
+ * entry they consume (the slip-bound argument in dam_conv_strip.hip, checked on the device).  out2_host receives {checks made,
+ * mismatches seen} since the last reset; synchronises the device.  The shipped library returns DAM_ERR_UNSUPPORTED. */
+int dam_strip_diag_counters(uint32_t* out2_host, int reset);
+
 /* ---------------------------------------------------------------------------------
  * BatchNorm2d on NHWC float32 [n_pixels][C], C % 16 == 0.  Replaces nn.BatchNorm2d + F.relu (+ the
  * residual add) of models/model_resnet.py:12-27,65,97 and models/model_scalar_1s.py:174-186,
