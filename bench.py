@@ -591,9 +591,11 @@ def run_via_trainer(name, cfg, args):
     n_songs, chunks = 8, 48                                      # 384 clips = 48 batches of 8 per epoch (1.8 GB of 16-bit PCM)
     songs, tracklist = _synthetic_songs(cfg, n_songs, chunks, pcm16=not args.float_pcm)
     ds = MultitrackAudioDataset.from_arrays(songs, chunk_length=cfg['seconds'], sr=cfg['sr'], tracklist=tracklist, seed=1)
-    # the loader hands ModelTrainer the uploaded PCM (PcmBatch): the captured step contains the front-end and reads it in
-    # place; --feature-loader: the round-3 arrangement (front-end per batch on the copy stream, features copied into the step)
-    pcm_fed = not args.feature_loader
+    # default: the loader runs the front-end per batch on the copy stream, beside the consumer's step, and the features are copied
+    # into the captured step (15 us).  --pcm-loader: the loader hands ModelTrainer the uploaded PCM (PcmBatch), the captured step
+    # contains the front-end and reads it in place -- measured 0.07-0.3 ms per step SLOWER (the 50 us front-end moves from beside
+    # the step into it; profiles/r04_via_trainer_ab.txt)
+    pcm_fed = args.pcm_loader
     train = ds.batch_loader(B, drop_last=True, workers=args.workers, pcm=pcm_fed)
     val = ds.batch_loader(B, indices=list(range(B)), workers=args.workers, pcm=pcm_fed)
     model = build_model(cfg, device)
@@ -813,7 +815,7 @@ def main():
                     help='diagnostic line: frames/s of WAV files -> decode threads -> pinned -> H2D -> STFT (iter_batches)')
     ap.add_argument('--workers', type=int, default=8, help='--ingest / --via-trainer: decode threads')
     ap.add_argument('--float-pcm', action='store_true', help='--via-trainer: float32 in-memory songs instead of 16-bit PCM')
-    ap.add_argument('--feature-loader', action='store_true', help='--via-trainer: loader yields features (round-3 arrangement)')
+    ap.add_argument('--pcm-loader', action='store_true', help='--via-trainer: loader yields uploaded PCM, front-end inside the captured step')
     ap.add_argument('--own-adam', action='store_true', help='--via-trainer: pass optim.Adam instead of torch.optim.Adam')
     args = ap.parse_args()
     if args.gpus < 1:

@@ -456,6 +456,84 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(const ConvGeo g, co
     }
 }
 
+// Two single-tap operators into the SAME output pixels in one launch: the data gradient of a down-sampling block's input gets, at its
+// (even, even) pixels, the centre tap of conv1's 3x3 / stride-2 transposed operator AND the whole 1x1 / stride-2 shortcut operator
+// (models/model_resnet.py:17-21,26: x feeds conv1 and the shortcut convolution) -- two direct launches of 7-16 us each, the second
+// re-reading what the first wrote, become one: y = Wp1[tap1]^T-chunks . x1 + Wp2[tap2]^T-chunks . x2.  Both inputs have the
+// geometry [B][H][W][C]; rounds of <= 8 chunks (all loads of a round in flight, then its MFMAs).
+template <int NB, int R, bool BOTH>      // R: chunk slots per operand and round; BOTH: nch <= R, the two operands' loads go out together
+__global__ __launch_bounds__(256) void conv1x1_pair_kernel(const float* __restrict__ X1, const float4* __restrict__ Wp1, int tap1,
+                                                           const float* __restrict__ X2, const float4* __restrict__ Wp2, int tap2,
+                                                           int B, int H, int W, int C, int N, float* __restrict__ Y, int OHt, int OWt,
+                                                           int os, int oo_h, int oo_w, int segs, int total_units) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int unit = blockIdx.x * 4 + wave;                  // (image, row, 16-pixel segment)
+    if (unit >= total_units) return;
+    const int nb0 = blockIdx.y * NB, nch = C / 16, NBtot = N / 16;
+    const int seg = unit % segs, row = unit / segs, img = row / H, oh = row - img * H;
+    const int ow = seg * 16 + j;
+    const bool valid = ow < W;
+    const int xoff = valid ? (((img * H + oh) * W + ow) * C + kq * 4) * 4 : 0x7fffffff;
+    v4f acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t xr1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp2), 0, 0x7fffffff, 0x00020000);
+#define DAM_PAIR_LOAD(XR_, WR_, TAP_, C0_, XV_, WA_)                                                                          \
+    _Pragma("unroll") for (int c = 0; c < R; ++c) {                                                                           \
+        const bool cok = (C0_) + c < nch;                                                                                     \
+        XV_[c] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(XR_, cok ? xoff : 0x7fffffff, ((C0_) + c) * 64, 0)); \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                     \
+            WA_[c][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(                                    \
+                WR_, cok ? lane * 16 : 0x7fffffff, ((((TAP_) * nch + (C0_) + c) * NBtot + nb0 + nb) * 64) * 16, 0));          \
+    }
+#define DAM_PAIR_MFMA(XV_, WA_)                       /* chunks past the end loaded zeros (out-of-range offsets) */             \
+    _Pragma("unroll") for (int c = 0; c < R; ++c)                                                                             \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                                   \
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(WA_[c][nb].x, XV_[c].x, acc[nb], 0, 0, 0);                         \
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(WA_[c][nb].y, XV_[c].y, acc[nb], 0, 0, 0);                         \
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(WA_[c][nb].z, XV_[c].z, acc[nb], 0, 0, 0);                         \
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(WA_[c][nb].w, XV_[c].w, acc[nb], 0, 0, 0);                         \
+        }
+    if constexpr (BOTH) {
+        float4 xa[R], wa[R][NB], xb[R], wb[R][NB];
+        DAM_PAIR_LOAD(xr1, wr1, tap1, 0, xa, wa)
+        DAM_PAIR_LOAD(xr2, wr2, tap2, 0, xb, wb)
+        DAM_PAIR_MFMA(xa, wa)
+        DAM_PAIR_MFMA(xb, wb)
+    } else {
+        // two register sets: the next round (of either operand) is requested before the current one's MFMAs
+        float4 xa[R], wa[R][NB], xb[R], wb[R][NB];
+        const int rounds = (nch + R - 1) / R, total = 2 * rounds;
+        DAM_PAIR_LOAD(xr1, wr1, tap1, 0, xa, wa)
+#pragma unroll 1
+        for (int r = 0; r < total; r += 2) {
+            {   // round r + 1 into set b
+                const int q = r + 1, c0 = (q >= rounds ? q - rounds : q) * R;
+                if (q >= rounds) { DAM_PAIR_LOAD(xr2, wr2, tap2, c0, xb, wb) } else { DAM_PAIR_LOAD(xr1, wr1, tap1, c0, xb, wb) }
+            }
+            DAM_PAIR_MFMA(xa, wa)
+            if (r + 2 < total) {
+                const int q = r + 2, c0 = (q >= rounds ? q - rounds : q) * R;
+                if (q >= rounds) { DAM_PAIR_LOAD(xr2, wr2, tap2, c0, xa, wa) } else { DAM_PAIR_LOAD(xr1, wr1, tap1, c0, xa, wa) }
+            }
+            DAM_PAIR_MFMA(xb, wb)
+        }
+    }
+#undef DAM_PAIR_LOAD
+#undef DAM_PAIR_MFMA
+    if (!valid) return;
+    const size_t opix = ((size_t)img * OHt + (oh * os + oo_h)) * OWt + (ow * os + oo_w);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int ch = (nb0 + nb) * 16 + kq * 4;
+        *reinterpret_cast<float4*>(Y + opix * N + ch) = make_float4(acc[nb].x, acc[nb].y, acc[nb].z, acc[nb].w);
+    }
+}
+
 template <int NB, int NCHMAX>
 int launch_conv1x1(const ConvGeo& g, const float* X, const float* Wp, const float* bias, float* Y, const float* res,
                    const float* res_mask, hipStream_t st) {
@@ -470,6 +548,35 @@ int launch_conv1x1(const ConvGeo& g, const float* X, const float* Wp, const floa
 
 }  // namespace
 }  // namespace dam
+
+extern "C" int dam_conv1x1_pair_f32(const float* x1, const float* w1_packed, int tap1, const float* x2, const float* w2_packed,
+                                    int tap2, int B, int H, int W, int C, int n_out, float* y, int OHt, int OWt, int out_stride,
+                                    int out_off_h, int out_off_w, void* stream) {
+    using namespace dam;
+    if (!x1 || !w1_packed || !x2 || !w2_packed || !y || B <= 0 || H <= 0 || W <= 0 || tap1 < 0 || tap2 < 0 || out_stride < 1)
+        return DAM_ERR_BAD_ARG;
+    if (C % 16 || n_out % 16 || C <= 0 || n_out <= 0) return DAM_ERR_UNSUPPORTED;
+    if ((H - 1) * out_stride + out_off_h >= OHt || (W - 1) * out_stride + out_off_w >= OWt || out_off_h < 0 || out_off_w < 0)
+        return DAM_ERR_BAD_ARG;
+    if ((int64_t)B * H * W * C * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;
+    const int segs = (int)cdiv(W, 16);
+    const int64_t units = (int64_t)B * H * segs;
+    if (units >= (1ll << 30)) return DAM_ERR_UNSUPPORTED;
+    const int nblk = n_out / 16, nch = C / 16;
+    hipStream_t st = (hipStream_t)stream;
+#define DAM_PAIR_GO(NB_, R_, BOTH_)                                                                                           \
+    hipLaunchKernelGGL((conv1x1_pair_kernel<NB_, R_, BOTH_>), dim3((unsigned)cdiv(units, 4), (unsigned)(nblk / NB_)), dim3(256), 0, st, x1, \
+                       reinterpret_cast<const float4*>(w1_packed), tap1, x2, reinterpret_cast<const float4*>(w2_packed), tap2, B, H, W, \
+                       C, n_out, y, OHt, OWt, out_stride, out_off_h, out_off_w, segs, (int)units)
+    if (nblk % 2 == 0) {
+        if (nch <= 2) DAM_PAIR_GO(2, 2, true); else if (nch <= 4) DAM_PAIR_GO(2, 4, true); else DAM_PAIR_GO(2, 4, false);
+    } else {
+        if (nch <= 2) DAM_PAIR_GO(1, 2, true); else if (nch <= 4) DAM_PAIR_GO(1, 4, true); else DAM_PAIR_GO(1, 8, false);
+    }
+#undef DAM_PAIR_GO
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
 
 // Generic tap-grid convolution (see dam_hip.h).  The host wrapper derives the patch geometry and picks the tile.
 extern "C" int64_t dam_conv_batch_bytes(void) { return (int64_t)sizeof(dam::ConvBatch); }

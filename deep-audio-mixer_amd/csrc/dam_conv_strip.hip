@@ -250,10 +250,42 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     int ccA[KP], ccB[KP];                            // outside the tensor (zeros are written), -1 = nothing to write; chunk
 #pragma unroll
     for (int k = 0; k < KP; ++k) { dstA[k] = -1; dstB[k] = -1; ccA[k] = 0; ccB[k] = 0; }
+    // TIMING EXPERIMENT ONLY (-DDAM_DIAG_DXHAT=1|2, tools/dxhat_ladder.py; results are wrong): what it would cost this kernel to form
+    // its INPUT operand dc = a * (dy . mask) + b * c + k (BatchNorm backward: the bn_bwd_apply launch folded into the loaders)
+    // itself -- every plane is accompanied by a second plane from another tensor (read through the `bias` pointer: real HBM
+    // traffic); 1 = the loads and one fma per quad, 2 = the full arithmetic with the mask recomputed from the second stream.
+#ifdef DAM_DIAG_DXHAT
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(bias) + (size_t)img * g.H * g.W * g.C, 0, g.H * g.W * g.C * 4, 0x00020000);
+    v4f lvcA[KP][GPP], lvcB[KP][GPP];
+#define DAM_SDX_ON 1
+#define DAM_SDX_REQ(LVC_, K_, SOFF_)                                                                                       \
+    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                                     \
+        LVC_[K_][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(crsrc, loffb[gi], SOFF_, 0))
+#if DAM_DIAG_DXHAT == 1
+#define DAM_SDX_COMBINE(LV_, LVC_, K_, GI_) __builtin_elementwise_fma(LVC_[K_][GI_], shq[0], LV_[K_][GI_])
+#else
+#define DAM_SDX_COMBINE(LV_, LVC_, K_, GI_)                                                                                \
+    ([&]() {                                                                                                               \
+        const v4f c_ = LVC_[K_][GI_], dy_ = LV_[K_][GI_];                                                                  \
+        const v4f m_ = __builtin_elementwise_fma(c_, scq[0], shq[0]);                                                      \
+        v4f dz_;                                                                                                           \
+        dz_.x = m_.x > 0.f ? dy_.x : 0.f; dz_.y = m_.y > 0.f ? dy_.y : 0.f;                                                \
+        dz_.z = m_.z > 0.f ? dy_.z : 0.f; dz_.w = m_.w > 0.f ? dy_.w : 0.f;                                                \
+        return __builtin_elementwise_fma(dz_, scq[0], __builtin_elementwise_fma(c_, shq[0], relu_lo4));                    \
+    }())
+#endif
+#else
+#define DAM_SDX_ON 0
+#define DAM_SDX_REQ(LVC_, K_, SOFF_) do { } while (0)
+#define DAM_SDX_COMBINE(LV_, LVC_, K_, GI_) (LV_[K_][GI_])
+#define lvcA lvA
+#define lvcB lvB
+#endif
     const int chs = NCH == 1 ? 0 : 1;
     int loaded_hi;
     { int lo; tile_rows(t_begin, lo, loaded_hi); }
-#define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_)                                                                                \
+#define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_, LVC_)                                                                          \
     do {                                                                                                                   \
         int first_ = 0, planes_ = 0;                                                                                       \
         if ((K_) < n_tiles) {                                                                                              \
@@ -270,6 +302,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             const int soff_ = ((rowok_ ? ih_ : 0) * g.W * g.C + (used_ ? cc_ : 0) * 16) * 4;                               \
             _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                             \
                 LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[gi], soff_, 0));   \
+            DAM_SDX_REQ(LVC_, k, soff_);                                                                                   \
             DST_[k] = used_ ? ((cc_ * CHB + ((ih_ + sg.ring_off) & (sg.NR - 1)) * RB) | (rowok_ ? 0 : 1 << 30)) : -1;     \
             CC_[k] = cc_;                                                                                                  \
         }                                                                                                                  \
@@ -277,8 +310,8 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
 #define DAM_STRIP_WRITE(ADDR_, DATA_, GI_)                                                                                 \
     asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
                  : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024 * HS) : "memory")
-#define DAM_STRIP_COMMIT(LV_, DST_, CC_) DAM_STRIP_COMMIT_N(KP, LV_, DST_, CC_)
-#define DAM_STRIP_COMMIT_N(KPX_, LV_, DST_, CC_)                                                                           \
+#define DAM_STRIP_COMMIT(LV_, DST_, CC_, LVC_) DAM_STRIP_COMMIT_N(KP, LV_, DST_, CC_, LVC_)
+#define DAM_STRIP_COMMIT_N(KPX_, LV_, DST_, CC_, LVC_)                                                                        \
     do {                                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < (KPX_); ++k) {                                                                   \
             if (DST_[k] >= 0) {                                                                                            \
@@ -292,6 +325,11 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
                             v_ = __builtin_elementwise_max(v_, relu_lo4);   /* max(., -inf) when there is no ReLU: no selects */ \
                             DAM_STRIP_WRITE(va_, v_, gi);                                                                  \
                         }                                                                                                  \
+                    } else if (DAM_SDX_ON) {                                                                               \
+                        _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) {                                               \
+                            const v4f v_ = DAM_SDX_COMBINE(LV_, LVC_, k, gi);                                              \
+                            DAM_STRIP_WRITE(va_, v_, gi);                                                                  \
+                        }                                                                                                  \
                     } else {                                                                                               \
                         _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_STRIP_WRITE(va_, LV_[k][gi], gi);           \
                     }                                                                                                      \
@@ -303,11 +341,11 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     } while (0)
 #ifdef DAM_DIAG_NO_LOAD        // timing experiments only (results are wrong)
 #undef DAM_STRIP_REQUEST
-#define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_) do { } while (0)
+#define DAM_STRIP_REQUEST(K_, LV_, DST_, CC_, LVC_) do { } while (0)
 #endif
     // SO prologue: the rows of the workgroup's FIRST tile as whole planes too, spread over all NT / 64 waves (plane = wave + k * NT/64)
     constexpr int KP0 = (NCH == 1 ? 1 : 2) * HS;
-#define DAM_STRIP_REQUEST0(LV_, DST_, CC_)                                                                                 \
+#define DAM_STRIP_REQUEST0(LV_, DST_, CC_, LVC_)                                                                             \
     do {                                                                                                                   \
         const int planes_ = (hi0 - lo0 + 1) << chs;                                                                        \
         _Pragma("unroll") for (int k = 0; k < KP0; ++k) {                                                                  \
@@ -318,6 +356,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             const int soff_ = ((rowok_ ? ih_ : 0) * g.W * g.C + (used_ ? cc_ : 0) * 16) * 4;                               \
             _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                             \
                 LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, loffb[gi], soff_, 0));   \
+            DAM_SDX_REQ(LVC_, k, soff_);                                                                                   \
             DST_[k] = used_ ? ((cc_ * CHB + ((ih_ + sg.ring_off) & (sg.NR - 1)) * RB) | (rowok_ ? 0 : 1 << 30)) : -1;     \
             CC_[k] = cc_;                                                                                                  \
         }                                                                                                                  \
@@ -347,15 +386,20 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     }
     DAM_STAMP(9);
     v4f lv0[SO ? KP0 : 1][SO ? GPP : 1];
+#ifdef DAM_DIAG_DXHAT
+    v4f lvc0[SO ? KP0 : 1][SO ? GPP : 1];
+#else
+#define lvc0 lv0
+#endif
     int dst0[KP0], cc0[KP0];
     if constexpr (SO != 0) {
         // rows of the first tile: whole planes over all waves (the per-piece path of the ping-pong form costs 3.4-5 k cycles
         // of address arithmetic per wave); the loader waves' requests for tiles 1 and 2 follow at once, so that tile 1's rows
         // are there long before slot 0 ends (requested after the prologue, the first barrier waited 1.3-3.4 k cycles for them)
-        DAM_STRIP_REQUEST0(lv0, dst0, cc0);
+        DAM_STRIP_REQUEST0(lv0, dst0, cc0, lvc0);
         if (grp == LGRP) {
-            DAM_STRIP_REQUEST(1, lvB, dstB, ccB);
-            DAM_STRIP_REQUEST(2, lvA, dstA, ccA);
+            DAM_STRIP_REQUEST(1, lvB, dstB, ccB, lvcB);
+            DAM_STRIP_REQUEST(2, lvA, dstA, ccA, lvcA);
         }
     } else {
         rows_issue(rl, lo0, hi0, 0, wave, NT / 64, lane, lv, ldst, laff);
@@ -374,7 +418,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
     __syncthreads();
     DAM_STAMP(2);
     if constexpr (SO != 0) {
-        DAM_STRIP_COMMIT_N(KP0, lv0, dst0, cc0);
+        DAM_STRIP_COMMIT_N(KP0, lv0, dst0, cc0, lvc0);
     } else {
         rows_commit<NCH>(smem, lv, ldst, laff, has_aff, scq, shq, relu_in);
         for (int base = (NT / 64) * STRIP_PU; base < total0; base += (NT / 64) * STRIP_PU) {
@@ -451,19 +495,19 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
         // a piece costs no VALU instruction at all: buffer_load with scalar base + per-lane offset, ds_write with the
         // piece's column mask in EXEC and an immediate offset.
         if constexpr (SO == 0) {
-            DAM_STRIP_REQUEST(1, lvB, dstB, ccB);
-            DAM_STRIP_REQUEST(2, lvA, dstA, ccA);
+            DAM_STRIP_REQUEST(1, lvB, dstB, ccB, lvcB);
+            DAM_STRIP_REQUEST(2, lvA, dstA, ccA, lvcA);
         }
         // slots come in pairs (n_slots is even) so that no load sits inside a conditional: the compiler then knows that the
         // set being written is the older of the two in flight and waits with vmcnt(pieces of the other set), not vmcnt(0)
         for (int s = 0; s < n_slots; s += 2) {
-            DAM_STRIP_COMMIT(lvB, dstB, ccB);       // tile s+1
-            DAM_STRIP_REQUEST(s + 3, lvB, dstB, ccB);
+            DAM_STRIP_COMMIT(lvB, dstB, ccB, lvcB);       // tile s+1
+            DAM_STRIP_REQUEST(s + 3, lvB, dstB, ccB, lvcB);
             if constexpr (SO != 0) SO_TABLE(s + 2);  // read by the compute waves in slot s+1
             DAM_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            DAM_STRIP_COMMIT(lvA, dstA, ccA);       // tile s+2
-            DAM_STRIP_REQUEST(s + 4, lvA, dstA, ccA);
+            DAM_STRIP_COMMIT(lvA, dstA, ccA, lvcA);       // tile s+2
+            DAM_STRIP_REQUEST(s + 4, lvA, dstA, ccA, lvcA);
             if constexpr (SO != 0) SO_TABLE(s + 3);
             DAM_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -473,6 +517,14 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
 #undef DAM_STRIP_WRITE
 #undef DAM_STRIP_COMMIT
 #undef DAM_STRIP_COMMIT_N
+#undef DAM_SDX_ON
+#undef DAM_SDX_REQ
+#undef DAM_SDX_COMBINE
+#ifndef DAM_DIAG_DXHAT
+#undef lvcA
+#undef lvcB
+#undef lvc0
+#endif
     }
 
     // BatchNorm partial statistics of this wave's outputs: shifted sums per lane (channels 4*kq..+3 of block nb), kept as

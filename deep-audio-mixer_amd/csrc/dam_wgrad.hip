@@ -429,9 +429,40 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
         int dst[KP];               // scalar: LDS byte offset of the plane | 1 << 30 (row outside the image: zeros), -1 = none
         int aff[KP], aff2[KP];     // scalar: chunk index kb of an X plane that gets the input affine, -1 otherwise
         const int rowstride = g.W * g.C * 4;
+        // TIMING EXPERIMENT ONLY (-DDAM_DIAG_DXHAT=1|2, tools/dxhat_ladder.py; results are wrong): what it would cost this kernel to
+        // form its dY operand dc = a * (dy . mask) + b * c + k (BatchNorm backward, the bn_bwd_apply launch folded into the
+        // loaders) itself: every dY plane is accompanied by a second plane from a THIRD tensor (read through the slab workspace
+        // pointer at +128 MB: real HBM traffic, no aliasing with X or dY); 1 = the loads and one fma, 2 = the full arithmetic
+        // with the mask recomputed from the second stream.
+#ifdef DAM_DIAG_DXHAT
+        const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(partial) + (size_t)(32u << 20) + (size_t)img * g.H * g.W * g.C, 0, img_bytes, 0x00020000);
+        v4f lvc_a[KP][GPP], lvc_b[KP][GPP], lvc_c[(2 * TKB + NL - 1) / NL][GPP];
+#define DAM_DXHAT_ON 1
+#define DAM_DXHAT_REQ(LVC_, K_, SOFF_)                                                                                      \
+    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                                     \
+        LVC_[K_][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(crsrc, loffb[gi], SOFF_, 0))
+#if DAM_DIAG_DXHAT == 1
+#define DAM_DXHAT_COMBINE(LV_, LVC_, K_, GI_) __builtin_elementwise_fma(LVC_[K_][GI_], shq[0], LV_[K_][GI_])
+#else
+#define DAM_DXHAT_COMBINE(LV_, LVC_, K_, GI_)                                                                              \
+    ([&]() {                                                                                                               \
+        const v4f c_ = LVC_[K_][GI_], dy_ = LV_[K_][GI_];                                                    \
+        const v4f m_ = __builtin_elementwise_fma(c_, scq[0], shq[0]);                                                      \
+        v4f dz_;                                                                                                           \
+        dz_.x = m_.x > 0.f ? dy_.x : 0.f; dz_.y = m_.y > 0.f ? dy_.y : 0.f;                                                \
+        dz_.z = m_.z > 0.f ? dy_.z : 0.f; dz_.w = m_.w > 0.f ? dy_.w : 0.f;                                                \
+        return __builtin_elementwise_fma(dz_, scq[0], __builtin_elementwise_fma(c_, shq[0], relu_lo4));                    \
+    }())
+#endif
+#else
+#define DAM_DXHAT_ON 0
+#define DAM_DXHAT_REQ(LVC_, K_, SOFF_) do { } while (0)
+#define DAM_DXHAT_COMBINE(LV_, LVC_, K_, GI_) (LV_[K_][GI_])
+#endif
         // X rows xr0 .. xr0+nx-1 (in-channel chunks of this tile) then dY rows dr0 .. dr0+nd-1 (out-channel blocks), one
         // plane = one (row, 16 channels); loader wave cwl takes planes cwl, cwl+4, ...  Loads are unconditional (clamped).
-#define DAM_RW_REQUEST(XR0_, NX_, DR0_, ND_, LV_, DST_, KP_, AFF_)                                                                               \
+#define DAM_RW_REQUEST(XR0_, NX_, DR0_, ND_, LV_, DST_, KP_, AFF_, LVC_)                                                                               \
     do {                                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < KP_; ++k) {                                                                  \
             const int pl_ = cwl + NL * k;                                                                          \
@@ -454,15 +485,16 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
             } else {                                                                                                       \
                 _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi)                                                         \
                     LV_[k][gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(drsrc, loffb[gi], soff_, 0)); \
+                DAM_DXHAT_REQ(LVC_, k, soff_);                                                                             \
             }                                                                                                              \
             DST_[k] = need_ ? (ldsoff_ | (inimg_ ? 0 : 1 << 30)) : -1;                                                     \
-            AFF_[k] = (isx_ && has_aff) ? c_ : -1;                                                                         \
+            AFF_[k] = (isx_ && has_aff) ? c_ : (isx_ ? -1 : -2);                                                           \
         }                                                                                                                  \
     } while (0)
 #define DAM_RW_WRITE(ADDR_, DATA_, GI_)                                                                                    \
     asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"                              \
                  : : "v"(ADDR_), "v"(DATA_), "s"(cmask[GI_]), "n"((GI_) * 1024) : "memory")
-#define DAM_RW_COMMIT(LV_, DST_, KP_, AFF_)                                                                                \
+#define DAM_RW_COMMIT(LV_, DST_, KP_, AFF_, LVC_)                                                                              \
     do {                                                                                                                   \
         _Pragma("unroll") for (int k = 0; k < KP_; ++k) {                                                                  \
             if (DST_[k] >= 0) {                                                                                            \
@@ -477,6 +509,11 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
                         v_ = __builtin_elementwise_max(v_, relu_lo4);       /* -inf without ReLU: no selects */             \
                         DAM_RW_WRITE(va_, v_, gi);                                                                         \
                     }                                                                                                      \
+                } else if (DAM_DXHAT_ON && AFF_[k] == -2) {                                                                \
+                    _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) {                                                   \
+                        v4f v_ = DAM_DXHAT_COMBINE(LV_, LVC_, k, gi);                                                          \
+                        DAM_RW_WRITE(va_, v_, gi);                                                                         \
+                    }                                                                                                      \
                 } else {                                                                                                   \
                     _Pragma("unroll") for (int gi = 0; gi < GPP; ++gi) DAM_RW_WRITE(va_, LV_[k][gi], gi);                  \
                 }                                                                                                          \
@@ -488,13 +525,13 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
         v4f lvb[KPB][GPP], lv2[KP][GPP];
         int dstb[KPB], dst2[KP], affb[KPB];
         DAM_WSTAMP(9);                                                         // setup done
-        DAM_RW_REQUEST(r_begin - 1, RPS, r_begin, RPS, lv, dst, KP, aff);
-        DAM_RW_REQUEST(r_begin + RPS - 1, 2, r_begin, 0, lvb, dstb, KPB, affb);
+        DAM_RW_REQUEST(r_begin - 1, RPS, r_begin, RPS, lv, dst, KP, aff, lvc_a);
+        DAM_RW_REQUEST(r_begin + RPS - 1, 2, r_begin, 0, lvb, dstb, KPB, affb, lvc_c);
         DAM_WSTAMP(10);                                                        // first rows requested
         DAM_RW_ZERO();
         DAM_WSTAMP(11);                                                        // padding cells cleared
-        DAM_RW_COMMIT(lv, dst, KP, aff);
-        DAM_RW_COMMIT(lvb, dstb, KPB, affb);
+        DAM_RW_COMMIT(lv, dst, KP, aff, lvc_a);
+        DAM_RW_COMMIT(lvb, dstb, KPB, affb, lvc_c);
         DAM_WSTAMP(12);                                                        // first rows written (their loads have landed)
         // the compute waves start slot 0 HERE; the requests for slots 1 and 2 follow (in front of this barrier they held the
         // first MFMA back by 5-8 k clocks: with three slots of rows wanted by 256 CUs at once the request queue backs up)
@@ -503,18 +540,18 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
         // adds (X rows r_begin+RPS(s+1)+1 .. +RPS, dY rows r_begin+RPS(s+1) .. +RPS-1; requested during slot s-1) and
         // requests those of slot s+3.  Two register sets alternate; slots come in pairs so that no load sits inside a
         // conditional.
-#define DAM_RW_SLOT(T_, LV_, DST_, AFF_) DAM_RW_REQUEST(r_begin + RPS * (T_) + 1, RPS, r_begin + RPS * (T_), RPS, LV_, DST_, KP, AFF_)
+#define DAM_RW_SLOT(T_, LV_, DST_, AFF_, LVC_) DAM_RW_REQUEST(r_begin + RPS * (T_) + 1, RPS, r_begin + RPS * (T_), RPS, LV_, DST_, KP, AFF_, LVC_)
         DAM_WSTAMP(2);
-        DAM_RW_SLOT(1, lv, dst, aff);
-        DAM_RW_SLOT(2, lv2, dst2, aff2);
+        DAM_RW_SLOT(1, lv, dst, aff, lvc_a);
+        DAM_RW_SLOT(2, lv2, dst2, aff2, lvc_b);
         for (int s = 0; s < n_slots2; s += 2) {
-            DAM_RW_COMMIT(lv, dst, KP, aff);
-            DAM_RW_SLOT(s + 3, lv, dst, aff);
+            DAM_RW_COMMIT(lv, dst, KP, aff, lvc_a);
+            DAM_RW_SLOT(s + 3, lv, dst, aff, lvc_a);
             DAM_WSTAMP(5);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             DAM_WSTAMP(7);
-            DAM_RW_COMMIT(lv2, dst2, KP, aff2);
-            DAM_RW_SLOT(s + 4, lv2, dst2, aff2);
+            DAM_RW_COMMIT(lv2, dst2, KP, aff2, lvc_b);
+            DAM_RW_SLOT(s + 4, lv2, dst2, aff2, lvc_b);
             DAM_WSTAMP(5);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             DAM_WSTAMP(7);
@@ -523,6 +560,14 @@ __global__ __launch_bounds__(256 + 64 * NL) void wgrad_rows_kernel(const RowsGeo
 #undef DAM_RW_REQUEST
 #undef DAM_RW_WRITE
 #undef DAM_RW_COMMIT
+#undef DAM_DXHAT_ON
+#undef DAM_DXHAT_REQ
+#undef DAM_DXHAT_COMBINE
+#ifndef DAM_DIAG_DXHAT
+#undef lvc_a
+#undef lvc_b
+#undef lvc_c
+#endif
     } else {
         // ================================ compute waves ================================
         const int cw = wave;

@@ -375,8 +375,12 @@ class BasicBlockFn(torch.autograd.Function):
         first = (keep(dw1, s_w1), keep(dg1, s_g1), keep(db1, s_b1), keep(dw2, s_w2), keep(dg2, s_g2), keep(db2, s_b2))
         if ctx.has_sc:
             dws = blk.spec_sc.wgrad(x, dcs, out=wview(s_ws, wsc))
-            dx = blk.spec1.dgrad(dc1, w1, hw)
-            blk.spec_sc.dgrad(dcs, wsc, hw, accumulate_into=dx)
+            if ops.PAIR_1X1 and blk.spec1.k == 3 and blk.spec1.stride == 2 and blk.spec_sc.stride == 2:
+                # the shortcut's whole data gradient and the centre tap of conv1's land on the same (even, even) pixels: one launch
+                dx = blk.spec1.dgrad(dc1, w1, hw, pair_1x1=(dcs, blk.spec_sc.packed(wsc, transpose=True)))
+            else:
+                dx = blk.spec1.dgrad(dc1, w1, hw)
+                blk.spec_sc.dgrad(dcs, wsc, hw, accumulate_into=dx)
             return (dx,) + first + (keep(dws, s_ws), keep(dgs, s_gs), keep(dbs, s_bs), None, None)
         up = ctx.upstream
         if up is not None and ops.DGRAD_BN_SUMS and up.c.shape == x.shape:

@@ -56,6 +56,10 @@ INKERNEL_FINALIZE = False
 FUSED_FINALIZE = os.environ.get('DAM_BN_FUSED_FIN', '1') != '0'
 
 
+# shortcut data gradient riding in conv1's single-tap class launch (dam_conv1x1_pair_f32); DAM_NO_PAIR_1X1=1: two launches (A/B)
+PAIR_1X1 = not os.environ.get('DAM_NO_PAIR_1X1')
+
+
 # BatchNorm-backward sums from the data-gradient epilogue (include/dam_hip.h: dam_bn_bwd_sums); DAM_NO_DGRAD_SUMS=1 keeps the
 # separate pass over dy and x (A/B switch)
 DGRAD_BN_SUMS = not os.environ.get('DAM_NO_DGRAD_SUMS')
@@ -150,7 +154,7 @@ def _dgrad_axis(parity, pad, dil, k, stride):
 
 
 def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, res_mask=None, accumulate_into=None,
-                 bn_bwd=None, res_mask_bits=None):
+                 bn_bwd=None, res_mask_bits=None, _diag_bias=None, pair_1x1=None):
     """dy: NHWC [B,Ho,Wo,Cout]; wpt packed with transpose=True.  Returns dx NHWC [B,H,W,n_in16]
     (+ res * (res_mask > 0) if given).  With accumulate_into=dx0 the result is added to dx0 in place.
     bn_bwd=(x, save_mean, save_invstd, mask_scale, mask_shift[, mask_bits]): dx is the gradient reaching relu(bn(x)) (or, with
@@ -178,7 +182,8 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
         rec = torch.empty(_lib.lib().dam_bn_workspace_floats(n16), dtype=torch.float32, device=dy.device)
         epi = _lib.BnBwdSums(_lib.ptr(xb), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(msc), _lib.ptr(msh), _lib.ptr(res_mask_bits),
                              _lib.ptr(up_bits))
-        parts = _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, H, W, 1, 0, 0, 1,
+        # (_diag_bias: timing builds only -- tools/dxhat_ladder.py hands the kernel a second input stream through the bias pointer)
+        parts = _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, _diag_bias, None, None, False, dx, H, W, H, W, 1, 0, 0, 1,
                          kh, kw, pad, -dil, pad, -dil, 0, kw, 1, res, res_mask, bn_partial=rec, bn_bwd=epi)
         return dx, ((rec, parts) if parts > 0 else None)
     _f32c(dy, 'dy'), _f32c(res, 'res'), _f32c(res_mask, 'res_mask')
@@ -192,6 +197,18 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
         _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, H, W, 1, 0, 0, 1,
                  kh, kw, pad, -dil, pad, -dil, 0, kw, 1, res, res_mask)
         return dx
+    # pair_1x1=(dy2, wpt2): a SECOND operator's data gradient into the same dx -- a 1x1 / stride-`stride` / pad-0 convolution of the
+    # same input (a down-sampling block's shortcut beside its conv1): its one tap lands on the pixels of this operator's single-tap
+    # parity class (0, 0) and rides in that class's launch (dam_conv1x1_pair_f32) instead of a launch of its own that re-reads dx
+    if pair_1x1 is not None:
+        dy2, wpt2 = pair_1x1
+        _lib.require_cuda(dy2, wpt2)
+        _f32c(dy2, 'pair dy')
+        if accumulate_into is not None or res is not None or tuple(dy2.shape) != tuple(dy.shape):
+            raise ValueError('pair_1x1: a second gradient of the same shape, no residual / accumulation')
+        a0 = _dgrad_axis(0, pad, dil, kh, stride), _dgrad_axis(0, pad, dil, kw, stride)
+        if a0[0] is None or a0[1] is None or a0[0][0] != 1 or a0[1][0] != 1 or a0[0][3] != 0 or a0[1][3] != 0:
+            raise ValueError('pair_1x1: class (0, 0) of this operator is not a single tap at offset 0')
     classes = [(_dgrad_axis(ph, pad, dil, kh, stride), _dgrad_axis(pw, pad, dil, kw, stride))
                for ph in range(stride) for pw in range(stride)]
     if any(a is None or b is None for a, b in classes) and accumulate_into is None:
@@ -207,6 +224,13 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
                 ah, aw = _dgrad_axis(ph, pad, dil, kh, stride), _dgrad_axis(pw, pad, dil, kw, stride)
                 nh, nw = (H - ph + stride - 1) // stride, (W - pw + stride - 1) // stride
                 if nh <= 0 or nw <= 0 or ah is None or aw is None:
+                    continue
+                if pair_1x1 is not None and ph == 0 and pw == 0:
+                    if nh != Ho or nw != Wo:
+                        raise ValueError('pair_1x1: class (0, 0) does not cover the gradient\'s pixels')
+                    _lib.check(_lib.lib().dam_conv1x1_pair_f32(_lib.ptr(dy), _lib.ptr(wpt), ah[1] * kw + aw[1], _lib.ptr(pair_1x1[0]),
+                                                               _lib.ptr(pair_1x1[1]), 0, B, Ho, Wo, Co, n16, _lib.ptr(dx), H, W, stride,
+                                                               0, 0, _lib.stream()), 'dam_conv1x1_pair_f32')
                     continue
                 _tapgrid(dy, B, Ho, Wo, Co, False, wpt, Co // 16, n16, None, None, None, False, dx, H, W, nh, nw,
                          stride, ph, pw, 1, ah[0], aw[0], ah[3], ah[4], aw[3], aw[4], ah[1] * kw + aw[1],

@@ -50,7 +50,7 @@ struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 /* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
  * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
  * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
-#define DAM_ABI_VERSION 8
+#define DAM_ABI_VERSION 9
 const char* dam_arch(void);
 int dam_abi_version(void);
 
@@ -157,6 +157,16 @@ int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nc
                            const float* res, const float* res_mask, float* bn_partial, int* bn_parts_host,
                            const struct dam_bn_fin* bn_fin, const struct dam_bn_bwd_sums* bn_bwd, float* workspace,
                            int64_t workspace_floats, void* batch, void* stream);
+
+/* Two single-tap operators into the same output pixels in ONE launch:
+ *   y[b, oh*out_stride+out_off_h, ow*out_stride+out_off_w, :] = W1p[tap1] . x1[b, oh, ow, :] + W2p[tap2] . x2[b, oh, ow, :]
+ * x1, x2: NHWC [B][H][W][C]; W1p / W2p: packed images (dam_conv_pack_weights_f32) with k_in = C and n_out outputs, of which tap
+ * tap1 / tap2 is used.  The data gradient of a down-sampling block's input (models/model_resnet.py:17-21,26: x feeds the 3x3 /
+ * stride-2 conv1 AND the 1x1 / stride-2 shortcut convolution) receives, at its (even, even) pixels, exactly these two terms: the
+ * centre tap of conv1's transposed operator applied to d conv1 and the shortcut's transposed operator applied to d shortcut. */
+int dam_conv1x1_pair_f32(const float* x1, const float* w1_packed, int tap1, const float* x2, const float* w2_packed, int tap2,
+                         int B, int H, int W, int C, int n_out, float* y, int OHt, int OWt, int out_stride, int out_off_h,
+                         int out_off_w, void* stream);
 
 /* Sibling launches in one.  The parity classes of a strided data gradient are up to four small launches over the same
  * tensors, weights and tile that differ only in their tap grid.  With a batch (caller-owned HOST memory of
