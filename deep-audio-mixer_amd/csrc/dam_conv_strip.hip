@@ -872,6 +872,11 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
 #else
             constexpr bool SO_NOSTU = false;
 #endif
+#ifdef DAM_SO_LATE_PREFETCH        // A/B build: the write-out operands of a tile requested in one filler at the end of its slot
+            constexpr bool SO_LATE_PF = true;
+#else
+            constexpr bool SO_LATE_PF = false;
+#endif
 #ifdef DAM_DIAG_SO_NOFILL          // timing experiments only: the bare MFMA + operand-read stream (results are wrong)
             constexpr bool SO_NOFILL = true;
 #else
@@ -945,25 +950,32 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
                         ((I_) == 0 && r == 0) ? (v4f){0.f, 0.f, 0.f, 0.f} : accX[P_][mb][nb], 0, 0, 0);                   \
     } while (0)
 #endif
-            // operands of the write-out of tile T_ (residual / mask / the BatchNorm's x), requested a slot ahead
-#define SO_PREFETCH(P_)                                                                                                   \
+            // operands of the write-out of tile T_ (residual / mask / the BatchNorm's x), requested a slot ahead -- PER PIXEL BLOCK, in the
+            // filler that has just written that block of the previous tile out (its operand registers are free from there on).
+            // Round 3 requested all of a tile's blocks in ONE filler at item 2 * MB, the slot's last, and consumed them from item 0
+            // of the next slot on: ~1 k cycles of lead for loads that take 4-5 k under this load.  PMC (profiles/r04_pmc_strip_epi.txt):
+            // SQ_WAIT_ANY 12.4 M wave-cycles per forward launch, 26.4 M with the sums epilogue, 36.3 M with residual + upstream sums --
+            // the compute waves stood in front of their write-out units.  DAM_SO_LATE_PREFETCH keeps the old placement (A/B build).
+#define SO_PREFETCH1(P_, MBI_)                                                                                            \
     do {                                                                                                                  \
         if constexpr (NEED_R) {                                                                                           \
-            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                           \
-                const int vo_ = voffX[P_][mb];                                                                            \
-                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {   /* pixels past the image fail the range check: 0 */  \
-                    rpf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vo_ + nb * 64, 0, 0)); \
-                    if constexpr (RMSK)                                                                                   \
-                        mpf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, vo_ + nb * 64, 0, 0)); \
-                    if constexpr (EPI >= 2) {                                                                             \
-                        mbpf[mb][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(bbrsrc, (vo_ >> 4) + nb * 4, 0, 0);       \
-                        xpf[mb][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(x2rsrc, vo_ + nb * 64, 0, 0)); \
-                    }                                                                                                     \
-                    if constexpr (EPI == 3)                                                                               \
-                        ubpf[mb][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(ubrsrc, (vo_ >> 4) + nb * 4, 0, 0);       \
+            const int vo_ = voffX[P_][MBI_];                                                                              \
+            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {       /* pixels past the image fail the range check: 0 */  \
+                rpf[MBI_][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vo_ + nb * 64, 0, 0)); \
+                if constexpr (RMSK)                                                                                       \
+                    mpf[MBI_][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, vo_ + nb * 64, 0, 0)); \
+                if constexpr (EPI >= 2) {                                                                                 \
+                    mbpf[MBI_][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(bbrsrc, (vo_ >> 4) + nb * 4, 0, 0);         \
+                    xpf[MBI_][nb] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(x2rsrc, vo_ + nb * 64, 0, 0)); \
                 }                                                                                                         \
+                if constexpr (EPI == 3)                                                                                   \
+                    ubpf[MBI_][nb] = (int)__builtin_amdgcn_raw_buffer_load_b8(ubrsrc, (vo_ >> 4) + nb * 4, 0, 0);         \
             }                                                                                                             \
         }                                                                                                                 \
+    } while (0)
+#define SO_PREFETCH(P_)                                                                                                   \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) SO_PREFETCH1(P_, mb);                                           \
     } while (0)
             // write-out of pixel block MBI_ of tile T_ (parity Q_).  PRED_: per-lane validity (the image's last tile only)
 #define SO_UNIT(Q_, T_, MBI_, PRED_)                                                                                      \
@@ -1031,8 +1043,9 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
         else if constexpr ((I_) < MB) {                                                                                   \
             if constexpr (WO_) SO_UNIT(1 - (P_), sa_ - 1, ((I_) < MB ? (I_) : 0), 0);                                     \
             SO_TABREAD(sa_ + 1, ((I_) < MB ? (I_) : 0));                                                                  \
+            if constexpr (!SO_LATE_PF) SO_PREFETCH1(P_, ((I_) < MB ? (I_) : 0));                                          \
         } else if constexpr ((I_) < 2 * MB) SO_GEOM(1 - (P_), ((I_) < 2 * MB && (I_) >= MB ? (I_) - MB : 0));             \
-        else if constexpr ((I_) == 2 * MB) SO_PREFETCH(P_);                                                               \
+        else if constexpr ((I_) == 2 * MB && SO_LATE_PF) SO_PREFETCH(P_);                                                 \
     } while (0)
             // one MFMA gap = 32 cycles of which the MFMA holds the issue port for 8: room for ~5 four-cycle instructions
 #ifndef DAM_SO_PAT_VALU
@@ -1126,6 +1139,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
 #undef SO_LOAD
 #undef SO_MFMA
 #undef SO_PREFETCH
+#undef SO_PREFETCH1
 #undef SO_UNIT
 #undef SO_FILL
 #undef SO_PATTERN

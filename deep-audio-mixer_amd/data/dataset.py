@@ -105,13 +105,19 @@ class MultitrackAudioDataset(data.Dataset):
                             '{}_STEM_{}.wav'.format(song_name, track_name.upper()))
 
     def _calculate_song_index(self, chunk_i: int) -> tuple:
-        song_i = 0
-        n_chunks = int(self.song_durations[song_i] / self._chunk_length)
-        while chunk_i >= n_chunks and song_i < len(self.songlist) - 1:
-            chunk_i -= n_chunks
-            song_i += 1
-            n_chunks = int(self.song_durations[song_i] / self._chunk_length)
-        return song_i, chunk_i
+        """Global chunk index -> (song, chunk inside the song): data/dataset.py:97-113 walks the songs one by one (per item, in
+        every worker); here a bisection over the cumulative chunk counts.  Same answers, including the reference's behaviour
+        past the end: indices beyond the last chunk land in the last song with a chunk number that runs on."""
+        starts = getattr(self, '_chunk_starts', None)
+        if starts is None or len(starts) != len(self.songlist):
+            starts, total = [], 0
+            for d in self.song_durations:
+                starts.append(total)
+                total += int(d / self._chunk_length)
+            self._chunk_starts = starts
+        from bisect import bisect_right
+        song_i = max(0, min(bisect_right(starts, chunk_i) - 1, len(starts) - 1))
+        return song_i, chunk_i - starts[song_i]
 
     # ---- features (data/dataset.py:132-162) on the GPU
     def compute_features(self, audio, window_size: int = 2048, hop_length: int = 1024):

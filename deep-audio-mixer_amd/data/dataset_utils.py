@@ -237,11 +237,34 @@ def wav_num_frames(path):
     return h['frames'], h['rate']
 
 
+_resample_warned = False
+
+
+def resample(a, rate, sr):
+    """[frames, channels] at `rate` Hz -> `sr` Hz, float32: what ``librosa.load(path, sr=sr)`` does on a rate mismatch
+    (data/dataset_utils.py:53-83).  librosa's resampler is a third-party dependency that is neither vendored nor installed
+    (soxr_hq in librosa >= 0.10, resampy's kaiser_best before): parity with it is UNPINNED -- this is scipy's polyphase
+    Kaiser-windowed FIR (scipy.signal.resample_poly), the same class of band-limited interpolator, output length
+    ceil(n * sr / rate) as librosa's.  MedleyDB / MUSDB18-HQ are 44.1 kHz throughout, so no reference caller resamples."""
+    global _resample_warned
+    from fractions import Fraction
+    from scipy.signal import resample_poly
+    if not _resample_warned:
+        import warnings
+        warnings.warn('resampling %d Hz audio to %d Hz on load with scipy.signal.resample_poly (librosa.load would use soxr / '
+                      'resampy: samples agree to the resamplers\' pass-band ripple, not bit for bit)' % (rate, sr), RuntimeWarning,
+                      stacklevel=3)
+        _resample_warned = True
+    f = Fraction(int(sr), int(rate))
+    out = resample_poly(a.astype(np.float64), f.numerator, f.denominator, axis=0)
+    n = -(-a.shape[0] * int(sr) // int(rate))
+    return np.ascontiguousarray(out[:n]).astype(np.float32)
+
+
 def _load(path, sr):
     a, rate = read_wav(path, dtype=np.float32)             # librosa.load yields float32
-    if rate != sr:
-        raise ValueError('%s is sampled at %d Hz, not %d (librosa.load would resample; resample the files offline)'
-                         % (path, rate, sr))
+    if sr is not None and rate != sr:
+        a = resample(a, rate, sr)
     return a[:, 0].copy() if a.shape[1] == 1 else a.T.copy()   # mono=False: [n] for mono files, else [channels, n]
 
 

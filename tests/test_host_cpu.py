@@ -43,6 +43,17 @@ def test_dataset_index_arithmetic():
     want = [(s, c) for s, n in enumerate(per_song) for c in range(n)]
     assert seen == want
     assert d._calculate_song_index(len(d) + 5)[0] == 2          # past the end: stays on the last song (reference loop)
+    # the bisection against the reference's linear walk (data/dataset.py:97-113), songs shorter than a chunk included
+    d2 = MultitrackAudioDataset.from_arrays(_songs([1.0, 6.5, 0.5, 0.7, 4.2, 1.9, 9.0, 1.1]), chunk_length=2, sr=8000, seed=5, device='cpu')
+
+    def walk(chunk_i):
+        song_i, n = 0, int(d2.song_durations[0] / 2)
+        while chunk_i >= n and song_i < len(d2.songlist) - 1:
+            chunk_i -= n
+            song_i += 1
+            n = int(d2.song_durations[song_i] / 2)
+        return song_i, chunk_i
+    assert [d2._calculate_song_index(i) for i in range(len(d2) + 3)] == [walk(i) for i in range(len(d2) + 3)]
     np.testing.assert_array_equal(d._stereo_to_mono(np.array([[1.0, 3.0], [2.0, -2.0]])), [2.0, 0.0])
 
 
@@ -62,8 +73,20 @@ def test_wav_partial_read(tmp_path):
     assert len(d) == 0 and d.get_num_songs() == 1                     # 0.625 s < one chunk
     tracks = dataset_utils.load_tracks(str(tmp_path), 'A', sr=sr)
     assert tracks['drums'].shape == (2, n) and tracks['drums'].dtype == np.float32     # librosa.load(mono=False)
-    with pytest.raises(ValueError, match='resample'):
-        dataset_utils.load_tracks(str(tmp_path), 'A')                 # 8 kHz files asked for at 44.1 kHz
+    # a rate mismatch is resampled on load, as librosa.load(path, sr=sr) does (data/dataset_utils.py:53-83): 8 kHz files asked
+    # for at 44.1 kHz -- length ceil(n * 44100 / 8000), and a tone keeps its frequency and level (the resampler itself is scipy's
+    # polyphase FIR: parity with librosa's soxr / resampy is unpinned, stated in the warning)
+    t = np.arange(n) / sr
+    tone = (0.5 * np.sin(2 * np.pi * 440.0 * t)[:, None] * np.ones((1, 2)) * 32767).astype('<i2')
+    with wave.open(str(tmp_path / 'A' / 'A_MIX.wav'), 'wb') as w:
+        w.setnchannels(2), w.setsampwidth(2), w.setframerate(sr)
+        w.writeframes(tone.tobytes())
+    with pytest.warns(RuntimeWarning, match='resampl'):
+        up = dataset_utils.load_tracks(str(tmp_path), 'A', tracklist=('mix',))['mix']
+    assert up.shape == (2, -(-n * 44100 // sr)) and up.dtype == np.float32
+    mid = up[0, 4410:-4410].astype(np.float64)
+    want = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(up.shape[1]) / 44100.0)[4410:-4410]
+    assert np.abs(mid - want).max() < 2e-3
 
 
 def test_wav_native_reads_from_many_threads(tmp_path):

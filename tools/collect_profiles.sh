@@ -20,7 +20,7 @@ done
 run --kernel-trace --stats --output-format csv -d $root/$out/trace_C5 -- python3 $root/bench.py --config C5 --steps 3 --warmup 1 --no-roofline
 cp $out/trace_C5/*/*_kernel_stats.csv $out/C5_kernel_stats.csv
 echo "[collect] C5 trace done"
-for probe in layer1 layer1_wgrad layer3 layer5 layer6 layer4_wgrad layer6_wgrad layer3s2_wgrad stft; do
+for probe in layer1 layer1_dgrad_epi1 layer1_dgrad_epi2 layer1_dgrad_epi3 layer1_wgrad layer3 layer6 layer6_wgrad stft; do
   i=0
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
@@ -35,5 +35,8 @@ python3 bench.py --steps 20 --warmup 3 > $out/bench_line_C3.json 2> $out/bench.e
 python3 bench.py --config C5 --steps 10 > $out/bench_line_C5.json 2>> $out/bench.err
 python3 bench.py --config C2 --steps 10 > $out/bench_line_C2.json 2>> $out/bench.err
 python3 bench.py --config C1 --steps 10 > $out/bench_line_C1.json 2>> $out/bench.err
+python3 bench.py --via-trainer --steps 200 > $out/bench_line_via_trainer.json 2>> $out/bench.err
+python3 bench.py --via-trainer --steps 200 --pcm-loader > $out/bench_line_via_trainer_pcm_loader.json 2>> $out/bench.err
+python3 bench.py --ingest > $out/bench_line_ingest.json 2>> $out/bench.err
 DAM_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 10 --warmup 2 --breakdown --no-roofline --no-host-stream > $out/bench_line_ddp2_gloo_rehearsal.json 2>> $out/bench.err
 tail -c 600 $out/bench_line_C3.json

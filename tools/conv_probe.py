@@ -17,7 +17,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device('cuda', 0)
 B, H, W = 8, 1025, 130
 torch.manual_seed(0)
-if which in ('layer1', 'layer1_wgrad', 'layer1_dgrad'):
+if which in ('layer1', 'layer1_wgrad', 'layer1_dgrad', 'layer1_dgrad_epi1', 'layer1_dgrad_epi2', 'layer1_dgrad_epi3'):
     x = torch.randn((B, H, W, 16), device=dev)
     wt = torch.randn((16, 16, 3, 3), device=dev) * 0.05
     wp, wpt = ops.pack_weights(wt), ops.pack_weights(wt, transpose=True)
@@ -31,6 +31,22 @@ if which in ('layer1', 'layer1_wgrad', 'layer1_dgrad'):
         fn = lambda: ops.conv2d_fwd(x, wp, 16, 3, 3, 1, 1, 1, **kw)
     elif which == 'layer1_dgrad':
         fn = lambda: ops.conv2d_dgrad(dy, wpt, 16, H, W, 3, 3, 1, 1, 1, res=dy, res_mask=x)
+    elif which.startswith('layer1_dgrad_epi'):
+        # the data gradients with the BatchNorm-backward sums epilogues: 1 = sums of bn1 (x rides in the residual operand), 2 = identity
+        # shortcut (residual + sign bytes) + the sums of the upstream relu(bn(x)) (mask from its affine), 3 = upstream mask as sign bytes
+        sc, sh = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.1
+        mean, invstd = torch.randn(16, device=dev) * 0.1, torch.rand(16, device=dev) + 0.5
+        y = torch.randn((B, H, W, 16), device=dev)
+        _, bits = ops.bn_apply(y, sc, sh, relu=True, sign_bits=True)
+        up = torch.randn((B, H, W, 16), device=dev)
+        if which.endswith('1'):
+            fn = lambda: ops.conv2d_dgrad(dy, wpt, 16, H, W, 3, 3, 1, 1, 1, bn_bwd=(x, mean, invstd, sc, sh))
+        elif which.endswith('2'):
+            fn = lambda: ops.conv2d_dgrad(dy, wpt, 16, H, W, 3, 3, 1, 1, 1, res=x, res_mask=y, res_mask_bits=bits, bn_bwd=(up, mean, invstd, sc, sh))
+        else:
+            _, ubits = ops.bn_apply(up, sc, sh, relu=True, sign_bits=True)
+            fn = lambda: ops.conv2d_dgrad(dy, wpt, 16, H, W, 3, 3, 1, 1, 1, res=x, res_mask=y, res_mask_bits=bits,
+                                          bn_bwd=(up, mean, invstd, None, None, ubits))
     else:
         fn = lambda: ops.conv2d_wgrad(x, dy, 16, 3, 3, 1, 1, 1)
 elif which == 'layer3':
