@@ -205,25 +205,35 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, i
 }
 
 // All convolution weights of a model in ONE launch: desc[t] = {src, dst, O, I, KH, KW, transpose, total floats}.
+// A thread owns one (n, k) position and walks its KH*KW taps: the taps of a weight are contiguous in OIHW (36 bytes for 3x3), so
+// its loads hit one or two cache lines and a wave's loads of one tap are neighbours of its loads of the next -- the first version
+// gave every (tap, n, k) its own thread, so each 128-byte line of a weight tensor was fetched by nine workgroups at nine different
+// times (19.6 us per ResNet18 step for 25 MB of packed images); the stores of one tap stay coalesced (consecutive positions).
 __global__ void pack_weights_multi_kernel(const long long* __restrict__ desc) {
     const long long* d = desc + (size_t)blockIdx.y * 8;
     const float* w = reinterpret_cast<const float*>(d[0]);
     float* out = reinterpret_cast<float*>(d[1]);
     const int O = (int)d[2], I = (int)d[3], KH = (int)d[4], KW = (int)d[5], transpose = (int)d[6];
-    const int64_t total = d[7];
     const int n = transpose ? I : O, k = transpose ? O : I;
-    const int nchunks = (k + 15) / 16, nblks = (n + 15) / 16;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int nchunks = (k + 15) / 16, nblks = (n + 15) / 16, taps = KH * KW;
+    const int64_t plane = (int64_t)nchunks * nblks * 256;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < plane; e += (int64_t)gridDim.x * blockDim.x) {
         const int s = e & 3, i = (e >> 2) & 15, kq = (e >> 6) & 3;
-        int64_t r = e >> 8;
-        const int nblk = r % nblks; r /= nblks;
-        const int chunk = r % nchunks;
-        const int tap = r / nchunks;
+        const int64_t r = e >> 8;
+        const int nblk = (int)(r % nblks), chunk = (int)(r / nblks);
         const int nn = nblk * 16 + i, kk = chunk * 16 + kq * 4 + s;
         const int o = transpose ? kk : nn, ii = transpose ? nn : kk;
-        float v = 0.f;
-        if (o < O && ii < I) v = w[((size_t)o * I + ii) * KH * KW + tap];
-        out[e] = v;
+        const bool in = o < O && ii < I;
+        const float* src = w + ((size_t)(in ? o : 0) * I + (in ? ii : 0)) * taps;
+        int tap = 0;
+        for (; tap + 9 <= taps; tap += 9) {             // nine loads in flight (a whole 3x3 kernel)
+            float v[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) v[u] = src[tap + u];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) out[(int64_t)(tap + u) * plane + e] = in ? v[u] : 0.f;
+        }
+        for (; tap < taps; ++tap) out[(int64_t)tap * plane + e] = in ? src[tap] : 0.f;
     }
 }
 
@@ -377,8 +387,9 @@ extern "C" int dam_conv_pack_weights_multi_f32(const int64_t* desc_dev, int n_te
     using namespace dam;
     if (!desc_dev || n_tensors <= 0 || max_total <= 0) return DAM_ERR_BAD_ARG;
     if (n_tensors > 65535) return DAM_ERR_UNSUPPORTED;
-    int64_t bx = cdiv(max_total, 256 * 4);
+    int64_t bx = cdiv(max_total, 256 * 9);          // (a thread packs every tap of its position)
     if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long long*>(desc_dev));
     DAM_CHECK_LAUNCH();

@@ -525,3 +525,29 @@ def test_fused_input_affine_without_relu(ops, B, C, H, W):
     got_dw = ops.conv2d_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), C, 3, 3, 1, 1, 1, in_scale=sc.cuda(), in_shift=sh.cuda(), relu_in=False)
     close(got_dw, want_dw, 5e-5)
 
+
+
+def test_pack_weights_multi_equals_single(dam_lib):
+    """dam_conv_pack_weights_multi_f32 (one launch for every convolution of a model, a thread per (n, k) position walking its taps)
+    against dam_conv_pack_weights_f32 tensor by tensor, bit for bit: 3x3, 1x1, 5x5, 9x9, channel counts that are not multiples
+    of 16 (zero padding), forward and transposed images."""
+    from deep_audio_mixer_amd import ops
+    L = dam_lib
+    g = torch.Generator().manual_seed(5)
+    shapes = [(16, 8, 3, 3), (16, 16, 3, 3), (32, 16, 1, 1), (96, 64, 3, 3), (48, 32, 5, 5), (128, 64, 9, 9), (256, 256, 3, 3), (20, 4, 3, 3)]
+    ws = [torch.randn(s, generator=g).cuda() for s in shapes]
+    rows, outs, want = [], [], []
+    for w in ws:
+        o, i, kh, kw = w.shape
+        for transpose in (False, True):
+            n_out, k_in = (i, o) if transpose else (o, i)
+            n = L.dam_conv_packed_weight_count(n_out, k_in, kh, kw)
+            buf = torch.full((n,), float('nan'), device='cuda')
+            outs.append(buf)
+            want.append(ops.pack_weights(w, transpose=transpose))
+            rows.append([w.data_ptr(), buf.data_ptr(), o, i, kh, kw, int(transpose), n])
+    desc = torch.tensor(rows, dtype=torch.int64).cuda()
+    ops.pack_weights_multi(desc, len(rows), max(r[7] for r in rows))
+    torch.cuda.synchronize()
+    for got, exp, r in zip(outs, want, rows):
+        assert torch.equal(got, exp), r[2:7]
