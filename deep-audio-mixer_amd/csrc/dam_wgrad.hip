@@ -69,6 +69,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
 #pragma unroll
     for (int i = 0; i < NBLK; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+    int toffs[TA * TB];                      // LDS byte offset of tap (ta, tb) relative to the lane's pixel of the staged patch
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            const int coff = g.off_w + tb * g.step_w - g.c0;
+            const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
+            toffs[ta * TB + tb] = (ta * g.step_h * g.PWT + slotoff) * 64;
+        }
     const size_t img_elems = (size_t)g.H * g.W * g.C;
     for (int tile = blockIdx.y; tile < g.total_tiles; tile += g.nsplit) {
         const int img = tile / g.tiles_m;
@@ -101,11 +110,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
         }
         __syncthreads();
 
-        // this wave's 64 pixels, 4 per MFMA step; lane group kq owns pixel 4*t + kq
+        // this wave's WP pixels, 4 per MFMA step; lane group kq owns pixel 4*t + kq.  Two operand sets: the TNB + TA*TB*TKB
+        // ds_read_b32 of step t + 1 are requested before the MFMAs of step t (one wave per SIMD here -- 80-odd KB of LDS per
+        // workgroup -- so nothing else hides the LDS latency: the single-set loop ran the 9x9 / 64 -> 128 layer of the scalar
+        // models at 0.41 of the matrix peak; DAM_WG_NO_PIPELINE keeps it for the A/B)
         int p = p0 + wave * WP + kq;
         int pc = p < HoWo ? p : HoWo - 1;
         int oh = pc / g.Wo, ow = pc - oh * g.Wo;
-        for (int t = 0; t < (WP >> 2); ++t) {
+        const int nsteps = WP >> 2;
+#ifdef DAM_WG_NO_PIPELINE
+        for (int t = 0; t < nsteps; ++t) {
             const int pl = wave * WP + 4 * t + kq;
             float av[TNB];
 #pragma unroll
@@ -138,6 +152,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
                 while (ow >= g.Wo) { ow -= g.Wo; ++oh; }
             }
         }
+#else
+        float av[2][TNB], bv[2][TA * TB * TKB];
+#define DAM_WG_LOAD(BUF_, T_)                                                                                               \
+    do {                                                                                                                  \
+        const int pl_ = wave * WP + 4 * (T_) + kq;                                                                        \
+        _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb)                                                                \
+            av[BUF_][nb] = *reinterpret_cast<const float*>(dy_s + ((nb * TMW + pl_) * 16 + j) * 4);                       \
+        const int base_ = (((oh - oh_first) * g.s) * g.PWT + ow) * 64 + j * 4;                                            \
+        _Pragma("unroll") for (int ta = 0; ta < TA; ++ta)                                                                 \
+            _Pragma("unroll") for (int tb = 0; tb < TB; ++tb)                                                             \
+                _Pragma("unroll") for (int kb = 0; kb < TKB; ++kb)                                                        \
+                    bv[BUF_][(ta * TB + tb) * TKB + kb] =                                                                 \
+                        *reinterpret_cast<const float*>(smem + kb * chunk_bytes + base_ + toffs[ta * TB + tb]);           \
+        p += 4;                                       /* this lane's pixel of the NEXT step (past the image: dY == 0) */  \
+        if (p < HoWo) {                                                                                                   \
+            ow += 4;                                                                                                      \
+            while (ow >= g.Wo) { ow -= g.Wo; ++oh; }                                                                      \
+        }                                                                                                                 \
+    } while (0)
+#define DAM_WG_MFMA(BUF_)                                                                                                   \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int ta = 0; ta < TA; ++ta)                                                                 \
+            _Pragma("unroll") for (int tb = 0; tb < TB; ++tb)                                                             \
+                _Pragma("unroll") for (int kb = 0; kb < TKB; ++kb)                                                        \
+                    _Pragma("unroll") for (int nb = 0; nb < TNB; ++nb) {                                                  \
+                        const int idx = ((nb * TKB + kb) * TA + ta) * TB + tb;                                            \
+                        acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[BUF_][nb], bv[BUF_][(ta * TB + tb) * TKB + kb], acc[idx], 0, 0, 0); \
+                    }                                                                                                     \
+    } while (0)
+        DAM_WG_LOAD(0, 0);
+        int t = 0;
+        for (; t + 2 <= nsteps; t += 2) {
+            DAM_WG_LOAD(1, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            DAM_WG_MFMA(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nsteps) DAM_WG_LOAD(0, t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            DAM_WG_MFMA(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t < nsteps) DAM_WG_MFMA(0);
+#undef DAM_WG_LOAD
+#undef DAM_WG_MFMA
+#endif
     }
 
     // combine the 4 waves through LDS (sequential adds: fixed order), then one slab per workgroup
@@ -1169,9 +1228,29 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
     g.tiles_k = (int)cdiv(g.nchunks, TKB);
     g.tap_groups = (int)cdiv(g.KH, TA);
     const int nx = g.tiles_n * g.tiles_k * g.tap_groups;
+    // Pixel split by MAKESPAN: every CU works through ceil(workgroups / 256) workgroups of ceil(total_tiles / nsplit) tiles each
+    // (co-resident workgroups share the matrix pipe, so it is the count per CU that matters).  The first rule -- at least 512
+    // workgroups -- gave the 9x9 / 64 -> 128 layer of the scalar models 72 x 8 = 576 workgroups of 40 tiles: a third round for a
+    // quarter of the chip (1.64 ms); 72 x 7 = 504 of 46 tiles is two rounds.  DAM_WG_NSPLIT_OLD keeps the first rule (A/B).
     int nsplit = (int)cdiv(512, nx);
     if (nsplit > g.total_tiles) nsplit = g.total_tiles;
     if (nsplit < 1) nsplit = 1;
+    static const bool old_rule = getenv("DAM_WG_NSPLIT_OLD") != nullptr;
+    if (!old_rule) {
+        // slots: two workgroups per CU where the LDS holds two (the small-patch layers: their staging phases overlap each
+        // other -- 256 workgroups of two tiles measured slower than 512 of one on the 33 x 5 stage), one otherwise
+        size_t lds0 = (size_t)TKB * g.PR * g.PWT * 64 + (size_t)TNB * g.TMW * 64;
+        if (lds0 < (size_t)NBLK * 1024) lds0 = (size_t)NBLK * 1024;
+        const int64_t slots = lds0 * 2 <= 160 * 1024 ? 512 : 256;
+        double best = 1e300;
+        const int hi = g.total_tiles < 64 ? g.total_tiles : 64;
+        for (int ns = 1; ns <= hi; ++ns) {
+            const int64_t wgs = (int64_t)nx * ns;
+            if (wgs * NBLK * 256 > ws_floats && ns > 1) break;
+            const double cost = (double)cdiv(wgs, slots) * ((double)cdiv(g.total_tiles, ns) + 1.0);   // + 1: per-workgroup fixed part
+            if (cost < best * 0.999) { best = cost; nsplit = ns; }
+        }
+    }
     while (nsplit > 1 && (int64_t)nsplit * nx * NBLK * 256 > ws_floats) --nsplit;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
     g.nsplit = nsplit;
