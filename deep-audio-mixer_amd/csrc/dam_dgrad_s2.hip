@@ -1,0 +1,212 @@
+// dam_dgrad_s2.hip -- the data gradient of a down-sampling block's INPUT in one launch (models/model_resnet.py:17-21,26 of the
+// reference, reached from loss.backward() at model_trainer.py:36): x feeds conv1 (3x3, stride 2, pad 1) and the shortcut convolution
+// (1x1, stride 2), so
+//
+//     dx[2i  , 2j  ] = W[1][1]^T dc[i,j]                                                              (+ Wsc^T ds[i,j])
+//     dx[2i  , 2j+1] = W[1][0]^T dc[i,j+1] + W[1][2]^T dc[i,j]
+//     dx[2i+1, 2j  ] = W[0][1]^T dc[i+1,j] + W[2][1]^T dc[i,j]
+//     dx[2i+1, 2j+1] = W[0][0]^T dc[i+1,j+1] + W[0][2]^T dc[i+1,j] + W[2][0]^T dc[i,j+1] + W[2][2]^T dc[i,j]
+//
+// with dc = d conv1 output, ds = d shortcut output (both [B][Hd][Wd][Co]) and zero beyond their edges.  Round 3 ran this as the
+// four output-parity classes of the transposed operator: three launches of the tile / row-ring kernels (each staging the same dc
+// again) plus one or two single-tap launches, 0.22-0.29 of the fp32 matrix peak, and every class writing 64-byte pieces at a
+// 128-byte pitch.  Here one wave owns 16 * MB consecutive pixels of dc (rows run on into each other) and produces ALL FOUR classes of them -- the 2 x 2
+// output pixels under each input pixel -- from four shifted operand loads per 16-channel chunk (the shifts re-read neighbours:
+// L1 hits), nine weight taps and 9 * 4 * MB * NB MFMAs per chunk; the two classes of an output row are stored back to back, so
+// every 128-byte line of dx leaves complete.  The workgroups are persistent (<= 2 per CU) and keep the WHOLE packed transposed
+// weight image (9 taps + the shortcut's) in LDS: it is read from L2 once per workgroup, not once per pixel block -- which bounds
+// the layers this kernel takes (9 * Co/16 * Ci/16 KB <= 96 KB: the 16 <- 32 and 32 <- 64 channel blocks of the ResNet; the wider
+// ones keep the class launches, their tensors are small).
+#include "dam_common.h"
+#include <cstdlib>
+
+namespace dam {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// NB: output-channel blocks of 16 (Ci / 16), NCH: input chunks of 16 (Co / 16), MB: pixel blocks of 16 per wave unit
+template <int NB, int NCH, int MB, bool PAIR>
+__global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__ DC, const float4* __restrict__ Wp,
+                                                       const float* __restrict__ DS, const float4* __restrict__ Wp2, int B, int Hd,
+                                                       int Wd, float* __restrict__ DX, int H, int W, int total_px, int total_units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [9 (+1)][NCH][NB][64 lanes] float4
+    constexpr int Co = 16 * NCH, Ci = 16 * NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    {   // the weight image: one pass, all loads of a thread in flight
+        constexpr int N4 = 9 * NCH * NB * 64, N4P = PAIR ? NCH * NB * 64 : 0;
+        for (int e = tid; e < N4; e += 256) reinterpret_cast<float4*>(smem)[e] = Wp[e];
+        if constexpr (PAIR)
+            for (int e = tid; e < N4P; e += 256) reinterpret_cast<float4*>(smem)[N4 + e] = Wp2[e];
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DC), 0, (unsigned)((size_t)B * Hd * Wd * Co * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAIR ? DS : DC), 0, (unsigned)((size_t)B * Hd * Wd * Co * 4), 0x00020000);
+    const int w_lane = lane * 16;
+    static_assert(NCH % 2 == 0, "chunk c of every unit uses operand set c & 1");
+    // Two operand sets: the loads of the NEXT chunk of the stream -- the unit's next chunk, or chunk 0 of the wave's next unit -- are
+    // requested before the MFMAs of the current one (the first version waited a full memory round trip in front of every chunk:
+    // 75 / 80 us per launch where the launches it replaced took 82 / 61).
+    float4 x00[2][MB], x01[2][MB], x10[2][MB], x11[2][MB], s00[2][PAIR ? MB : 1];
+    int o00[MB], o01[MB], o10[MB], o11[MB], n00[MB], n01[MB], n10[MB], n11[MB];
+    // byte offsets of this lane's pixel in the four shifted views (out of the tensor: an offset the range check rejects -> 0)
+#define DAM_S2_OFFSETS(U_, A_, B_, C_, D_)                                                                                    \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                                   \
+            const int p_ = (U_) * (16 * MB) + mb * 16 + j;          /* pixel of the flattened [B * Hd * Wd] index space */    \
+            const int row_ = p_ / Wd, col_ = p_ - row_ * Wd, i_ = row_ % Hd;                                                  \
+            const int base = (p_ * Co + kq * 4) * 4;                                                                          \
+            const bool c0 = (U_) < total_units && p_ < total_px, c1 = c0 && col_ + 1 < Wd, row1_ = i_ + 1 < Hd;               \
+            A_[mb] = c0 ? base : 0x7fffffff;                                                                                  \
+            B_[mb] = c1 ? base + Co * 4 : 0x7fffffff;                                                                         \
+            C_[mb] = (c0 && row1_) ? base + Wd * Co * 4 : 0x7fffffff;                                                         \
+            D_[mb] = (c1 && row1_) ? base + (Wd + 1) * Co * 4 : 0x7fffffff;                                                   \
+        }                                                                                                                     \
+    } while (0)
+#define DAM_S2_LOAD(S_, A_, B_, C_, D_, CH_)                                                                                  \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                                       \
+        x00[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, A_[mb], (CH_) * 64, 0));           \
+        x01[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, B_[mb], (CH_) * 64, 0));           \
+        x10[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, C_[mb], (CH_) * 64, 0));           \
+        x11[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, D_[mb], (CH_) * 64, 0));           \
+        if constexpr (PAIR) s00[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sr, A_[mb], (CH_) * 64, 0)); \
+    }
+    // tap T_ of the transposed operator feeds class CL_ from operand X_ (set S_, chunk CH_)
+#define DAM_S2_TAP(T_, CL_, X_, S_, CH_)                                                                                      \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                                   \
+            const float4 wa = *reinterpret_cast<const float4*>(smem + w_lane + ((((T_) * NCH + (CH_)) * NB + nb) * 1024));    \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                               \
+                acc[CL_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, X_[S_][mb].x, acc[CL_][mb][nb], 0, 0, 0);       \
+                acc[CL_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, X_[S_][mb].y, acc[CL_][mb][nb], 0, 0, 0);       \
+                acc[CL_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, X_[S_][mb].z, acc[CL_][mb][nb], 0, 0, 0);       \
+                acc[CL_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, X_[S_][mb].w, acc[CL_][mb][nb], 0, 0, 0);       \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    } while (0)
+    int unit = blockIdx.x * 4 + wave;
+    const int ustride = gridDim.x * 4;
+    DAM_S2_OFFSETS(unit, o00, o01, o10, o11);
+    DAM_S2_LOAD(0, o00, o01, o10, o11, 0)
+    while (unit < total_units) {
+        v4f acc[4][MB][NB];                 // class (p, q) = 2 p + q
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[cl][mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
+        DAM_S2_OFFSETS(unit + ustride, n00, n01, n10, n11);      // (no next unit: every offset out of range, the loads read 0)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) { DAM_S2_LOAD((c + 1) & 1, o00, o01, o10, o11, c + 1) }
+            else { DAM_S2_LOAD(0, n00, n01, n10, n11, 0) }
+            __builtin_amdgcn_sched_barrier(0);
+            DAM_S2_TAP(4, 0, x00, c & 1, c);                                                             // W[1][1]
+            if constexpr (PAIR) DAM_S2_TAP(9, 0, s00, c & 1, c);                                         // the shortcut's single tap
+            DAM_S2_TAP(3, 1, x01, c & 1, c); DAM_S2_TAP(5, 1, x00, c & 1, c);                            // W[1][0], W[1][2]
+            DAM_S2_TAP(1, 2, x10, c & 1, c); DAM_S2_TAP(7, 2, x00, c & 1, c);                            // W[0][1], W[2][1]
+            DAM_S2_TAP(0, 3, x11, c & 1, c); DAM_S2_TAP(2, 3, x10, c & 1, c);                            // W[0][0], W[0][2]
+            DAM_S2_TAP(6, 3, x01, c & 1, c); DAM_S2_TAP(8, 3, x00, c & 1, c);                            // W[2][0], W[2][2]
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // write-out: lane holds channels 4 kq .. +3 of block nb of its pixel; the two classes of an output row go out back to back
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int p = unit * (16 * MB) + mb * 16 + j;
+            if (p >= total_px) continue;
+            const int row = p / Wd, col = p - row * Wd, img = row / Hd, i = row - img * Hd;
+            const bool orow1 = 2 * i + 1 < H, ocol1 = 2 * col + 1 < W;
+            const size_t p00 = (((size_t)img * H + 2 * i) * W + 2 * col) * Ci + kq * 4;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float* o = DX + p00 + nb * 16;
+                *reinterpret_cast<v4f*>(o) = acc[0][mb][nb];
+                if (ocol1) *reinterpret_cast<v4f*>(o + Ci) = acc[1][mb][nb];
+                if (orow1) {
+                    *reinterpret_cast<v4f*>(o + (size_t)W * Ci) = acc[2][mb][nb];
+                    if (ocol1) *reinterpret_cast<v4f*>(o + (size_t)W * Ci + Ci) = acc[3][mb][nb];
+                }
+            }
+        }
+        unit += ustride;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { o00[mb] = n00[mb]; o01[mb] = n01[mb]; o10[mb] = n10[mb]; o11[mb] = n11[mb]; }
+    }
+#undef DAM_S2_OFFSETS
+#undef DAM_S2_LOAD
+#undef DAM_S2_TAP
+}
+
+template <int NB, int NCH, int MB>
+int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const float* wpt2, int B, int Hd, int Wd, float* dx, int H,
+                    int W, hipStream_t st) {
+    // Units are 16 * MB pixels of the FLATTENED [B * Hd * Wd] index space (a unit per row segment left the last segment of every row
+    // nearly empty: Wd = 33 -> half the MFMAs on padding), each lane finds its row / column by division.
+    const int64_t px = (int64_t)B * Hd * Wd;
+    if (px >= (1ll << 30)) return DAM_ERR_UNSUPPORTED;
+    const int64_t units = cdiv(px, 16 * MB);
+    const size_t lds = (size_t)(9 + (ds ? 1 : 0)) * NCH * NB * 1024;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    }
+    int max_per_cu = (int)((size_t)160 * 1024 / (lds > 0 ? lds : 1));
+    if (max_per_cu > 2) max_per_cu = 2;
+    if (max_per_cu < 1) max_per_cu = 1;
+    static const int forced = [] { const char* e = getenv("DAM_S2_PER_CU"); return e ? atoi(e) : 0; }();      // A/B knob
+    // Workgroups per CU by makespan: n resident waves per SIMD share its MFMA pipe, so a SIMD's time is (units per wave) * n unit
+    // times; more waves hide the operand latency better, which decides when the costs are within ~15 %.
+    int per_cu = 1;
+    int64_t best = 0;
+    for (int n = 1; n <= max_per_cu; ++n) {
+        const int64_t cost = cdiv(units, (int64_t)4 * cus * n) * n * 100;
+        if (n == 1 || cost * 100 <= best * 115) { best = n == 1 ? cost : (cost < best ? cost : best); per_cu = n; }
+    }
+    if (forced >= 1 && forced <= max_per_cu) per_cu = forced;
+    const int64_t rounds = cdiv(units, (int64_t)4 * cus * per_cu);
+    int64_t wgs = cdiv(units, 4 * rounds);                         // every wave `rounds` units (the last ones one fewer)
+    if (ds) {
+        static bool raised = false;
+        if (!raised && lds > 64 * 1024) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;
+            raised = true;
+        }
+        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, true>), dim3((unsigned)wgs), dim3(256), lds, st, dc,
+                           reinterpret_cast<const float4*>(wpt), ds, reinterpret_cast<const float4*>(wpt2), B, Hd, Wd, dx, H, W, (int)px, (int)units);
+    } else {
+        static bool raised = false;
+        if (!raised && lds > 64 * 1024) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;
+            raised = true;
+        }
+        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, false>), dim3((unsigned)wgs), dim3(256), lds, st, dc,
+                           reinterpret_cast<const float4*>(wpt), (const float*)nullptr, (const float4*)nullptr, B, Hd, Wd, dx, H, W, (int)px, (int)units);
+    }
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
+}  // namespace
+}  // namespace dam
+
+// include/dam_hip.h.  DAM_ERR_UNSUPPORTED: the layer is not one this kernel takes (the caller runs the parity classes).
+extern "C" int dam_dgrad_s2_3x3_f32(const float* dy, const float* w_packed_t, const float* dy_pair, const float* w_pair_packed_t,
+                                    int B, int Hd, int Wd, int Co, int Ci, float* dx, int H, int W, void* stream) {
+    using namespace dam;
+    if (!dy || !w_packed_t || !dx || B <= 0 || Hd <= 0 || Wd <= 0 || H <= 0 || W <= 0) return DAM_ERR_BAD_ARG;
+    if ((dy_pair != nullptr) != (w_pair_packed_t != nullptr)) return DAM_ERR_BAD_ARG;
+    if (Hd != (H + 1) / 2 || Wd != (W + 1) / 2) return DAM_ERR_BAD_ARG;             // 3x3 / stride 2 / pad 1 geometry
+    if ((int64_t)B * Hd * Wd * Co * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;   // byte offsets of the range-checked loads
+    hipStream_t st = (hipStream_t)stream;
+    static const int mb1 = [] { const char* e = getenv("DAM_S2_MB1"); return e ? atoi(e) : 0; }();           // A/B knob
+    if (Co == 32 && Ci == 16 && !(mb1 & 1)) return launch_dgrad_s2<1, 2, 2>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 32 && Ci == 16 && (mb1 & 1)) return launch_dgrad_s2<1, 2, 1>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 64 && Ci == 32 && (mb1 & 2)) return launch_dgrad_s2<2, 4, 1>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 64 && Ci == 32) return launch_dgrad_s2<2, 4, 2>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    return DAM_ERR_UNSUPPORTED;
+}

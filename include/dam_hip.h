@@ -50,7 +50,7 @@ struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 /* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
  * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
  * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
-#define DAM_ABI_VERSION 9
+#define DAM_ABI_VERSION 10
 const char* dam_arch(void);
 int dam_abi_version(void);
 
@@ -167,6 +167,17 @@ int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C, int in_nc
 int dam_conv1x1_pair_f32(const float* x1, const float* w1_packed, int tap1, const float* x2, const float* w2_packed, int tap2,
                          int B, int H, int W, int C, int n_out, float* y, int OHt, int OWt, int out_stride, int out_off_h,
                          int out_off_w, void* stream);
+
+/* The whole data gradient of a 3x3 / stride-2 / pad-1 convolution's input in ONE launch -- all four output parity classes from
+ * one read of dy -- optionally with a second, 1x1 / stride-2 operator of the same input added at the (even, even) pixels (a
+ * down-sampling block: conv1 and the shortcut convolution both read x, models/model_resnet.py:17-21,26):
+ *   dx[b, u, v, :] = sum_{a,b} W[a][b]^T dy[b, (u+1-a)/2, (v+1-b)/2, :]  (integer quotients only)  [+ Wp^T dy_pair[b, u/2, v/2, :]]
+ * dy, dy_pair: NHWC [B][Hd][Wd][Co] with Hd = (H+1)/2, Wd = (W+1)/2; w_packed_t / w_pair_packed_t: dam_conv_pack_weights_f32
+ * images with transpose = 1 (nine taps / one tap); dx: NHWC [B][H][W][Ci].  Every byte of dx is written.
+ * The packed weights stay in LDS for the life of a workgroup: DAM_ERR_UNSUPPORTED for layers whose image does not fit
+ * (taken: Co = 32 -> Ci = 16 and Co = 64 -> Ci = 32); the caller then runs the parity classes through dam_conv2d_tapgrid_f32. */
+int dam_dgrad_s2_3x3_f32(const float* dy, const float* w_packed_t, const float* dy_pair, const float* w_pair_packed_t, int B,
+                         int Hd, int Wd, int Co, int Ci, float* dx, int H, int W, void* stream);
 
 /* Sibling launches in one.  The parity classes of a strided data gradient are up to four small launches over the same
  * tensors, weights and tile that differ only in their tap grid.  With a batch (caller-owned HOST memory of

@@ -551,3 +551,31 @@ def test_pack_weights_multi_equals_single(dam_lib):
     torch.cuda.synchronize()
     for got, exp, r in zip(outs, want, rows):
         assert torch.equal(got, exp), r[2:7]
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 16, 32, 41, 27), (2, 16, 32, 40, 28), (8, 16, 32, 1025, 130), (2, 32, 64, 513, 65),
+                                          (1, 32, 64, 34, 17), (1, 16, 32, 3, 3), (2, 16, 32, 21, 131)])
+@pytest.mark.parametrize('pair', [False, True], ids=['alone', 'with_shortcut'])
+def test_strided_dgrad_one_launch(ops, monkeypatch, B, Ci, Co, H, W, pair):
+    """dam_dgrad_s2_3x3_f32: the data gradient of a 3x3 / stride-2 / pad-1 convolution's input -- all four output parity classes
+    from one read of dy, optionally + the 1x1 / stride-2 shortcut's gradient at the (even, even) pixels -- against
+    torch.nn.grad.conv2d_input in float64, odd and even sizes, ragged pixel segments, and bit for bit the same as ... no: within
+    float32 summation order of the parity-class launches it replaces (DAM_NO_DGRAD_S2)."""
+    g = torch.Generator().manual_seed(B * 100 + H + W + pair)
+    Hd, Wd = (H + 1) // 2, (W + 1) // 2
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    dy = torch.randn(B, Co, Hd, Wd, generator=g)
+    want = torch.nn.grad.conv2d_input((B, Ci, H, W), w.double(), dy.double(), 2, 1, 1)
+    wpt = ops.pack_weights(w.cuda(), transpose=True)
+    kw = {}
+    if pair:
+        wsc = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+        ds = torch.randn(B, Co, Hd, Wd, generator=g)
+        want = want + torch.nn.grad.conv2d_input((B, Ci, H, W), wsc.double(), ds.double(), 2, 0, 1)
+        kw['pair_1x1'] = (nhwc(ds).cuda(), ops.pack_weights(wsc.cuda(), transpose=True))
+    assert ops.DGRAD_S2
+    dx = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, Ci, H, W, 3, 3, 2, 1, 1, **kw)
+    close(nchw(dx), want, 2e-5)
+    monkeypatch.setattr(ops, 'DGRAD_S2', False)                       # the launches it replaces: same numbers to rounding
+    dx_old = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, Ci, H, W, 3, 3, 2, 1, 1, **kw)
+    close(dx, dx_old.cpu(), 1e-5)
