@@ -191,6 +191,124 @@ int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const fl
     return DAM_OK;
 }
 
+
+// ---- the wide down-sampling blocks (96 <- 64 ... 256 <- 128 channels): the packed weight image (240 KB ... 1.3 MB) does not fit a
+// workgroup's LDS and the tensors are small (<= 17 k pixels of dc), so a unit is one (16 * MB pixels, one 16-channel block of dx) pair
+// and a wave takes exactly one: its ten weight fragments per 16-channel chunk of dc come straight from L2 into the MFMA's A operand
+// (64 lanes x 16 bytes = one packed 1 KB block per load; every wave with the same channel block reads the same image), the operand
+// loads are the four shifted views of the kernel above, and two register sets keep the next chunk's fifteen loads in flight under the
+// current chunk's 40 * MB MFMAs.  No LDS, no barrier: several workgroups per CU cover each other's waits.
+template <int MB, bool PAIR>
+__global__ __launch_bounds__(256) void dgrad_s2_stream_kernel(const float* __restrict__ DC, const float4* __restrict__ Wp,
+                                                              const float* __restrict__ DS, const float4* __restrict__ Wp2, int Hd, int Wd,
+                                                              float* __restrict__ DX, int H, int W, int total_px, int NCH, int NB,
+                                                              int total_units) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= total_units) return;                                   // (no barrier below)
+    const int nb = unit % NB, pg = unit / NB;                         // the waves of a workgroup mostly share the pixels: L1 hits
+    const int j = lane & 15, kq = lane >> 4;
+    const int Co = 16 * NCH, Ci = 16 * NB;
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DC), 0, (unsigned)((size_t)total_px * Co * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAIR ? DS : DC), 0, (unsigned)((size_t)total_px * Co * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp), 0, (unsigned)((size_t)9 * NCH * NB * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(PAIR ? Wp2 : Wp), 0, (unsigned)((size_t)NCH * NB * 1024), 0x00020000);
+    int o00[MB], o01[MB], o10[MB], o11[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int p = pg * (16 * MB) + mb * 16 + j;
+        const int row = p / Wd, col = p - row * Wd, i = row % Hd;
+        const int base = (p * Co + kq * 4) * 4;
+        const bool c0 = p < total_px, c1 = c0 && col + 1 < Wd, row1 = i + 1 < Hd;
+        o00[mb] = c0 ? base : 0x7fffffff;
+        o01[mb] = c1 ? base + Co * 4 : 0x7fffffff;
+        o10[mb] = (c0 && row1) ? base + Wd * Co * 4 : 0x7fffffff;
+        o11[mb] = (c1 && row1) ? base + (Wd + 1) * Co * 4 : 0x7fffffff;
+    }
+    float4 x00[2][MB], x01[2][MB], x10[2][MB], x11[2][MB], s00[2][PAIR ? MB : 1], wt[2][PAIR ? 10 : 9];
+    // (the chunk rides in the scalar offset, which the range check ignores: the caller of this macro keeps CH_ < NCH)
+#define DAM_S2S_LOAD(S_, CH_)                                                                                                 \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                                   \
+            x00[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, o00[mb], (CH_) * 64, 0));      \
+            x01[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, o01[mb], (CH_) * 64, 0));      \
+            x10[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, o10[mb], (CH_) * 64, 0));      \
+            x11[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, o11[mb], (CH_) * 64, 0));      \
+            if constexpr (PAIR) s00[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sr, o00[mb], (CH_) * 64, 0)); \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                                         \
+            wt[S_][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16, ((t * NCH + (CH_)) * NB + nb) * 1024, 0)); \
+        if constexpr (PAIR)                                                                                                   \
+            wt[S_][9] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w2r, lane * 16, ((CH_) * NB + nb) * 1024, 0)); \
+    } while (0)
+#define DAM_S2S_TAP(T_, CL_, X_, S_)                                                                                          \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                                       \
+        acc[CL_][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][T_].x, X_[S_][mb].x, acc[CL_][mb], 0, 0, 0);               \
+        acc[CL_][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][T_].y, X_[S_][mb].y, acc[CL_][mb], 0, 0, 0);               \
+        acc[CL_][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][T_].z, X_[S_][mb].z, acc[CL_][mb], 0, 0, 0);               \
+        acc[CL_][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][T_].w, X_[S_][mb].w, acc[CL_][mb], 0, 0, 0);               \
+    }
+#define DAM_S2S_CHUNK(S_)                                                                                                     \
+    do {                                                                                                                      \
+        DAM_S2S_TAP(4, 0, x00, S_)                                                                                            \
+        if constexpr (PAIR) { DAM_S2S_TAP(9, 0, s00, S_) }                                                                    \
+        DAM_S2S_TAP(3, 1, x01, S_) DAM_S2S_TAP(5, 1, x00, S_)                                                                 \
+        DAM_S2S_TAP(1, 2, x10, S_) DAM_S2S_TAP(7, 2, x00, S_)                                                                 \
+        DAM_S2S_TAP(0, 3, x11, S_) DAM_S2S_TAP(2, 3, x10, S_) DAM_S2S_TAP(6, 3, x01, S_) DAM_S2S_TAP(8, 3, x00, S_)           \
+    } while (0)
+    v4f acc[4][MB];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[cl][mb] = (v4f){0.f, 0.f, 0.f, 0.f};
+    DAM_S2S_LOAD(0, 0);
+    for (int c = 0; c < NCH; c += 2) {                                 // NCH is even (the entry point checks)
+        DAM_S2S_LOAD(1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        DAM_S2S_CHUNK(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) DAM_S2S_LOAD(0, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        DAM_S2S_CHUNK(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int p = pg * (16 * MB) + mb * 16 + j;
+        if (p >= total_px) continue;
+        const int row = p / Wd, col = p - row * Wd, img = row / Hd, i = row - img * Hd;
+        const bool orow1 = 2 * i + 1 < H, ocol1 = 2 * col + 1 < W;
+        float* o = DX + (((size_t)img * H + 2 * i) * W + 2 * col) * Ci + nb * 16 + kq * 4;
+        *reinterpret_cast<v4f*>(o) = acc[0][mb];
+        if (ocol1) *reinterpret_cast<v4f*>(o + Ci) = acc[1][mb];
+        if (orow1) {
+            *reinterpret_cast<v4f*>(o + (size_t)W * Ci) = acc[2][mb];
+            if (ocol1) *reinterpret_cast<v4f*>(o + (size_t)W * Ci + Ci) = acc[3][mb];
+        }
+    }
+#undef DAM_S2S_LOAD
+#undef DAM_S2S_TAP
+#undef DAM_S2S_CHUNK
+}
+
+template <int MB>
+int launch_dgrad_s2_stream(const float* dc, const float* wpt, const float* ds, const float* wpt2, int B, int Hd, int Wd, int Co, int Ci,
+                           float* dx, int H, int W, hipStream_t st) {
+    const int64_t px = (int64_t)B * Hd * Wd;
+    const int NCH = Co / 16, NB = Ci / 16;
+    const int64_t units = cdiv(px, 16 * MB) * NB;
+    if (px >= (1ll << 26) || units >= (1ll << 30)) return DAM_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)cdiv(units, 4)), block(256);
+    if (ds)
+        hipLaunchKernelGGL((dgrad_s2_stream_kernel<MB, true>), grid, block, 0, st, dc, reinterpret_cast<const float4*>(wpt), ds,
+                           reinterpret_cast<const float4*>(wpt2), Hd, Wd, dx, H, W, (int)px, NCH, NB, (int)units);
+    else
+        hipLaunchKernelGGL((dgrad_s2_stream_kernel<MB, false>), grid, block, 0, st, dc, reinterpret_cast<const float4*>(wpt),
+                           (const float*)nullptr, (const float4*)nullptr, Hd, Wd, dx, H, W, (int)px, NCH, NB, (int)units);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
 }  // namespace
 }  // namespace dam
 
@@ -208,5 +326,14 @@ extern "C" int dam_dgrad_s2_3x3_f32(const float* dy, const float* w_packed_t, co
     if (Co == 32 && Ci == 16 && (mb1 & 1)) return launch_dgrad_s2<1, 2, 1>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
     if (Co == 64 && Ci == 32 && (mb1 & 2)) return launch_dgrad_s2<2, 4, 1>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
     if (Co == 64 && Ci == 32) return launch_dgrad_s2<2, 4, 2>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    // wider layers: the weight image streams from L2 (even chunk count: the two register sets alternate)
+    static const int no_stream = [] { const char* e = getenv("DAM_S2_NO_STREAM"); return e ? atoi(e) : 0; }();       // A/B knob
+    if (!no_stream && Co % 32 == 0 && Ci % 16 == 0 && (int64_t)9 * Co * Ci * 4 < (1ll << 31)) {
+        const int64_t units1 = cdiv((int64_t)B * Hd * Wd, 16) * (Ci / 16);
+        static const int mb_forced = [] { const char* e = getenv("DAM_S2_STREAM_MB"); return e ? atoi(e) : 0; }();   // A/B knob
+        const bool two = mb_forced ? mb_forced == 2 : units1 >= 8 * 1024;          // two pixel blocks per wave once the chip is full
+        return two ? launch_dgrad_s2_stream<2>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, Co, Ci, dx, H, W, st)
+                   : launch_dgrad_s2_stream<1>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, Co, Ci, dx, H, W, st);
+    }
     return DAM_ERR_UNSUPPORTED;
 }

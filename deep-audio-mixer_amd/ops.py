@@ -58,6 +58,7 @@ FUSED_FINALIZE = os.environ.get('DAM_BN_FUSED_FIN', '1') != '0'
 
 # strided 3x3 data gradients of the thin stages as one launch (dam_dgrad_s2_3x3_f32); DAM_NO_DGRAD_S2=1: the parity-class launches (A/B)
 DGRAD_S2 = not os.environ.get('DAM_NO_DGRAD_S2')
+dgrad_s2_launches = 0        # launches dam_dgrad_s2_3x3_f32 accepted (tests check that a shape took the one-launch form)
 # shortcut data gradient riding in conv1's single-tap class launch (dam_conv1x1_pair_f32); DAM_NO_PAIR_1X1=1: two launches (A/B)
 PAIR_1X1 = not os.environ.get('DAM_NO_PAIR_1X1')
 
@@ -212,13 +213,15 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
         if a0[0] is None or a0[1] is None or a0[0][0] != 1 or a0[1][0] != 1 or a0[0][3] != 0 or a0[1][3] != 0:
             raise ValueError('pair_1x1: class (0, 0) of this operator is not a single tap at offset 0')
     # 3x3 / stride 2 / pad 1 (the first convolution of a down-sampling block): all four parity classes (+ the pair term) from
-    # one read of dy in one launch, where the layer's packed weights fit a workgroup's LDS (dam_dgrad_s2_3x3_f32)
+    # one read of dy in one launch (dam_dgrad_s2_3x3_f32: weights resident in LDS for the thin layers, streamed from L2 for the wide)
     if (DGRAD_S2 and stride == 2 and kh == 3 and kw == 3 and pad == 1 and dil == 1 and accumulate_into is None and res is None
             and Ho == (H + 1) // 2 and Wo == (W + 1) // 2):
         st = _lib.lib().dam_dgrad_s2_3x3_f32(_lib.ptr(dy), _lib.ptr(wpt), _lib.ptr(pair_1x1[0]) if pair_1x1 else None,
                                              _lib.ptr(pair_1x1[1]) if pair_1x1 else None, B, Ho, Wo, Co, n16, _lib.ptr(dx), H, W,
                                              _lib.stream())
         if st == 0:
+            global dgrad_s2_launches
+            dgrad_s2_launches += 1
             return dx
         if st != -2:                                   # DAM_ERR_UNSUPPORTED: not a layer that kernel takes -> the class launches
             _lib.check(st, 'dam_dgrad_s2_3x3_f32')

@@ -554,7 +554,10 @@ def test_pack_weights_multi_equals_single(dam_lib):
 
 
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 16, 32, 41, 27), (2, 16, 32, 40, 28), (8, 16, 32, 1025, 130), (2, 32, 64, 513, 65),
-                                          (1, 32, 64, 34, 17), (1, 16, 32, 3, 3), (2, 16, 32, 21, 131)])
+                                          (1, 32, 64, 34, 17), (1, 16, 32, 3, 3), (2, 16, 32, 21, 131),
+                                          # the wide blocks (weights streamed from L2): the ResNet's layer4.0 / 5.0 / 6.0, ragged, two blocks per wave
+                                          (8, 64, 96, 257, 33), (8, 96, 128, 129, 17), (8, 128, 256, 65, 9), (1, 64, 96, 7, 5),
+                                          (2, 64, 96, 513, 130), (1, 32, 32, 9, 12)])
 @pytest.mark.parametrize('pair', [False, True], ids=['alone', 'with_shortcut'])
 def test_strided_dgrad_one_launch(ops, monkeypatch, B, Ci, Co, H, W, pair):
     """dam_dgrad_s2_3x3_f32: the data gradient of a 3x3 / stride-2 / pad-1 convolution's input -- all four output parity classes
@@ -574,7 +577,9 @@ def test_strided_dgrad_one_launch(ops, monkeypatch, B, Ci, Co, H, W, pair):
         want = want + torch.nn.grad.conv2d_input((B, Ci, H, W), wsc.double(), ds.double(), 2, 0, 1)
         kw['pair_1x1'] = (nhwc(ds).cuda(), ops.pack_weights(wsc.cuda(), transpose=True))
     assert ops.DGRAD_S2
+    taken = ops.dgrad_s2_launches
     dx = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, Ci, H, W, 3, 3, 2, 1, 1, **kw)
+    assert ops.dgrad_s2_launches == taken + 1, 'the shape fell back to the parity-class launches'
     close(nchw(dx), want, 2e-5)
     monkeypatch.setattr(ops, 'DGRAD_S2', False)                       # the launches it replaces: same numbers to rounding
     dx_old = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, Ci, H, W, 3, 3, 2, 1, 1, **kw)

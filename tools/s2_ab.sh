@@ -2,14 +2,10 @@
 # A/B of the one-launch strided data gradient's launch knobs on the C3 step (ms per step, 200 steps each)
 set -e
 mkdir -p gpurun_out/r4
-run() { env "$@" python bench.py --steps 200 --warmup 20 --no-cpu-baseline | python -c "import sys,json; print('$*', json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])"; }
+run() { env "$@" python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; print('$*', json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])"; }
 run DAM_X=0
 run DAM_NO_DGRAD_S2=1
-run DAM_S2_MB1=2
-run DAM_S2_MB1=3
-run DAM_S2_MB1=1
-run DAM_S2_PER_CU=1
-run DAM_S2_PER_CU=2
-run DAM_S2_PER_CU=1 DAM_S2_MB1=2
-run DAM_S2_PER_CU=2 DAM_S2_MB1=2
+run DAM_S2_NO_STREAM=1
+run DAM_S2_STREAM_MB=2
+run DAM_S2_STREAM_MB=1
 run DAM_X=0
