@@ -1060,6 +1060,21 @@ extern "C" int dam_bn_finalize_f32(const float* partial, int parts, int C, const
     return DAM_OK;
 }
 
+extern "C" int dam_bn_finalize_pair_f32(const float* partial_a, const float* partial_b, int parts, int C, const dam_bn_fin* a,
+                                        const dam_bn_fin* b, void* stream) {
+    if (!partial_a || !partial_b || parts <= 0 || C <= 0 || !a || !b) return DAM_ERR_BAD_ARG;
+    if (!a->gamma || !a->beta || !a->save_mean || !a->save_invstd || !a->scale || !a->shift || !b->gamma || !b->beta ||
+        !b->save_mean || !b->save_invstd || !b->scale || !b->shift)
+        return DAM_ERR_BAD_ARG;
+    const BnFinArgs fb{b->gamma, b->beta, b->running_mean, b->running_var, (long long*)b->num_batches_tracked, b->momentum,
+                       b->eps, b->save_mean, b->save_invstd, b->scale, b->shift, nullptr};
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C, 2), dim3(64), 0, (hipStream_t)stream, partial_a, parts, C, a->gamma, a->beta,
+                       a->running_mean, a->running_var, (long long*)a->num_batches_tracked, a->momentum, a->eps, a->save_mean,
+                       a->save_invstd, a->scale, a->shift, fb, partial_b);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
 extern "C" int dam_bn_eval_affine_f32(int C, const float* gamma, const float* beta, const float* running_mean,
                                       const float* running_var, float eps, float* save_mean, float* save_invstd,
                                       float* scale, float* shift, void* stream) {

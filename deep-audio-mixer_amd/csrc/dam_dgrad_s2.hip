@@ -26,19 +26,21 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // NB: output-channel blocks of 16 (Ci / 16), NCH: input chunks of 16 (Co / 16), MB: pixel blocks of 16 per wave unit
-template <int NB, int NCH, int MB, bool PAIR>
-__global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__ DC, const float4* __restrict__ Wp,
+// WAVES: waves per workgroup (4; 8 where the weight image leaves room for one workgroup per CU only -- two waves per SIMD cover each
+// other's waits: a wave's stores sit in the same in-order counter as its operand loads, every unit starts by waiting for them)
+template <int NB, int NCH, int MB, bool PAIR, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __restrict__ DC, const float4* __restrict__ Wp,
                                                        const float* __restrict__ DS, const float4* __restrict__ Wp2, int B, int Hd,
-                                                       int Wd, float* __restrict__ DX, int H, int W, int total_px, int total_units) {
+                                                       int Wd, float* __restrict__ DX, int H, int W, int total_px, int total_units, int xcd_aware) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [9 (+1)][NCH][NB][64 lanes] float4
     constexpr int Co = 16 * NCH, Ci = 16 * NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
     {   // the weight image: one pass, all loads of a thread in flight
         constexpr int N4 = 9 * NCH * NB * 64, N4P = PAIR ? NCH * NB * 64 : 0;
-        for (int e = tid; e < N4; e += 256) reinterpret_cast<float4*>(smem)[e] = Wp[e];
+        for (int e = tid; e < N4; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[e] = Wp[e];
         if constexpr (PAIR)
-            for (int e = tid; e < N4P; e += 256) reinterpret_cast<float4*>(smem)[N4 + e] = Wp2[e];
+            for (int e = tid; e < N4P; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[N4 + e] = Wp2[e];
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DC), 0, (unsigned)((size_t)B * Hd * Wd * Co * 4), 0x00020000);
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
     // Two operand sets: the loads of the NEXT chunk of the stream -- the unit's next chunk, or chunk 0 of the wave's next unit -- are
     // requested before the MFMAs of the current one (the first version waited a full memory round trip in front of every chunk:
     // 75 / 80 us per launch where the launches it replaced took 82 / 61).
-    float4 x00[2][MB], x01[2][MB], x10[2][MB], x11[2][MB], s00[2][PAIR ? MB : 1];
+    float4 xo[2][PAIR ? 5 : 4][MB], wa[2][NB];      // operands: 0 = dc[i][j], 1 = dc[i][j+1], 2 = dc[i+1][j], 3 = dc[i+1][j+1], 4 = ds[i][j]
     int o00[MB], o01[MB], o10[MB], o11[MB], n00[MB], n01[MB], n10[MB], n11[MB];
     // byte offsets of this lane's pixel in the four shifted views (out of the tensor: an offset the range check rejects -> 0)
 #define DAM_S2_OFFSETS(U_, A_, B_, C_, D_)                                                                                    \
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
             const int p_ = (U_) * (16 * MB) + mb * 16 + j;          /* pixel of the flattened [B * Hd * Wd] index space */    \
             const int row_ = p_ / Wd, col_ = p_ - row_ * Wd, i_ = row_ % Hd;                                                  \
             const int base = (p_ * Co + kq * 4) * 4;                                                                          \
-            const bool c0 = (U_) < total_units && p_ < total_px, c1 = c0 && col_ + 1 < Wd, row1_ = i_ + 1 < Hd;               \
+            const bool c0 = (U_) < unit_end && p_ < total_px,    c1 = c0 && col_ + 1 < Wd, row1_ = i_ + 1 < Hd;               \
             A_[mb] = c0 ? base : 0x7fffffff;                                                                                  \
             B_[mb] = c1 ? base + Co * 4 : 0x7fffffff;                                                                         \
             C_[mb] = (c0 && row1_) ? base + Wd * Co * 4 : 0x7fffffff;                                                         \
@@ -66,30 +68,54 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
     } while (0)
 #define DAM_S2_LOAD(S_, A_, B_, C_, D_, CH_)                                                                                  \
     _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                                       \
-        x00[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, A_[mb], (CH_) * 64, 0));           \
-        x01[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, B_[mb], (CH_) * 64, 0));           \
-        x10[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, C_[mb], (CH_) * 64, 0));           \
-        x11[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, D_[mb], (CH_) * 64, 0));           \
-        if constexpr (PAIR) s00[S_][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sr, A_[mb], (CH_) * 64, 0)); \
+        xo[S_][0][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, A_[mb], (CH_) * 64, 0));         \
+        xo[S_][1][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, B_[mb], (CH_) * 64, 0));         \
+        xo[S_][2][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, C_[mb], (CH_) * 64, 0));         \
+        xo[S_][3][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, D_[mb], (CH_) * 64, 0));         \
+        if constexpr (PAIR) xo[S_][4][mb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sr, A_[mb], (CH_) * 64, 0)); \
     }
-    // tap T_ of the transposed operator feeds class CL_ from operand X_ (set S_, chunk CH_)
-#define DAM_S2_TAP(T_, CL_, X_, S_, CH_)                                                                                      \
+    // The taps of the transposed operator in issue order: {weight tap (9 = the shortcut's), output class 2 p + q, operand}.
+    // The NB weight fragments of a tap are requested ONE TAP AHEAD of its MFMAs (left to itself the compiler reads them right in
+    // front of their use and every 4 * MB * NB MFMAs wait a full LDS round trip).
+    constexpr int NT = PAIR ? 10 : 9;
+    constexpr int TAPS[10][3] = {{4, 0, 0}, {3, 1, 1}, {5, 1, 0}, {1, 2, 2}, {7, 2, 0}, {0, 3, 3}, {2, 3, 2}, {6, 3, 1}, {8, 3, 0}, {9, 0, 4}};
+#define DAM_S2_WREAD(BUF_, T_, CH_)                                                                                           \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                         \
+        wa[BUF_][nb] = *reinterpret_cast<const float4*>(smem + w_lane + (((T_) * NCH + (CH_)) * NB + nb) * 1024);
+#define DAM_S2_CHUNK(S_, CH_)                                                                                                 \
     do {                                                                                                                      \
-        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                                   \
-            const float4 wa = *reinterpret_cast<const float4*>(smem + w_lane + ((((T_) * NCH + (CH_)) * NB + nb) * 1024));    \
-            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                               \
-                acc[CL_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, X_[S_][mb].x, acc[CL_][mb][nb], 0, 0, 0);       \
-                acc[CL_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, X_[S_][mb].y, acc[CL_][mb][nb], 0, 0, 0);       \
-                acc[CL_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, X_[S_][mb].z, acc[CL_][mb][nb], 0, 0, 0);       \
-                acc[CL_][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, X_[S_][mb].w, acc[CL_][mb][nb], 0, 0, 0);       \
+        DAM_S2_WREAD(0, TAPS[0][0], CH_)                                                                                      \
+        _Pragma("unroll") for (int s = 0; s < NT; ++s) {                                                                      \
+            if (s + 1 < NT) { DAM_S2_WREAD((s + 1) & 1, TAPS[s + 1 < NT ? s + 1 : 0][0], CH_) }                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
+            /* component-major: consecutive MFMAs go to different accumulators (NB * MB independent chains) */               \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                   \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                           \
+                    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                       \
+                        v4f& a_ = acc[TAPS[s][1]][mb][nb];                                                                    \
+                        const float4 w_ = wa[s & 1][nb], x_ = xo[S_][TAPS[s][2]][mb];                                         \
+                        const float wq = q == 0 ? w_.x : q == 1 ? w_.y : q == 2 ? w_.z : w_.w;                                \
+                        const float xq = q == 0 ? x_.x : q == 1 ? x_.y : q == 2 ? x_.z : x_.w;                                \
+                        a_ = __builtin_amdgcn_mfma_f32_16x16x4f32(wq, xq, a_, 0, 0, 0);                                       \
+                    }                                                                                                         \
+                }                                                                                                             \
             }                                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
     } while (0)
-    int unit = blockIdx.x * 4 + wave;
-    const int ustride = gridDim.x * 4;
+    // XCD-aware unit order: workgroup b runs on XCD b % 8 and every XCD has its own L2.  Each XCD takes one CONTIGUOUS eighth of
+    // the units, so the rows that neighbouring units share (the taps reach one row up and down) are fetched into ONE L2 instead of
+    // up to three; inside an XCD wave-major: the units left over after the last full round go to ONE wave each of different
+    // workgroups (SIMDs).  DAM_S2_NO_XCD=1 (read by the launcher: `xcd_aware`): the plain interleaved order (A/B).
+    const int n_xcd = (xcd_aware && (gridDim.x & 7) == 0) ? 8 : 1;
+    const int wg_per_xcd = gridDim.x / n_xcd, per_xcd = (total_units + n_xcd - 1) / n_xcd;
+    const int u_lo = (blockIdx.x % n_xcd) * per_xcd;
+    const int unit_end = u_lo + per_xcd < total_units ? u_lo + per_xcd : total_units;
+    const int ustride = wg_per_xcd * WAVES;
+    int unit = u_lo + wave * wg_per_xcd + blockIdx.x / n_xcd;
     DAM_S2_OFFSETS(unit, o00, o01, o10, o11);
     DAM_S2_LOAD(0, o00, o01, o10, o11, 0)
-    while (unit < total_units) {
+    while (unit < unit_end) {
         v4f acc[4][MB][NB];                 // class (p, q) = 2 p + q
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl)
@@ -103,12 +129,7 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
             if (c + 1 < NCH) { DAM_S2_LOAD((c + 1) & 1, o00, o01, o10, o11, c + 1) }
             else { DAM_S2_LOAD(0, n00, n01, n10, n11, 0) }
             __builtin_amdgcn_sched_barrier(0);
-            DAM_S2_TAP(4, 0, x00, c & 1, c);                                                             // W[1][1]
-            if constexpr (PAIR) DAM_S2_TAP(9, 0, s00, c & 1, c);                                         // the shortcut's single tap
-            DAM_S2_TAP(3, 1, x01, c & 1, c); DAM_S2_TAP(5, 1, x00, c & 1, c);                            // W[1][0], W[1][2]
-            DAM_S2_TAP(1, 2, x10, c & 1, c); DAM_S2_TAP(7, 2, x00, c & 1, c);                            // W[0][1], W[2][1]
-            DAM_S2_TAP(0, 3, x11, c & 1, c); DAM_S2_TAP(2, 3, x10, c & 1, c);                            // W[0][0], W[0][2]
-            DAM_S2_TAP(6, 3, x01, c & 1, c); DAM_S2_TAP(8, 3, x00, c & 1, c);                            // W[2][0], W[2][2]
+            DAM_S2_CHUNK(c & 1, c);
             __builtin_amdgcn_sched_barrier(0);
         }
         // write-out: lane holds channels 4 kq .. +3 of block nb of its pixel; the two classes of an output row go out back to back
@@ -136,10 +157,11 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
     }
 #undef DAM_S2_OFFSETS
 #undef DAM_S2_LOAD
-#undef DAM_S2_TAP
+#undef DAM_S2_WREAD
+#undef DAM_S2_CHUNK
 }
 
-template <int NB, int NCH, int MB>
+template <int NB, int NCH, int MB, int WAVES>
 int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const float* wpt2, int B, int Hd, int Wd, float* dx, int H,
                     int W, hipStream_t st) {
     // Units are 16 * MB pixels of the FLATTENED [B * Hd * Wd] index space (a unit per row segment left the last segment of every row
@@ -154,38 +176,40 @@ int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const fl
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     }
     int max_per_cu = (int)((size_t)160 * 1024 / (lds > 0 ? lds : 1));
-    if (max_per_cu > 2) max_per_cu = 2;
+    if (max_per_cu > 3) max_per_cu = 3;
+    if (WAVES == 8) max_per_cu = 1;
     if (max_per_cu < 1) max_per_cu = 1;
+    static const int xcd_aware = getenv("DAM_S2_NO_XCD") ? 0 : 1;      // A/B knob
     static const int forced = [] { const char* e = getenv("DAM_S2_PER_CU"); return e ? atoi(e) : 0; }();      // A/B knob
     // Workgroups per CU by makespan: n resident waves per SIMD share its MFMA pipe, so a SIMD's time is (units per wave) * n unit
     // times; more waves hide the operand latency better, which decides when the costs are within ~15 %.
     int per_cu = 1;
     int64_t best = 0;
     for (int n = 1; n <= max_per_cu; ++n) {
-        const int64_t cost = cdiv(units, (int64_t)4 * cus * n) * n * 100;
+        const int64_t cost = cdiv(units, (int64_t)WAVES * cus * n) * n * 100;
         if (n == 1 || cost * 100 <= best * 115) { best = n == 1 ? cost : (cost < best ? cost : best); per_cu = n; }
     }
     if (forced >= 1 && forced <= max_per_cu) per_cu = forced;
-    const int64_t rounds = cdiv(units, (int64_t)4 * cus * per_cu);
-    int64_t wgs = cdiv(units, 4 * rounds);                         // every wave `rounds` units (the last ones one fewer)
+    int64_t wgs = (int64_t)cus * per_cu;
+    if (wgs > cdiv(units, WAVES)) wgs = cdiv(units, WAVES);
     if (ds) {
         static bool raised = false;
         if (!raised && lds > 64 * 1024) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, true, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;
             raised = true;
         }
-        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, true>), dim3((unsigned)wgs), dim3(256), lds, st, dc,
-                           reinterpret_cast<const float4*>(wpt), ds, reinterpret_cast<const float4*>(wpt2), B, Hd, Wd, dx, H, W, (int)px, (int)units);
+        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, true, WAVES>), dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, dc,
+                           reinterpret_cast<const float4*>(wpt), ds, reinterpret_cast<const float4*>(wpt2), B, Hd, Wd, dx, H, W, (int)px, (int)units, xcd_aware);
     } else {
         static bool raised = false;
         if (!raised && lds > 64 * 1024) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, false, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;
             raised = true;
         }
-        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, false>), dim3((unsigned)wgs), dim3(256), lds, st, dc,
-                           reinterpret_cast<const float4*>(wpt), (const float*)nullptr, (const float4*)nullptr, B, Hd, Wd, dx, H, W, (int)px, (int)units);
+        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, false, WAVES>), dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, dc,
+                           reinterpret_cast<const float4*>(wpt), (const float*)nullptr, (const float4*)nullptr, B, Hd, Wd, dx, H, W, (int)px, (int)units, xcd_aware);
     }
     DAM_CHECK_LAUNCH();
     return DAM_OK;
@@ -322,10 +346,11 @@ extern "C" int dam_dgrad_s2_3x3_f32(const float* dy, const float* w_packed_t, co
     if ((int64_t)B * Hd * Wd * Co * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;   // byte offsets of the range-checked loads
     hipStream_t st = (hipStream_t)stream;
     static const int mb1 = [] { const char* e = getenv("DAM_S2_MB1"); return e ? atoi(e) : 0; }();           // A/B knob
-    if (Co == 32 && Ci == 16 && !(mb1 & 1)) return launch_dgrad_s2<1, 2, 2>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
-    if (Co == 32 && Ci == 16 && (mb1 & 1)) return launch_dgrad_s2<1, 2, 1>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
-    if (Co == 64 && Ci == 32 && (mb1 & 2)) return launch_dgrad_s2<2, 4, 1>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
-    if (Co == 64 && Ci == 32) return launch_dgrad_s2<2, 4, 2>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 32 && Ci == 16 && !(mb1 & 1)) return launch_dgrad_s2<1, 2, 2, 4>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 32 && Ci == 16 && (mb1 & 1)) return launch_dgrad_s2<1, 2, 1, 4>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 64 && Ci == 32 && (mb1 & 2)) return launch_dgrad_s2<2, 4, 2, 4>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 64 && Ci == 32 && (mb1 & 4)) return launch_dgrad_s2<2, 4, 2, 8>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 64 && Ci == 32) return launch_dgrad_s2<2, 4, 1, 8>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
     // wider layers: the weight image streams from L2 (even chunk count: the two register sets alternate)
     static const int no_stream = [] { const char* e = getenv("DAM_S2_NO_STREAM"); return e ? atoi(e) : 0; }();       // A/B knob
     if (!no_stream && Co % 32 == 0 && Ci % 16 == 0 && (int64_t)9 * Co * Ci * 4 < (1ll << 31)) {

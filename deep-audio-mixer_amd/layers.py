@@ -315,8 +315,18 @@ class BasicBlockFn(torch.autograd.Function):
             bn_sc = blk.shortcut[1]
             # (no statistics from these two launches: the pair pass below is one launch sequence for both tensors, a
             # fused epilogue on conv1 alone would leave the shortcut's statistics a pass of their own)
-            c1, st1 = blk.spec1.fwd_conv(x, w1.detach(), blk.bn1, training, fuse_stats=False)
-            cs, sts = blk.spec_sc.fwd_conv(x, wsc.detach(), bn_sc, training, fuse_stats=False)
+            one = None
+            if (ops.CONV_S2_PAIR and training and blk.spec1.k == 3 and blk.spec1.stride == 2 and blk.spec1.pad == 1
+                    and blk.spec1.dil == 1 and blk.spec_sc.k == 1 and blk.spec_sc.stride == 2 and blk.spec_sc.pad == 0
+                    and not blk.spec1.in_nchw):
+                # both convolutions and both statistics passes from one read of x (thin stages; None: not such a layer)
+                one = ops.conv_s2_pair_fwd(x, blk.spec1.packed(w1.detach()), blk.spec_sc.packed(wsc.detach()), blk.spec1.cout)
+            if one is not None:
+                c1, cs, (p1, p2, parts) = one
+                st1, sts = ops.bn_finalize_pair(p1, p2, parts, _bn_args(blk.bn1, True), _bn_args(bn_sc, True))
+            else:
+                c1, st1 = blk.spec1.fwd_conv(x, w1.detach(), blk.bn1, training, fuse_stats=False)
+                cs, sts = blk.spec_sc.fwd_conv(x, wsc.detach(), bn_sc, training, fuse_stats=False)
             if st1 is None and sts is None and training and c1.shape == cs.shape:
                 # two independent BatchNorms over tensors of one shape, ready together: one statistics pass for both
                 st1, sts = ops.bn_stats_pair(c1, _bn_args(blk.bn1, True), cs, _bn_args(bn_sc, True))

@@ -63,6 +63,11 @@ dgrad_s2_launches = 0        # launches dam_dgrad_s2_3x3_f32 accepted (tests che
 PAIR_1X1 = not os.environ.get('DAM_NO_PAIR_1X1')
 
 
+# a down-sampling block's conv1 + shortcut convolution + both statistics passes as one launch (dam_conv_s2_pair_fwd_f32);
+# DAM_NO_CONV_S2_PAIR=1: the separate launches (A/B)
+CONV_S2_PAIR = not os.environ.get('DAM_NO_CONV_S2_PAIR')
+
+
 # BatchNorm-backward sums from the data-gradient epilogue (include/dam_hip.h: dam_bn_bwd_sums); DAM_NO_DGRAD_SUMS=1 keeps the
 # separate pass over dy and x (A/B switch)
 DGRAD_BN_SUMS = not os.environ.get('DAM_NO_DGRAD_SUMS')
@@ -501,6 +506,41 @@ def bn_stats_pair(xa, bn_a, xb, bn_b):
     ws = _workspace(xa.device, 2 * L.dam_bn_workspace_floats(C))
     _lib.check(L.dam_bn_stats_pair_f32(_lib.ptr(xa), _lib.ptr(xb), xa.numel() // C, C, ctypes.byref(fa), ctypes.byref(fb),
                                        _lib.ptr(ws), _lib.stream()), 'dam_bn_stats_pair_f32')
+    return tuple(outs[0]), tuple(outs[1])
+
+
+def conv_s2_pair_fwd(x, wp, wp_sc, n_out, stats=True):
+    """conv1 (3x3 / stride 2 / pad 1) and the 1x1 / stride-2 shortcut convolution of one NHWC input in one launch:
+    (c1, cs, (records1, records_sc, parts) or None), or None when the layer is not one dam_conv_s2_pair_fwd_f32 takes."""
+    _lib.require_cuda(x, wp, wp_sc)
+    _f32c(x, 'x')
+    B, H, W, C = x.shape
+    n16 = (n_out + 15) // 16 * 16
+    Hd, Wd = (H + 1) // 2, (W + 1) // 2
+    c1 = torch.empty((B, Hd, Wd, n16), dtype=torch.float32, device=x.device)
+    cs = torch.empty_like(c1)
+    p1 = p2 = None
+    parts = ctypes.c_int(0)
+    if stats:
+        n = _lib.lib().dam_bn_workspace_floats(n16)
+        p1 = torch.empty(n, dtype=torch.float32, device=x.device)
+        p2 = torch.empty(n, dtype=torch.float32, device=x.device)
+    st = _lib.lib().dam_conv_s2_pair_fwd_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(wp_sc), B, H, W, C, n16, _lib.ptr(c1), _lib.ptr(cs),
+                                             _lib.ptr(p1), _lib.ptr(p2), ctypes.byref(parts), _lib.stream())
+    if st == -2:                                       # DAM_ERR_UNSUPPORTED
+        return None
+    _lib.check(st, 'dam_conv_s2_pair_fwd_f32')
+    return c1, cs, ((p1, p2, parts.value) if stats else None)
+
+
+def bn_finalize_pair(partial_a, partial_b, parts, bn_a, bn_b):
+    """bn_finalize for two BatchNorms whose records have one count (conv_s2_pair_fwd): one launch.  bn_a, bn_b as bn_stats_pair.
+    Returns two (save_mean, save_invstd, scale, shift) tuples."""
+    C = bn_a[0].numel()
+    outs = [torch.empty((4, C), dtype=torch.float32, device=partial_a.device) for _ in range(2)]
+    fa, fb = _bn_fin_struct(bn_a, outs[0], partial_a.device), _bn_fin_struct(bn_b, outs[1], partial_a.device)
+    _lib.check(_lib.lib().dam_bn_finalize_pair_f32(_lib.ptr(partial_a), _lib.ptr(partial_b), parts, C, ctypes.byref(fa),
+                                                   ctypes.byref(fb), _lib.stream()), 'dam_bn_finalize_pair_f32')
     return tuple(outs[0]), tuple(outs[1])
 
 

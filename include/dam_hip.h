@@ -50,7 +50,7 @@ struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 /* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
  * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
  * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
-#define DAM_ABI_VERSION 10
+#define DAM_ABI_VERSION 11
 const char* dam_arch(void);
 int dam_abi_version(void);
 
@@ -174,10 +174,21 @@ int dam_conv1x1_pair_f32(const float* x1, const float* w1_packed, int tap1, cons
  *   dx[b, u, v, :] = sum_{a,b} W[a][b]^T dy[b, (u+1-a)/2, (v+1-b)/2, :]  (integer quotients only)  [+ Wp^T dy_pair[b, u/2, v/2, :]]
  * dy, dy_pair: NHWC [B][Hd][Wd][Co] with Hd = (H+1)/2, Wd = (W+1)/2; w_packed_t / w_pair_packed_t: dam_conv_pack_weights_f32
  * images with transpose = 1 (nine taps / one tap); dx: NHWC [B][H][W][Ci].  Every byte of dx is written.
- * The packed weights stay in LDS for the life of a workgroup: DAM_ERR_UNSUPPORTED for layers whose image does not fit
- * (taken: Co = 32 -> Ci = 16 and Co = 64 -> Ci = 32); the caller then runs the parity classes through dam_conv2d_tapgrid_f32. */
+ * Co = 32 -> Ci = 16 and Co = 64 -> Ci = 32 keep the packed weights in LDS for the life of a persistent workgroup; other layers
+ * with Co % 32 == 0 and Ci % 16 == 0 stream the weight fragments from L2 (one (pixel block, channel block) unit per wave).
+ * DAM_ERR_UNSUPPORTED for anything else; the caller then runs the parity classes through dam_conv2d_tapgrid_f32. */
 int dam_dgrad_s2_3x3_f32(const float* dy, const float* w_packed_t, const float* dy_pair, const float* w_pair_packed_t, int B,
                          int Hd, int Wd, int Co, int Ci, float* dx, int H, int W, void* stream);
+
+/* Forward of the same block: conv1 (3x3 / stride 2 / pad 1, no bias) and the shortcut convolution (1x1 / stride 2) of one input
+ * in ONE launch, with the BatchNorm statistics records of both outputs (models/model_resnet.py:17-21,24-26: both feed a
+ * training-mode BatchNorm).  x: NHWC [B][H][W][Ci]; w_packed / wsc_packed: dam_conv_pack_weights_f32 images with transpose = 0;
+ * y, ysc: NHWC [B][(H+1)/2][(W+1)/2][Co].  partial / partial_sc (both or neither; >= dam_bn_workspace_floats(Co) floats each):
+ * records [*parts_host][Co][3] = (n, mean, M2), one per workgroup, for dam_bn_finalize_pair_f32 / dam_bn_finalize_f32 /
+ * dam_bn_finalize_apply_f32.  Taken: Ci = 16 -> Co = 32 and Ci = 32 -> Co = 64 (both weight images resident in LDS);
+ * DAM_ERR_UNSUPPORTED otherwise: the caller runs dam_conv2d_tapgrid_f32 twice and dam_bn_stats_pair_f32. */
+int dam_conv_s2_pair_fwd_f32(const float* x, const float* w_packed, const float* wsc_packed, int B, int H, int W, int Ci, int Co,
+                             float* y, float* ysc, float* partial, float* partial_sc, int* parts_host, void* stream);
 
 /* Sibling launches in one.  The parity classes of a strided data gradient are up to four small launches over the same
  * tensors, weights and tile that differ only in their tap grid.  With a batch (caller-owned HOST memory of
@@ -285,6 +296,11 @@ int dam_bn_finalize_f32(const float* partial, int parts, int C, const float* gam
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
                         float* shift, void* stream);
+
+/* dam_bn_finalize_f32 for the two BatchNorms of a pair in one launch (records of equal count and channel number, e.g. from
+ * dam_conv_s2_pair_fwd_f32).  a, b: struct dam_bn_fin (`counter` is ignored). */
+int dam_bn_finalize_pair_f32(const float* partial_a, const float* partial_b, int parts, int C, const struct dam_bn_fin* a,
+                             const struct dam_bn_fin* b, void* stream);
 
 /* First half of dam_bn_stats_f32 on its own: the partial records [*parts_host][C][3] (a HOST int receives the count), sized
  * for dam_bn_finalize_apply_f32 (or dam_bn_finalize_f32).  workspace: dam_bn_workspace_floats(C) floats. */

@@ -584,3 +584,44 @@ def test_strided_dgrad_one_launch(ops, monkeypatch, B, Ci, Co, H, W, pair):
     monkeypatch.setattr(ops, 'DGRAD_S2', False)                       # the launches it replaces: same numbers to rounding
     dx_old = ops.conv2d_dgrad(nhwc(dy).cuda(), wpt, Ci, H, W, 3, 3, 2, 1, 1, **kw)
     close(dx, dx_old.cpu(), 1e-5)
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 16, 32, 41, 27), (2, 16, 32, 40, 28), (8, 16, 32, 1025, 130), (8, 32, 64, 513, 65),
+                                          (1, 32, 64, 34, 17), (1, 16, 32, 3, 3), (2, 16, 32, 21, 131), (1, 32, 64, 2, 2)])
+def test_downsampling_pair_forward_one_launch(ops, B, Ci, Co, H, W):
+    """dam_conv_s2_pair_fwd_f32: a down-sampling block's conv1 (3x3 / stride 2 / pad 1) and its 1x1 / stride-2 shortcut convolution
+    from one read of x, with the BatchNorm statistics records of both outputs -- against torch's conv2d in float64, odd and even
+    sizes, units that straddle rows and images; the records merged (dam_bn_finalize_pair_f32) against the float64 mean / variance of
+    the float64 outputs, and their pixel counts against the tensor's."""
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    x = torch.randn(B, Ci, H, W, generator=g) + 0.3 * torch.randn(1, Ci, 1, 1, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    wsc = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    want1 = F.conv2d(x.double(), w.double(), None, 2, 1)
+    wants = F.conv2d(x.double(), wsc.double(), None, 2, 0)
+    got = ops.conv_s2_pair_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), ops.pack_weights(wsc.cuda()), Co)
+    assert got is not None, 'the shape fell back to the separate launches'
+    c1, cs, (p1, p2, parts) = got
+    close(nchw(c1), want1)
+    close(nchw(cs), wants)
+    npx = want1.numel() // Co
+    for rec in (p1, p2):
+        r = rec[:parts * Co * 3].view(parts, Co, 3).double().cpu()
+        assert torch.equal(r[:, :, 0].sum(0), torch.full((Co,), float(npx), dtype=torch.float64))
+        assert (r[:, :, 2] >= 0).all()
+    mk = lambda: (torch.ones(Co).cuda(), torch.zeros(Co).cuda(), torch.zeros(Co).cuda(), torch.ones(Co).cuda(),
+                  torch.zeros((), dtype=torch.int64).cuda(), 0.1, 1e-5)
+    bn_a, bn_b = mk(), mk()
+    sa, sb = ops.bn_finalize_pair(p1, p2, parts, bn_a, bn_b)
+    for (mean, invstd, scale, shift), want, bn in ((sa, want1, bn_a), (sb, wants, bn_b)):
+        var, mu = torch.var_mean(want, dim=(0, 2, 3), unbiased=False)
+        close(mean, mu, 1e-5)
+        close(invstd, 1.0 / torch.sqrt(var + 1e-5), 1e-5)
+        close(scale, 1.0 / torch.sqrt(var + 1e-5), 1e-5)
+        assert int(bn[4].item()) == 1
+        if npx > 1:
+            close(bn[2], 0.1 * mu, 1e-5)
+            close(bn[3], 0.9 + 0.1 * var * npx / (npx - 1), 1e-5)
+    # without statistics (evaluation-style call): same outputs
+    c1b, csb, none = ops.conv_s2_pair_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), ops.pack_weights(wsc.cuda()), Co, stats=False)
+    assert none is None and torch.equal(c1b, c1) and torch.equal(csb, cs)
