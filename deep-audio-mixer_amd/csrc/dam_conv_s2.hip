@@ -273,7 +273,16 @@ int launch_conv_s2_pair(const float* x, const float* wp, const float* wp2, int B
     }
     // Workgroups per CU by makespan, as in dam_dgrad_s2.hip: n resident waves per SIMD share its MFMA pipe; more waves hide the operand
     // latency better, which decides while the costs are within ~15 %.  One statistics record per workgroup, <= BN_RECORDS_MAX.
-    int max_per_cu = (int)((size_t)160 * 1024 / lds);
+    const bool stats = p1 != nullptr;
+    static int occ[2] = {0, 0};       // resident workgroups per CU of this instantiation (registers and LDS; asked once)
+    int& oc = occ[stats ? 1 : 0];
+    if (!oc) {
+        int n = 0;
+        const hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_s2_pair_kernel<NB, NCH, true, WAVES>, 64 * WAVES, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_s2_pair_kernel<NB, NCH, false, WAVES>, 64 * WAVES, lds);
+        oc = (e == hipSuccess && n >= 1) ? n : 1;
+    }
+    int max_per_cu = oc;
     if (max_per_cu > 3) max_per_cu = 3;
     if (WAVES == 8) max_per_cu = 1;
     if (max_per_cu < 1) max_per_cu = 1;
@@ -290,7 +299,6 @@ int launch_conv_s2_pair(const float* x, const float* wp, const float* wp2, int B
     int64_t wgs = (int64_t)cus * per_cu;
     if (wgs > cdiv(units, WAVES)) wgs = cdiv(units, WAVES);
     static const int xcd_aware = getenv("DAM_S2_NO_XCD") ? 0 : 1;      // A/B knob
-    const bool stats = p1 != nullptr;
     if (parts_host) *parts_host = stats ? (int)wgs : 0;
     static bool raised[2] = {false, false};
     if (lds > 64 * 1024 && !raised[stats ? 1 : 0]) {

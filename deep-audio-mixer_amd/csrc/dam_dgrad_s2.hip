@@ -18,6 +18,7 @@
 // the layers this kernel takes (9 * Co/16 * Ci/16 KB <= 96 KB: the 16 <- 32 and 32 <- 64 channel blocks of the ResNet; the wider
 // ones keep the class launches, their tensors are small).
 #include "dam_common.h"
+#include "dam_bn_fin.h"
 #include <cstdlib>
 
 namespace dam {
@@ -28,10 +29,18 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // NB: output-channel blocks of 16 (Ci / 16), NCH: input chunks of 16 (Co / 16), MB: pixel blocks of 16 per wave unit
 // WAVES: waves per workgroup (4; 8 where the weight image leaves room for one workgroup per CU only -- two waves per SIMD cover each
 // other's waits: a wave's stores sit in the same in-order counter as its operand loads, every unit starts by waiting for them)
-template <int NB, int NCH, int MB, bool PAIR, int WAVES>
+// SUMS: dx is the gradient reaching y = relu(bn(u) + shortcut) of the block in FRONT of this one (models/model_resnet.py:26-27; its
+// ReLU mask as the sign bytes bn_apply left): the two per-channel sums of that BatchNorm's backward pass, sum(dz) and sum(dz * uhat)
+// with dz = dx * (y > 0), uhat = (u - mean) * invstd, are taken here from the output registers and one read of u and the sign
+// bytes -- instead of a pass over dx and u (bn_bwd_partial_kernel<3>: 28 / 16 us on the two thin stages).  One record per workgroup.
+struct S2Sums {
+    const float* u; const unsigned char* bits; const float* mean; const float* invstd; float* rec;      // rec: [workgroups][Ci][2]
+};
+template <int NB, int NCH, int MB, bool PAIR, int WAVES, bool SUMS>
 __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __restrict__ DC, const float4* __restrict__ Wp,
                                                        const float* __restrict__ DS, const float4* __restrict__ Wp2, int B, int Hd,
-                                                       int Wd, float* __restrict__ DX, int H, int W, int total_px, int total_units, int xcd_aware) {
+                                                       int Wd, float* __restrict__ DX, int H, int W, int total_px, int total_units, int xcd_aware,
+                                                       const S2Sums sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [9 (+1)][NCH][NB][64 lanes] float4
     constexpr int Co = 16 * NCH, Ci = 16 * NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,6 +55,17 @@ __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __res
     const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DC), 0, (unsigned)((size_t)B * Hd * Wd * Co * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAIR ? DS : DC), 0, (unsigned)((size_t)B * Hd * Wd * Co * 4), 0x00020000);
     const int w_lane = lane * 16;
+    float su1[SUMS ? NB : 1][4], su2[SUMS ? NB : 1][4];
+    float4 umu[SUMS ? NB : 1], uis[SUMS ? NB : 1];
+    if constexpr (SUMS) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            umu[nb] = *reinterpret_cast<const float4*>(sums.mean + nb * 16 + kq * 4);
+            uis[nb] = *reinterpret_cast<const float4*>(sums.invstd + nb * 16 + kq * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) su1[nb][q] = su2[nb][q] = 0.f;
+        }
+    }
     static_assert(NCH % 2 == 0, "chunk c of every unit uses operand set c & 1");
     // Two operand sets: the loads of the NEXT chunk of the stream -- the unit's next chunk, or chunk 0 of the wave's next unit -- are
     // requested before the MFMAs of the current one (the first version waited a full memory round trip in front of every chunk:
@@ -139,21 +159,88 @@ __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __res
             if (p >= total_px) continue;
             const int row = p / Wd, col = p - row * Wd, img = row / Hd, i = row - img * Hd;
             const bool orow1 = 2 * i + 1 < H, ocol1 = 2 * col + 1 < W;
-            const size_t p00 = (((size_t)img * H + 2 * i) * W + 2 * col) * Ci + kq * 4;
+            const size_t px00 = ((size_t)img * H + 2 * i) * W + 2 * col;            // output pixel of class (0, 0)
+            const size_t p00 = px00 * Ci + kq * 4;
+            if constexpr (SUMS) {
+                // the four output pixels' u quads and sign bytes first (all in flight), then the stores, then the sums
+                float4 uv[4][NB];
+                unsigned ub[4][NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                float* o = DX + p00 + nb * 16;
-                *reinterpret_cast<v4f*>(o) = acc[0][mb][nb];
-                if (ocol1) *reinterpret_cast<v4f*>(o + Ci) = acc[1][mb][nb];
-                if (orow1) {
-                    *reinterpret_cast<v4f*>(o + (size_t)W * Ci) = acc[2][mb][nb];
-                    if (ocol1) *reinterpret_cast<v4f*>(o + (size_t)W * Ci + Ci) = acc[3][mb][nb];
+                for (int cl = 0; cl < 4; ++cl) {
+                    const bool ok = (cl & 1 ? ocol1 : true) && (cl & 2 ? orow1 : true);
+                    const size_t px = px00 + (cl & 1 ? 1 : 0) + (cl & 2 ? (size_t)W : 0);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        uv[cl][nb] = ok ? *reinterpret_cast<const float4*>(sums.u + px * Ci + nb * 16 + kq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        ub[cl][nb] = ok ? sums.bits[px * (Ci / 4) + nb * 4 + kq] : 0u;
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float* o = DX + p00 + nb * 16;
+                    *reinterpret_cast<v4f*>(o) = acc[0][mb][nb];
+                    if (ocol1) *reinterpret_cast<v4f*>(o + Ci) = acc[1][mb][nb];
+                    if (orow1) {
+                        *reinterpret_cast<v4f*>(o + (size_t)W * Ci) = acc[2][mb][nb];
+                        if (ocol1) *reinterpret_cast<v4f*>(o + (size_t)W * Ci + Ci) = acc[3][mb][nb];
+                    }
+                }
+#pragma unroll
+                for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float uq[4] = {uv[cl][nb].x, uv[cl][nb].y, uv[cl][nb].z, uv[cl][nb].w};
+                        const float mq[4] = {umu[nb].x, umu[nb].y, umu[nb].z, umu[nb].w}, iq[4] = {uis[nb].x, uis[nb].y, uis[nb].z, uis[nb].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float dz = (ub[cl][nb] >> q) & 1u ? acc[cl][mb][nb][q] : 0.f;       // (a class outside the image: bits 0)
+                            su1[nb][q] += dz;
+                            su2[nb][q] = fmaf(dz, (uq[q] - mq[q]) * iq[q], su2[nb][q]);
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float* o = DX + p00 + nb * 16;
+                    *reinterpret_cast<v4f*>(o) = acc[0][mb][nb];
+                    if (ocol1) *reinterpret_cast<v4f*>(o + Ci) = acc[1][mb][nb];
+                    if (orow1) {
+                        *reinterpret_cast<v4f*>(o + (size_t)W * Ci) = acc[2][mb][nb];
+                        if (ocol1) *reinterpret_cast<v4f*>(o + (size_t)W * Ci + Ci) = acc[3][mb][nb];
+                    }
                 }
             }
         }
         unit += ustride;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) { o00[mb] = n00[mb]; o01[mb] = n01[mb]; o10[mb] = n10[mb]; o11[mb] = n11[mb]; }
+    }
+    if constexpr (SUMS) {
+        // lane sums -> the sixteen pixel lanes of a channel quad (fixed order) -> the workgroup's waves through LDS: one record
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { su1[nb][q] += __shfl_xor(su1[nb][q], off); su2[nb][q] += __shfl_xor(su2[nb][q], off); }
+        __syncthreads();                                               // every wave is done with the weights
+        float* red = reinterpret_cast<float*>(smem);                 // [WAVES][Ci][2]
+        if (j == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    red[(wave * Ci + nb * 16 + kq * 4 + q) * 2] = su1[nb][q];
+                    red[(wave * Ci + nb * 16 + kq * 4 + q) * 2 + 1] = su2[nb][q];
+                }
+        }
+        __syncthreads();
+        if (tid < 2 * Ci) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += red[w * Ci * 2 + tid];
+            sums.rec[(size_t)blockIdx.x * Ci * 2 + tid] = t;
+        }
     }
 #undef DAM_S2_OFFSETS
 #undef DAM_S2_LOAD
@@ -163,7 +250,7 @@ __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __res
 
 template <int NB, int NCH, int MB, int WAVES>
 int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const float* wpt2, int B, int Hd, int Wd, float* dx, int H,
-                    int W, hipStream_t st) {
+                    int W, const S2Sums& sums, int* parts_host, hipStream_t st) {
     // Units are 16 * MB pixels of the FLATTENED [B * Hd * Wd] index space (a unit per row segment left the last segment of every row
     // nearly empty: Wd = 33 -> half the MFMAs on padding), each lane finds its row / column by division.
     const int64_t px = (int64_t)B * Hd * Wd;
@@ -175,10 +262,21 @@ int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const fl
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     }
-    int max_per_cu = (int)((size_t)160 * 1024 / (lds > 0 ? lds : 1));
+    // resident workgroups per CU of THIS instantiation (registers and LDS; asked once): a grid beyond it would run a second, partial round
+    static int occ[2][2] = {{0, 0}, {0, 0}};
+    int& oc = occ[ds ? 1 : 0][sums.u ? 1 : 0];
+    if (!oc) {
+        int n = 0;
+        hipError_t e;
+        if (ds) e = sums.u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dgrad_s2_kernel<NB, NCH, MB, true, WAVES, true>, 64 * WAVES, lds)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dgrad_s2_kernel<NB, NCH, MB, true, WAVES, false>, 64 * WAVES, lds);
+        else e = sums.u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dgrad_s2_kernel<NB, NCH, MB, false, WAVES, true>, 64 * WAVES, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dgrad_s2_kernel<NB, NCH, MB, false, WAVES, false>, 64 * WAVES, lds);
+        oc = (e == hipSuccess && n >= 1) ? n : 1;
+    }
+    int max_per_cu = oc;
     if (max_per_cu > 3) max_per_cu = 3;
     if (WAVES == 8) max_per_cu = 1;
-    if (max_per_cu < 1) max_per_cu = 1;
     static const int xcd_aware = getenv("DAM_S2_NO_XCD") ? 0 : 1;      // A/B knob
     static const int forced = [] { const char* e = getenv("DAM_S2_PER_CU"); return e ? atoi(e) : 0; }();      // A/B knob
     // Workgroups per CU by makespan: n resident waves per SIMD share its MFMA pipe, so a SIMD's time is (units per wave) * n unit
@@ -192,25 +290,23 @@ int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const fl
     if (forced >= 1 && forced <= max_per_cu) per_cu = forced;
     int64_t wgs = (int64_t)cus * per_cu;
     if (wgs > cdiv(units, WAVES)) wgs = cdiv(units, WAVES);
-    if (ds) {
-        static bool raised = false;
-        if (!raised && lds > 64 * 1024) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, true, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;
-            raised = true;
-        }
-        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, true, WAVES>), dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, dc,
-                           reinterpret_cast<const float4*>(wpt), ds, reinterpret_cast<const float4*>(wpt2), B, Hd, Wd, dx, H, W, (int)px, (int)units, xcd_aware);
-    } else {
-        static bool raised = false;
-        if (!raised && lds > 64 * 1024) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, false, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;
-            raised = true;
-        }
-        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, false, WAVES>), dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, dc,
-                           reinterpret_cast<const float4*>(wpt), (const float*)nullptr, (const float4*)nullptr, B, Hd, Wd, dx, H, W, (int)px, (int)units, xcd_aware);
-    }
+    if (sums.u && wgs > BN_BWD_RECORDS_MAX) return DAM_ERR_UNSUPPORTED;
+#define DAM_S2_GO(PAIR_, SUMS_)                                                                                                   \
+    do {                                                                                                                          \
+        static bool raised = false;                                                                                               \
+        if (!raised && lds > 64 * 1024) {                                                                                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, PAIR_, WAVES, SUMS_>),              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;     \
+            raised = true;                                                                                                        \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((dgrad_s2_kernel<NB, NCH, MB, PAIR_, WAVES, SUMS_>), dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, dc, \
+                           reinterpret_cast<const float4*>(wpt), ds, reinterpret_cast<const float4*>(wpt2), B, Hd, Wd, dx, H, W,      \
+                           (int)px, (int)units, xcd_aware, sums);                                                                 \
+    } while (0)
+    if (ds) { if (sums.u) DAM_S2_GO(true, true); else DAM_S2_GO(true, false); }
+    else { if (sums.u) DAM_S2_GO(false, true); else DAM_S2_GO(false, false); }
+#undef DAM_S2_GO
+    if (parts_host) *parts_host = sums.u ? (int)wgs : 0;
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
@@ -338,19 +434,24 @@ int launch_dgrad_s2_stream(const float* dc, const float* wpt, const float* ds, c
 
 // include/dam_hip.h.  DAM_ERR_UNSUPPORTED: the layer is not one this kernel takes (the caller runs the parity classes).
 extern "C" int dam_dgrad_s2_3x3_f32(const float* dy, const float* w_packed_t, const float* dy_pair, const float* w_pair_packed_t,
-                                    int B, int Hd, int Wd, int Co, int Ci, float* dx, int H, int W, void* stream) {
+                                    int B, int Hd, int Wd, int Co, int Ci, float* dx, int H, int W, const dam_bn_bwd_sums* bn_bwd,
+                                    float* bn_partial, int* bn_parts_host, void* stream) {
     using namespace dam;
     if (!dy || !w_packed_t || !dx || B <= 0 || Hd <= 0 || Wd <= 0 || H <= 0 || W <= 0) return DAM_ERR_BAD_ARG;
     if ((dy_pair != nullptr) != (w_pair_packed_t != nullptr)) return DAM_ERR_BAD_ARG;
     if (Hd != (H + 1) / 2 || Wd != (W + 1) / 2) return DAM_ERR_BAD_ARG;             // 3x3 / stride 2 / pad 1 geometry
     if ((int64_t)B * Hd * Wd * Co * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;   // byte offsets of the range-checked loads
     hipStream_t st = (hipStream_t)stream;
+    if (bn_parts_host) *bn_parts_host = 0;
+    // the upstream BatchNorm's backward sums (mask as sign bytes only): taken by the persistent kernels, "not produced" elsewhere
+    S2Sums sums{nullptr, nullptr, nullptr, nullptr, nullptr};
+    static const int no_sums = getenv("DAM_S2_NO_SUMS") ? 1 : 0;          // A/B knob
+    if (bn_bwd && bn_bwd->x && bn_bwd->mask_bits && bn_bwd->mean && bn_bwd->invstd && bn_partial && bn_parts_host && !no_sums)
+        sums = S2Sums{bn_bwd->x, bn_bwd->mask_bits, bn_bwd->mean, bn_bwd->invstd, bn_partial};
     static const int mb1 = [] { const char* e = getenv("DAM_S2_MB1"); return e ? atoi(e) : 0; }();           // A/B knob
-    if (Co == 32 && Ci == 16 && !(mb1 & 1)) return launch_dgrad_s2<1, 2, 2, 4>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
-    if (Co == 32 && Ci == 16 && (mb1 & 1)) return launch_dgrad_s2<1, 2, 1, 4>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
-    if (Co == 64 && Ci == 32 && (mb1 & 2)) return launch_dgrad_s2<2, 4, 2, 4>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
-    if (Co == 64 && Ci == 32 && (mb1 & 4)) return launch_dgrad_s2<2, 4, 2, 8>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
-    if (Co == 64 && Ci == 32) return launch_dgrad_s2<2, 4, 1, 8>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, st);
+    if (Co == 32 && Ci == 16 && !(mb1 & 1)) return launch_dgrad_s2<1, 2, 2, 4>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, sums, bn_parts_host, st);
+    if (Co == 32 && Ci == 16 && (mb1 & 1)) return launch_dgrad_s2<1, 2, 1, 4>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, sums, bn_parts_host, st);
+    if (Co == 64 && Ci == 32) return launch_dgrad_s2<2, 4, 1, 8>(dy, w_packed_t, dy_pair, w_pair_packed_t, B, Hd, Wd, dx, H, W, sums, bn_parts_host, st);
     // wider layers: the weight image streams from L2 (even chunk count: the two register sets alternate)
     static const int no_stream = [] { const char* e = getenv("DAM_S2_NO_STREAM"); return e ? atoi(e) : 0; }();       // A/B knob
     if (!no_stream && Co % 32 == 0 && Ci % 16 == 0 && (int64_t)9 * Co * Ci * 4 < (1ll << 31)) {

@@ -349,7 +349,10 @@ class BasicBlockFn(torch.autograd.Function):
         ctx.blk, ctx.training, ctx.has_sc = blk, training, wsc is not None
         # an identity block's conv1 data gradient + shortcut IS the gradient of its input: if that input is a relu(bn(c)) whose
         # producer left its record (_UpstreamBn: the stem in front of the first block), backward takes that BatchNorm's sums too
-        ctx.upstream = getattr(x, '_dam_upstream', None) if wsc is None else None
+        # (a down-sampling block's one-launch data gradient does the same for the residual block in front of it: mask as sign bytes)
+        ctx.upstream = getattr(x, '_dam_upstream', None)
+        if wsc is not None and (ctx.upstream is None or ctx.upstream.bits is None or ctx.upstream.scale is not None):
+            ctx.upstream = None
         ctx.slots = tuple(_slot(p) for p in (w1, g1, b1, w2, g2, b2, wsc, gsc, bsc))
         return out
 
@@ -387,7 +390,14 @@ class BasicBlockFn(torch.autograd.Function):
             dws = blk.spec_sc.wgrad(x, dcs, out=wview(s_ws, wsc))
             if ops.PAIR_1X1 and blk.spec1.k == 3 and blk.spec1.stride == 2 and blk.spec_sc.stride == 2:
                 # the shortcut's whole data gradient and the centre tap of conv1's land on the same (even, even) pixels: one launch
-                dx = blk.spec1.dgrad(dc1, w1, hw, pair_1x1=(dcs, blk.spec_sc.packed(wsc, transpose=True)))
+                up = ctx.upstream
+                pair = (dcs, blk.spec_sc.packed(wsc, transpose=True))
+                if up is not None and ops.DGRAD_BN_SUMS and ops.DGRAD_S2 and up.c.shape == x.shape:
+                    dx, sums = blk.spec1.dgrad(dc1, w1, hw, pair_1x1=pair, bn_bwd=up.request())
+                    if sums is not None:
+                        up.offer(sums, dx)
+                else:
+                    dx = blk.spec1.dgrad(dc1, w1, hw, pair_1x1=pair)
             else:
                 dx = blk.spec1.dgrad(dc1, w1, hw)
                 blk.spec_sc.dgrad(dcs, wsc, hw, accumulate_into=dx)

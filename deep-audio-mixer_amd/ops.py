@@ -162,15 +162,30 @@ def _dgrad_axis(parity, pad, dil, k, stride):
 
 
 def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, res_mask=None, accumulate_into=None,
-                 bn_bwd=None, res_mask_bits=None, _diag_bias=None, pair_1x1=None):
+                 bn_bwd=None, res_mask_bits=None, _diag_bias=None, pair_1x1=None, _s2_sums=None):
     """dy: NHWC [B,Ho,Wo,Cout]; wpt packed with transpose=True.  Returns dx NHWC [B,H,W,n_in16]
     (+ res * (res_mask > 0) if given).  With accumulate_into=dx0 the result is added to dx0 in place.
-    bn_bwd=(x, save_mean, save_invstd, mask_scale, mask_shift[, mask_bits]): dx is the gradient reaching relu(bn(x)) (or, with
+    bn_bwd=(x, save_mean, save_invstd, mask_scale, mask_shift[, mask_bits]) (stride 1; 3x3 / stride 2 / pad 1 with the mask_bits
+    form): dx is the gradient reaching relu(bn(x)) (or, with
     mask_bits and scale = shift = None, relu(bn(x) + shortcut) whose sign bytes they are); returns
     (dx, partials) where partials = (records, count) for bn_backward(partials=) when the launch could also take that
     BatchNorm's two backward sums from its epilogue, else None (stride 1; with a residual only when its mask is also given
     as the sign bytes of bn_apply, res_mask_bits -- the float res_mask serves the launches that cannot use them)."""
     _lib.require_cuda(dy, wpt)
+    if bn_bwd is not None and stride == 2:
+        # the strided form: the upstream BatchNorm is a residual block's bn2 (mask = the sign bytes of the block output); only the
+        # one-launch kernels of the thin stages take its sums, (dx, None) otherwise
+        if accumulate_into is not None or res is not None or len(bn_bwd) < 6 or bn_bwd[5] is None or bn_bwd[3] is not None:
+            raise ValueError('bn_bwd at stride 2: mask as sign bytes, no residual / accumulation')
+        xb, mean, invstd, up_bits = bn_bwd[0], bn_bwd[1], bn_bwd[2], bn_bwd[5]
+        _lib.require_cuda(xb)
+        n16 = (n_in + 15) // 16 * 16
+        if tuple(xb.shape) != (dy.shape[0], H, W, n16):
+            raise ValueError('bn_bwd: x has the shape of the data gradient')
+        rec = torch.empty(_lib.lib().dam_bn_workspace_floats(n16), dtype=torch.float32, device=dy.device)
+        epi = _lib.BnBwdSums(_lib.ptr(xb), _lib.ptr(mean), _lib.ptr(invstd), None, None, None, _lib.ptr(up_bits))
+        got = conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride, pad, dil, pair_1x1=pair_1x1, _s2_sums=(epi, rec))
+        return got if isinstance(got, tuple) else (got, None)
     if bn_bwd is not None:
         if stride != 1 or accumulate_into is not None:
             raise ValueError('bn_bwd: stride-1 data gradients only')
@@ -221,12 +236,17 @@ def conv2d_dgrad(dy, wpt, n_in, H, W, kh, kw, stride=1, pad=0, dil=1, res=None, 
     # one read of dy in one launch (dam_dgrad_s2_3x3_f32: weights resident in LDS for the thin layers, streamed from L2 for the wide)
     if (DGRAD_S2 and stride == 2 and kh == 3 and kw == 3 and pad == 1 and dil == 1 and accumulate_into is None and res is None
             and Ho == (H + 1) // 2 and Wo == (W + 1) // 2):
+        parts = ctypes.c_int(0)
         st = _lib.lib().dam_dgrad_s2_3x3_f32(_lib.ptr(dy), _lib.ptr(wpt), _lib.ptr(pair_1x1[0]) if pair_1x1 else None,
                                              _lib.ptr(pair_1x1[1]) if pair_1x1 else None, B, Ho, Wo, Co, n16, _lib.ptr(dx), H, W,
+                                             ctypes.byref(_s2_sums[0]) if _s2_sums else None,
+                                             _lib.ptr(_s2_sums[1]) if _s2_sums else None, ctypes.byref(parts) if _s2_sums else None,
                                              _lib.stream())
         if st == 0:
             global dgrad_s2_launches
             dgrad_s2_launches += 1
+            if _s2_sums:
+                return dx, ((_s2_sums[1], parts.value) if parts.value > 0 else None)
             return dx
         if st != -2:                                   # DAM_ERR_UNSUPPORTED: not a layer that kernel takes -> the class launches
             _lib.check(st, 'dam_dgrad_s2_3x3_f32')

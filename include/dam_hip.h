@@ -50,7 +50,7 @@ struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 /* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
  * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
  * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
-#define DAM_ABI_VERSION 11
+#define DAM_ABI_VERSION 12
 const char* dam_arch(void);
 int dam_abi_version(void);
 
@@ -176,9 +176,14 @@ int dam_conv1x1_pair_f32(const float* x1, const float* w1_packed, int tap1, cons
  * images with transpose = 1 (nine taps / one tap); dx: NHWC [B][H][W][Ci].  Every byte of dx is written.
  * Co = 32 -> Ci = 16 and Co = 64 -> Ci = 32 keep the packed weights in LDS for the life of a persistent workgroup; other layers
  * with Co % 32 == 0 and Ci % 16 == 0 stream the weight fragments from L2 (one (pixel block, channel block) unit per wave).
- * DAM_ERR_UNSUPPORTED for anything else; the caller then runs the parity classes through dam_conv2d_tapgrid_f32. */
+ * DAM_ERR_UNSUPPORTED for anything else; the caller then runs the parity classes through dam_conv2d_tapgrid_f32.
+ * bn_bwd / bn_partial / bn_parts_host (optional, all three or none; see dam_bn_bwd_sums below, `mask_bits` form only): dx is the
+ * gradient reaching relu(bn(u) + shortcut), the output of the block in front (models/model_resnet.py:26-27); the two thin layers'
+ * kernels then also write that BatchNorm's two backward sums as records [*bn_parts_host][Ci][2] into bn_partial (hand them to
+ * dam_bn_backward_f32 as partials_given); *bn_parts_host == 0: not produced, run the separate pass. */
 int dam_dgrad_s2_3x3_f32(const float* dy, const float* w_packed_t, const float* dy_pair, const float* w_pair_packed_t, int B,
-                         int Hd, int Wd, int Co, int Ci, float* dx, int H, int W, void* stream);
+                         int Hd, int Wd, int Co, int Ci, float* dx, int H, int W, const struct dam_bn_bwd_sums* bn_bwd,
+                         float* bn_partial, int* bn_parts_host, void* stream);
 
 /* Forward of the same block: conv1 (3x3 / stride 2 / pad 1, no bias) and the shortcut convolution (1x1 / stride 2) of one input
  * in ONE launch, with the BatchNorm statistics records of both outputs (models/model_resnet.py:17-21,24-26: both feed a

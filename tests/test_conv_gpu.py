@@ -625,3 +625,41 @@ def test_downsampling_pair_forward_one_launch(ops, B, Ci, Co, H, W):
     # without statistics (evaluation-style call): same outputs
     c1b, csb, none = ops.conv_s2_pair_fwd(nhwc(x).cuda(), ops.pack_weights(w.cuda()), ops.pack_weights(wsc.cuda()), Co, stats=False)
     assert none is None and torch.equal(c1b, c1) and torch.equal(csb, cs)
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 16, 32, 41, 27), (2, 16, 32, 40, 28), (2, 32, 64, 34, 17), (4, 32, 64, 257, 33), (1, 16, 32, 3, 3),
+                                          (1, 64, 96, 7, 5)])
+def test_strided_dgrad_takes_the_upstream_batchnorm_sums(ops, B, Ci, Co, H, W):
+    """dam_dgrad_s2_3x3_f32 with bn_bwd: dx reaches y = relu(bn(u) + shortcut) of the block in front; the launch also leaves
+    sum(dz) and sum(dz * uhat), dz = dx * (y > 0), per channel -- against float64 sums over the dx it wrote; the wide layers
+    (weights streamed) report "not produced"."""
+    g = torch.Generator().manual_seed(B * 10 + H + W)
+    Hd, Wd = (H + 1) // 2, (W + 1) // 2
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    wsc = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    dy, ds = torch.randn(B, Hd, Wd, Co, generator=g).cuda(), torch.randn(B, Hd, Wd, Co, generator=g).cuda()
+    u = (torch.randn(B, H, W, Ci, generator=g) * 1.5 + 0.4).cuda()
+    mean, invstd = (torch.randn(Ci, generator=g) * 0.3).cuda(), (torch.rand(Ci, generator=g) + 0.5).cuda()
+    y = torch.randn(B, H, W, Ci, generator=g).cuda()
+    _, bits = ops.bn_apply(y, torch.ones(Ci).cuda(), torch.zeros(Ci).cuda(), relu=True, sign_bits=True)
+    pair = (ds, ops.pack_weights(wsc.cuda(), transpose=True))
+    wpt = ops.pack_weights(w.cuda(), transpose=True)
+    dx, sums = ops.conv2d_dgrad(dy, wpt, Ci, H, W, 3, 3, 2, 1, 1, pair_1x1=pair, bn_bwd=(u, mean, invstd, None, None, bits))
+    plain = ops.conv2d_dgrad(dy, wpt, Ci, H, W, 3, 3, 2, 1, 1, pair_1x1=pair)
+    assert torch.equal(dx, plain)
+    if Ci > 32:
+        assert sums is None
+        return
+    rec, parts = sums
+    r = rec[:parts * Ci * 2].view(parts, Ci, 2).double().sum(0).cpu()
+    dz = (dx.double() * (y > 0)).cpu()
+    uhat = ((u.double() - mean.double()) * invstd.double()).cpu()
+    close(r[:, 0], dz.sum((0, 1, 2)), 2e-5)
+    want2 = (dz * uhat).sum((0, 1, 2))
+    assert (r[:, 1] - want2).abs().max().item() <= 2e-5 * (dz * uhat).abs().sum((0, 1, 2)).max().item()
+    # the records feed bn_backward(partials=): same result as its own pass over dx and u
+    gam = (torch.rand(Ci, generator=g) + 0.5).cuda()
+    a = ops.bn_backward(dx, None, u, gam, mean, invstd, True, mask_bits=bits, partials=sums)
+    b = ops.bn_backward(dx, None, u, gam, mean, invstd, True, mask_bits=bits)
+    for t1, t2 in zip(a, b):
+        close(t1, t2.cpu(), 2e-5)

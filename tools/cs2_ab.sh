@@ -4,6 +4,6 @@ set -e
 mkdir -p gpurun_out/r4
 run() { env "$@" python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; print('$*', json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])"; }
 run DAM_X=0
-run DAM_S2_NO_XCD=1
+run DAM_S2_NO_SUMS=1
 run DAM_X=0
-run DAM_S2_NO_XCD=1
+run DAM_S2_NO_SUMS=1
