@@ -144,10 +144,35 @@ __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __res
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[cl][mb][nb] = (v4f){0.f, 0.f, 0.f, 0.f};
         DAM_S2_OFFSETS(unit + ustride, n00, n01, n10, n11);      // (no next unit: every offset out of range, the loads read 0)
+        float4 uv[SUMS ? MB : 1][4][NB];
+        unsigned ub[SUMS ? MB : 1][4][NB];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (c + 1 < NCH) { DAM_S2_LOAD((c + 1) & 1, o00, o01, o10, o11, c + 1) }
             else { DAM_S2_LOAD(0, n00, n01, n10, n11, 0) }
+            if constexpr (SUMS) {
+                if (c == NCH - 1) {
+                    // the write-out's u quads and sign bytes, requested under the unit's last chunk of MFMAs (asked for at the
+                    // write-out itself they cost the launch 8-12 us of exposed round trips)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int p = unit * (16 * MB) + mb * 16 + j;
+                        const int row = p / Wd, col = p - row * Wd, img = row / Hd, i = row - img * Hd;
+                        const bool live = p < total_px, orow1 = 2 * i + 1 < H, ocol1 = 2 * col + 1 < W;
+                        const size_t px00 = ((size_t)img * H + 2 * i) * W + 2 * col;
+#pragma unroll
+                        for (int cl = 0; cl < 4; ++cl) {
+                            const bool ok = live && (cl & 1 ? ocol1 : true) && (cl & 2 ? orow1 : true);
+                            const size_t px = px00 + (cl & 1 ? 1 : 0) + (cl & 2 ? (size_t)W : 0);
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) {
+                                uv[mb][cl][nb] = ok ? *reinterpret_cast<const float4*>(sums.u + px * Ci + nb * 16 + kq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                ub[mb][cl][nb] = ok ? sums.bits[px * (Ci / 4) + nb * 4 + kq] : 0u;
+                            }
+                        }
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             DAM_S2_CHUNK(c & 1, c);
             __builtin_amdgcn_sched_barrier(0);
@@ -162,19 +187,6 @@ __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __res
             const size_t px00 = ((size_t)img * H + 2 * i) * W + 2 * col;            // output pixel of class (0, 0)
             const size_t p00 = px00 * Ci + kq * 4;
             if constexpr (SUMS) {
-                // the four output pixels' u quads and sign bytes first (all in flight), then the stores, then the sums
-                float4 uv[4][NB];
-                unsigned ub[4][NB];
-#pragma unroll
-                for (int cl = 0; cl < 4; ++cl) {
-                    const bool ok = (cl & 1 ? ocol1 : true) && (cl & 2 ? orow1 : true);
-                    const size_t px = px00 + (cl & 1 ? 1 : 0) + (cl & 2 ? (size_t)W : 0);
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        uv[cl][nb] = ok ? *reinterpret_cast<const float4*>(sums.u + px * Ci + nb * 16 + kq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        ub[cl][nb] = ok ? sums.bits[px * (Ci / 4) + nb * 4 + kq] : 0u;
-                    }
-                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     float* o = DX + p00 + nb * 16;
@@ -189,11 +201,11 @@ __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __res
                 for (int cl = 0; cl < 4; ++cl)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        const float uq[4] = {uv[cl][nb].x, uv[cl][nb].y, uv[cl][nb].z, uv[cl][nb].w};
+                        const float uq[4] = {uv[mb][cl][nb].x, uv[mb][cl][nb].y, uv[mb][cl][nb].z, uv[mb][cl][nb].w};
                         const float mq[4] = {umu[nb].x, umu[nb].y, umu[nb].z, umu[nb].w}, iq[4] = {uis[nb].x, uis[nb].y, uis[nb].z, uis[nb].w};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float dz = (ub[cl][nb] >> q) & 1u ? acc[cl][mb][nb][q] : 0.f;       // (a class outside the image: bits 0)
+                            const float dz = (ub[mb][cl][nb] >> q) & 1u ? acc[cl][mb][nb][q] : 0.f;       // (a class outside the image: bits 0)
                             su1[nb][q] += dz;
                             su2[nb][q] = fmaf(dz, (uq[q] - mq[q]) * iq[q], su2[nb][q]);
                         }
