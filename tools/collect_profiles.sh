@@ -14,6 +14,7 @@ run() { ( cd /tmp && rocprofv3 "$@" ) > $out/last.log 2>&1 || { tail -5 $out/las
 for cfg in C3 C2 C1; do
   run --kernel-trace --stats --output-format csv -d $root/$out/trace_$cfg -- python3 $root/bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-host-stream
   python3 tools/trace_summary.py $out/trace_$cfg 5 70 > $out/${cfg}_kernel_trace_summary.txt
+  python3 tools/step_timeline.py $out/trace_$cfg > $out/${cfg}_step_timeline.txt
   cp $out/trace_$cfg/*/*_kernel_stats.csv $out/${cfg}_kernel_stats.csv
   echo "[collect] $cfg trace done"
 done
