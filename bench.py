@@ -221,10 +221,11 @@ def roofline_object(name, cfg, device, t_frames):
         # the figure below was taken at batch 8 on the forward launch of this kernel at the commit named in traffic_source
         obj = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_MFMA / 1e12, 'unit': 'TFLOP/s', 'frac': tf * 1e12 / PEAK_F32_MFMA,
                'traffic': 140.0e6 if cfg['batch'] == 8 else None,
-               'traffic_source': 'profiles/r03_pmc_final.csv (tools/collect_profiles.sh r03: FETCH_SIZE 36,693 KB x 2 for the gfx950 '
+               'traffic_source': 'profiles/r04_pmc_summary.csv (tools/collect_profiles.sh r04: FETCH_SIZE 36,697 KB x 2 for the gfx950 '
                                  'halving of wide coalesced reads + WRITE_SIZE 66,625 KB = 140.0 MB, forward launch of the '
-                                 'self-overlapped kernel, batch 8, 1.03 x the 136.4 MB algorithmic bytes); a constant from that '
-                                 'separate PMC run, not re-measured by this run',
+                                 'self-overlapped kernel, batch 8, 1.03 x the 136.4 MB algorithmic bytes; the data gradients with '
+                                 'epilogues: 206.7 / 277.6 / 281.8 MB = 1.00 x theirs); a constant from that separate PMC run, '
+                                 'not re-measured by this run',
                'kernel': kern, 'avg_launch_s': t, 'flops_per_launch': k['flops_per_launch'],
                'forward_only': {'avg_launch_s': k['fwd_s'], 'achieved': k['flops_per_launch'] / k['fwd_s'] / 1e12,
                                 'frac': k['flops_per_launch'] / k['fwd_s'] / PEAK_F32_MFMA},
