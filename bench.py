@@ -121,15 +121,27 @@ def synth_clips(n_clips, n_stems, n_samples, device, seed):
     return clips
 
 
-def time_kernel(fn, iters=30, warm=5):
-    """Average device time of one launch sequence, HIP events on the current (launch) stream."""
+def time_kernel(fn, iters=30, warm=5, graph=False):
+    """Average device time of one launch sequence, HIP events on the current (launch) stream.  graph=True: the sequence is
+    captured once and replayed, as the training step replays it -- no host time between its launches (eager launches of
+    ~55 us kernels leave the interpreter ~5 % behind the device on some boxes, which would be timed as kernel time)."""
     import torch
     for _ in range(warm):
         fn()
+    run = fn
+    if graph:
+        from deep_audio_mixer_amd import staging
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with staging.capture_guard:
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                fn()
+        run = g.replay
+        run()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        fn()
+        run()
     b.record()
     b.synchronize()
     return a.elapsed_time(b) * 1e-3 / iters
@@ -162,8 +174,8 @@ def roofline_resnet_layer1(device, batch, t_frames):
     dy = torch.randn((B, H, W, c), device=device)
     flops = 2.0 * B * H * W * c * 9 * c
     out = {'flops_per_launch': flops, 'alg_bytes_per_launch': 4.0 * B * H * W * 2 * c}
-    out['fwd_s'] = time_kernel(lambda: ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1))
-    out['wgrad_s'] = time_kernel(lambda: ops.conv2d_wgrad(x, dy, c, 3, 3, 1, 1, 1))
+    out['fwd_s'] = time_kernel(lambda: ops.conv2d_fwd(x, wp, c, 3, 3, 1, 1, 1), warm=100)
+    out['wgrad_s'] = time_kernel(lambda: ops.conv2d_wgrad(x, dy, c, 3, 3, 1, 1, 1), warm=40)
     # the launches of this kernel in one training step, as the step issues them (stem + two BasicBlocks of layer1):
     # 3 forward with BatchNorm statistics, 2 forward with statistics and the fused input affine, 2 plain data gradients,
     # 2 data gradients with the residual / mask epilogue -- what a kernel trace of the step averages
@@ -189,7 +201,10 @@ def roofline_resnet_layer1(device, batch, t_frames):
         ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1, res=x2, res_mask=msk, res_mask_bits=bits, bn_bwd=(x, mean, invstd, sc, sh))
         ops.conv2d_dgrad(dy, wpt, c, H, W, 3, 3, 1, 1, 1, res=x2, res_mask=msk, res_mask_bits=bits,
                          bn_bwd=(x, mean, invstd, None, None, bits))
-    out['step_mix_s'] = time_kernel(step_mix) / 9.0
+    # 40 warm-up rounds (20 ms of launches): timed after 5 the same sequence reads 60 us per launch instead of 55-56 (clocks and
+    # memory-side cache still cold) -- the figure the step's kernel trace shows is the warm one
+    out['step_mix_s'] = time_kernel(step_mix, warm=40, graph=True) / 9.0
+    out['step_mix_eager_s'] = time_kernel(step_mix, warm=10) / 9.0
     return out
 
 
@@ -227,6 +242,7 @@ def roofline_object(name, cfg, device, t_frames):
                                  'epilogues: 206.7 / 277.6 / 281.8 MB = 1.00 x theirs); a constant from that separate PMC run, '
                                  'not re-measured by this run',
                'kernel': kern, 'avg_launch_s': t, 'flops_per_launch': k['flops_per_launch'],
+               'avg_launch_eager_s': k.get('step_mix_eager_s') if train else None,
                'forward_only': {'avg_launch_s': k['fwd_s'], 'achieved': k['flops_per_launch'] / k['fwd_s'] / 1e12,
                                 'frac': k['flops_per_launch'] / k['fwd_s'] / PEAK_F32_MFMA},
                'wgrad': {'avg_launch_s': k['wgrad_s'], 'achieved': k['flops_per_launch'] / k['wgrad_s'] / 1e12},
