@@ -234,7 +234,7 @@ struct ReduceJob {
     int sl;                  // split lanes: 32, 8 or 1
     int blocks;              // workgroups of the launch that work on this job
 };
-constexpr int REDUCE_MAX_JOBS = 24;
+constexpr int REDUCE_MAX_JOBS = 40;       // one flush per ResNet18 backward (30 weight gradients); 40 x 72 B of kernel arguments
 struct ReduceBatch {
     ReduceJob job[REDUCE_MAX_JOBS];
     int njobs;
