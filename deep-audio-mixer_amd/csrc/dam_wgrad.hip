@@ -1243,7 +1243,9 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
         if (lds0 < (size_t)NBLK * 1024) lds0 = (size_t)NBLK * 1024;
         const int64_t slots = lds0 * 2 <= 160 * 1024 ? 512 : 256;
         double best = 1e300;
-        const int hi = g.total_tiles < 64 ? g.total_tiles : 64;
+        // (up to 512 splits: a layer with ONE channel tile -- the scalar models' 4 -> 16 first convolution -- had 63 workgroups on 256 CUs
+        // under the former cap of 64: 170 us for 0.15 GFLOP)
+        const int hi = g.total_tiles < 512 ? g.total_tiles : 512;
         for (int ns = 1; ns <= hi; ++ns) {
             const int64_t wgs = (int64_t)nx * ns;
             if (wgs * NBLK * 256 > ws_floats && ns > 1) break;
