@@ -10,13 +10,15 @@
 // with dc = d conv1 output, ds = d shortcut output (both [B][Hd][Wd][Co]) and zero beyond their edges.  Round 3 ran this as the
 // four output-parity classes of the transposed operator: three launches of the tile / row-ring kernels (each staging the same dc
 // again) plus one or two single-tap launches, 0.22-0.29 of the fp32 matrix peak, and every class writing 64-byte pieces at a
-// 128-byte pitch.  Here one wave owns 16 * MB consecutive pixels of dc (rows run on into each other) and produces ALL FOUR classes of them -- the 2 x 2
-// output pixels under each input pixel -- from four shifted operand loads per 16-channel chunk (the shifts re-read neighbours:
-// L1 hits), nine weight taps and 9 * 4 * MB * NB MFMAs per chunk; the two classes of an output row are stored back to back, so
-// every 128-byte line of dx leaves complete.  The workgroups are persistent (<= 2 per CU) and keep the WHOLE packed transposed
-// weight image (9 taps + the shortcut's) in LDS: it is read from L2 once per workgroup, not once per pixel block -- which bounds
-// the layers this kernel takes (9 * Co/16 * Ci/16 KB <= 96 KB: the 16 <- 32 and 32 <- 64 channel blocks of the ResNet; the wider
-// ones keep the class launches, their tensors are small).
+// 128-byte pitch.  Here one wave owns 16 * MB consecutive pixels of dc (the flattened [B * Hd * Wd] index: rows run on into each
+// other) and produces ALL FOUR classes of them -- the 2 x 2 output pixels under each input pixel -- from four shifted operand
+// loads per 16-channel chunk (the shifts re-read neighbours: L1 hits), nine weight taps and 9 * 4 * MB * NB MFMAs per chunk; the two
+// classes of an output row are stored back to back, so every 128-byte line of dx leaves complete.  Two kernels:
+//   dgrad_s2_kernel         the thin blocks (16 <- 32, 32 <- 64 channels): persistent workgroups keep the WHOLE packed transposed
+//                           weight image (9 taps + the shortcut's: 20 / 80 KB) in LDS, read from L2 once per workgroup;
+//   dgrad_s2_stream_kernel  the wide blocks (image 240 KB ... 1.3 MB): one (pixel block, channel block) unit per wave, the weight
+//                           fragments go straight from L2 into the MFMA operand.
+// DESIGN.md section 4.2a has the measurements; profiles/r04_s2_kernels_ab.txt the steps that led here.
 #include "dam_common.h"
 #include "dam_bn_fin.h"
 #include <cstdlib>
