@@ -222,43 +222,107 @@ __global__ void masksum_fwd_kernel(const float* __restrict__ x, const float* __r
 }
 
 // partial[b][blk][s] = sum_i d[b][i] * x[b][s][i]  where d = dmasked (MODE 0) or (masked - gt) (MODE 1, also sum d^2)
-template <int MODE>
+// SC: the stem count at compile time (2, 4, 8: the models of the reference) or 0 = run time (<= MAX_STEMS).  With SC the thread
+// requests the S + 1 loads of TWO elements of its stride walk before it touches the first (the kernel is a pure stream of four or
+// five dependent round trips per thread otherwise: 16 us for 43 MB); the generic form predicates 16 loads per element and is
+// slower that way.  Even plane lengths take 8-byte loads (two neighbouring elements per lane).
+template <int MODE, int SC>
 __global__ __launch_bounds__(256) void masksum_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                                  const float* __restrict__ d_or_gt, int S, int64_t FT,
+                                                                  const float* __restrict__ d_or_gt, int S_rt, int64_t FT,
                                                                   float* __restrict__ masked_out,
                                                                   float* __restrict__ partial /* [B][nblk][S+1] */) {
-    __shared__ float red[4];
+    constexpr int SM = SC ? SC : MAX_STEMS, U = SC ? 2 : 1;
+    const int S = SC ? SC : S_rt;
     const int b = blockIdx.y;
-    float gv[MAX_STEMS], acc[MAX_STEMS + 1];
+    float gv[SM], acc[SM + 1];
 #pragma unroll
-    for (int s = 0; s < MAX_STEMS; ++s) { gv[s] = (MODE == 1 && s < S) ? g[b * S + s] : 0.f; acc[s] = 0.f; }
-    acc[MAX_STEMS] = 0.f;
+    for (int s = 0; s < SM; ++s) { gv[s] = (MODE == 1 && s < S) ? g[b * S + s] : 0.f; acc[s] = 0.f; }
+    acc[SM] = 0.f;
     const float* xb = x + (size_t)b * S * FT;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < FT; i += (int64_t)gridDim.x * blockDim.x) {
-        float xv[MAX_STEMS];
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    if (SC && (FT & 1) == 0) {
+        // even plane length (every plane then starts 8-byte aligned): 8-byte loads, two elements per lane and request
+        const int64_t F2 = FT >> 1;
+        const float2* tb = reinterpret_cast<const float2*>(d_or_gt + (size_t)b * FT);
+        for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < F2; i0 += step * U) {
+            float2 xv[U][SM], tv[U];
 #pragma unroll
-        for (int s = 0; s < MAX_STEMS; ++s) xv[s] = s < S ? xb[(size_t)s * FT + i] : 0.f;
-        float d;
-        if (MODE == 1) {
-            float m = 0.f;
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + u * step;
+                const bool ok = i < F2;
 #pragma unroll
-            for (int s = 0; s < MAX_STEMS; ++s) m = fmaf(gv[s], xv[s], m);
-            if (masked_out) masked_out[(size_t)b * FT + i] = m;
-            d = m - d_or_gt[(size_t)b * FT + i];
-            acc[MAX_STEMS] = fmaf(d, d, acc[MAX_STEMS]);
-        } else {
-            d = d_or_gt[(size_t)b * FT + i];
+                for (int s = 0; s < SM; ++s)
+                    xv[u][s] = ok ? reinterpret_cast<const float2*>(xb + (size_t)s * FT)[i] : make_float2(0.f, 0.f);
+                tv[u] = ok ? tb[i] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + u * step;
+                if (i < F2) {
+                    float2 d;
+                    if (MODE == 1) {
+                        float2 m = make_float2(0.f, 0.f);
+#pragma unroll
+                        for (int s = 0; s < SM; ++s) { m.x = fmaf(gv[s], xv[u][s].x, m.x); m.y = fmaf(gv[s], xv[u][s].y, m.y); }
+                        if (masked_out) reinterpret_cast<float2*>(masked_out + (size_t)b * FT)[i] = m;
+                        d = make_float2(m.x - tv[u].x, m.y - tv[u].y);
+                        acc[SM] = fmaf(d.x, d.x, acc[SM]);
+                        acc[SM] = fmaf(d.y, d.y, acc[SM]);
+                    } else {
+                        d = tv[u];
+                    }
+#pragma unroll
+                    for (int s = 0; s < SM; ++s) { acc[s] = fmaf(d.x, xv[u][s].x, acc[s]); acc[s] = fmaf(d.y, xv[u][s].y, acc[s]); }
+                }
+            }
         }
+    } else {
+        for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < FT; i0 += step * U) {
+            float xv[U][SM], tv[U];
 #pragma unroll
-        for (int s = 0; s < MAX_STEMS; ++s) acc[s] = fmaf(d, xv[s], acc[s]);
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + u * step;
+                const bool ok = i < FT;
+#pragma unroll
+                for (int s = 0; s < SM; ++s) xv[u][s] = (ok && s < S) ? xb[(size_t)s * FT + i] : 0.f;
+                tv[u] = ok ? d_or_gt[(size_t)b * FT + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + u * step;
+                if (i < FT) {
+                    float d;
+                    if (MODE == 1) {
+                        float m = 0.f;
+#pragma unroll
+                        for (int s = 0; s < SM; ++s) m = fmaf(gv[s], xv[u][s], m);
+                        if (masked_out) masked_out[(size_t)b * FT + i] = m;
+                        d = m - tv[u];
+                        acc[SM] = fmaf(d, d, acc[SM]);
+                    } else {
+                        d = tv[u];
+                    }
+#pragma unroll
+                    for (int s = 0; s < SM; ++s) acc[s] = fmaf(d, xv[u][s], acc[s]);
+                }
+            }
+        }
     }
+    // all S + 1 sums in ONE pass: wave sums by shuffles, one barrier, thread s adds the four waves' values (nine block_sum calls
+    // in a row were eighteen barriers)
+    __shared__ float redw[4][MAX_STEMS + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k <= SM; ++k) {
+        const float t = wave_sum64(acc[k]);
+        if (lane == 0) redw[wave][k == SM ? MAX_STEMS : k] = t;
+    }
+    __syncthreads();
     float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (S + 1);
-    for (int s = 0; s < S; ++s) {
-        const float t = block_sum(acc[s], red);
-        if (threadIdx.x == 0) out[s] = t;
+    if ((int)threadIdx.x <= S) {
+        const int k = (int)threadIdx.x == S ? MAX_STEMS : (int)threadIdx.x;
+        out[threadIdx.x] = redw[0][k] + redw[1][k] + redw[2][k] + redw[3][k];
     }
-    const float t = block_sum(acc[MAX_STEMS], red);
-    if (threadIdx.x == 0) out[S] = t;
 }
 // dg[b][s] = scale * sum_blk partial;  loss = sum of squared error / count   (MODE 1).  One wave per (b, s), last block: loss.
 __global__ __launch_bounds__(64) void masksum_bwd_finalize_kernel(const float* __restrict__ partial, int B, int nblk, int S,
@@ -350,8 +414,14 @@ extern "C" int dam_masksum_bwd_f32(const float* dmasked, const float* x, int B, 
     if (S < 1 || S > MAX_STEMS || B > 65535) return DAM_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int gx = (int)(cdiv(FT, 1024) < 256 ? cdiv(FT, 1024) : 256);
-    hipLaunchKernelGGL((masksum_bwd_partial_kernel<0>), dim3(gx, B), dim3(256), 0, st, x, (const float*)nullptr, dmasked, S, FT,
-                       (float*)nullptr, workspace);
+#define DAM_MASKSUM_GO(MODE_, G_, D_, M_)                                                                                       \
+    do {                                                                                                                        \
+        if (S == 8) hipLaunchKernelGGL((masksum_bwd_partial_kernel<MODE_, 8>), dim3(gx, B), dim3(256), 0, st, x, G_, D_, S, FT, M_, workspace);      \
+        else if (S == 4) hipLaunchKernelGGL((masksum_bwd_partial_kernel<MODE_, 4>), dim3(gx, B), dim3(256), 0, st, x, G_, D_, S, FT, M_, workspace); \
+        else if (S == 2) hipLaunchKernelGGL((masksum_bwd_partial_kernel<MODE_, 2>), dim3(gx, B), dim3(256), 0, st, x, G_, D_, S, FT, M_, workspace); \
+        else hipLaunchKernelGGL((masksum_bwd_partial_kernel<MODE_, 0>), dim3(gx, B), dim3(256), 0, st, x, G_, D_, S, FT, M_, workspace);             \
+    } while (0)
+    DAM_MASKSUM_GO(0, (const float*)nullptr, dmasked, (float*)nullptr);
     DAM_CHECK_LAUNCH();
     hipLaunchKernelGGL(masksum_bwd_finalize_kernel, dim3(B * S), dim3(64), 0, st, workspace, B, gx, S, 1.0, 0.0,
                        dgains, (float*)nullptr);
@@ -365,7 +435,7 @@ extern "C" int dam_masksum_mse_f32(const float* x, const float* gains, const flo
     if (S < 1 || S > MAX_STEMS || B > 65535) return DAM_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int gx = (int)(cdiv(FT, 1024) < 256 ? cdiv(FT, 1024) : 256);
-    hipLaunchKernelGGL((masksum_bwd_partial_kernel<1>), dim3(gx, B), dim3(256), 0, st, x, gains, gt, S, FT, masked, workspace);
+    DAM_MASKSUM_GO(1, gains, gt, masked);
     DAM_CHECK_LAUNCH();
     const double count = (double)B * (double)FT;
     hipLaunchKernelGGL(masksum_bwd_finalize_kernel, dim3(B * S + 1), dim3(64), 0, st, workspace, B, gx, S,
