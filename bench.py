@@ -203,8 +203,12 @@ def roofline_resnet_layer1(device, batch, t_frames):
                          bn_bwd=(x, mean, invstd, None, None, bits))
     # 40 warm-up rounds (20 ms of launches): timed after 5 the same sequence reads 60 us per launch instead of 55-56 (clocks and
     # memory-side cache still cold) -- the figure the step's kernel trace shows is the warm one
-    out['step_mix_s'] = time_kernel(step_mix, warm=40, graph=True) / 9.0
-    out['step_mix_eager_s'] = time_kernel(step_mix, warm=10) / 9.0
+    out['step_mix_eager_s'] = time_kernel(step_mix, warm=40) / 9.0
+    try:
+        out['step_mix_s'] = time_kernel(step_mix, warm=5, graph=True) / 9.0
+    except Exception as e:      # a failed capture must not cost the bench line: the eager figure stands in (and says so)
+        sys.stderr.write('bench: roofline probe could not be captured (%r); eager timing used\n' % (e,))
+        out['step_mix_s'] = out['step_mix_eager_s']
     return out
 
 
