@@ -1241,7 +1241,8 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
         // other -- 256 workgroups of two tiles measured slower than 512 of one on the 33 x 5 stage), one otherwise
         size_t lds0 = (size_t)TKB * g.PR * g.PWT * 64 + (size_t)TNB * g.TMW * 64;
         if (lds0 < (size_t)NBLK * 1024) lds0 = (size_t)NBLK * 1024;
-        const int64_t slots = lds0 * 2 <= 160 * 1024 ? 512 : 256;
+        static const int slots_forced = [] { const char* e = getenv("DAM_WG_SLOTS"); return e ? atoi(e) : 0; }();      // A/B knob
+        const int64_t slots = slots_forced ? slots_forced : (lds0 * 2 <= 160 * 1024 ? 512 : 256);
         double best = 1e300;
         // (up to 512 splits: a layer with ONE channel tile -- the scalar models' 4 -> 16 first convolution -- had 63 workgroups on 256 CUs
         // under the former cap of 64: 170 us for 0.15 GFLOP)
