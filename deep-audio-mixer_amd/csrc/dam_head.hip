@@ -15,22 +15,29 @@ namespace {
 
 constexpr int MAX_STEMS = 16;
 
-// h[b][s][p] = relu(cb[s] + sum_c trunk[b][p][c] * cw[s][c]);  one wave per pixel.
+// h[b][s][p] = relu(cb[s] + sum_c trunk[b][p][c] * cw[s][c]);  one lane GROUP per pixel: 64 lanes for >= 132 channels (the ResNet's
+// 256), 32 / 16 lanes for <= 128 / <= 64 (the scalar models' 128: a whole wave per pixel left half its lanes idle and did six
+// shuffle steps per stem where five serve -- 37.7 us for 41 MB).
+template <int GS>
 __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ trunk, int P, int C, int S,
                                                         const float* __restrict__ cw, const float* __restrict__ cb,
                                                         float* __restrict__ h) {
     extern __shared__ float w_s[];   // [S][C]
     for (int e = threadIdx.x; e < S * C; e += blockDim.x) w_s[e] = cw[e];
     __syncthreads();
+    constexpr int G = 64 / GS;                               // pixels per wave and round
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int gl = lane % GS, gi = lane / GS;
     const int Q = C / 4;
-    for (int p = blockIdx.x * 4 + wave; p < P; p += gridDim.x * 4) {
+    for (int p0 = (blockIdx.x * 4 + wave) * G; p0 < P; p0 += gridDim.x * 4 * G) {
+        const int p = p0 + gi;
+        const bool live = p < P;
         float acc[MAX_STEMS];
 #pragma unroll
         for (int s = 0; s < MAX_STEMS; ++s) acc[s] = 0.f;
-        const float4* row = reinterpret_cast<const float4*>(trunk + ((size_t)b * P + p) * C);
-        for (int q = lane; q < Q; q += 64) {
-            const float4 v = row[q];
+        const float4* row = reinterpret_cast<const float4*>(trunk + ((size_t)b * P + (live ? p : 0)) * C);
+        for (int q = gl; q < Q; q += GS) {
+            const float4 v = live ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int s = 0; s < MAX_STEMS; ++s) {
                 if (s < S) {
@@ -42,8 +49,10 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
 #pragma unroll
         for (int s = 0; s < MAX_STEMS; ++s) {
             if (s < S) {
-                const float t = wave_sum64(acc[s]);
-                if (lane == 0) h[((size_t)b * S + s) * P + p] = fmaxf(t + cb[s], 0.f);
+                float t = wave_sum16(acc[s]);
+                if (GS >= 32) t += __shfl_xor(t, 16);
+                if (GS >= 64) t += __shfl_xor(t, 32);
+                if (gl == 0 && live) h[((size_t)b * S + s) * P + p] = fmaxf(t + cb[s], 0.f);
             }
         }
     }
@@ -66,13 +75,25 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* __restrict__ 
     const int s = blockIdx.x, b = blockIdx.y;
     const float* hr = h + ((size_t)b * S + s) * P;
     const float* wr = fcw + (size_t)s * P;
-    float a = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) a = fmaf(hr[p], wr[p], a);
+    // eight independent chains, sixteen loads in flight per thread: the scalar models' 20049-pixel rows took 78 dependent
+    // round trips per thread (29.5 us for 16 workgroups)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int p = threadIdx.x;
+    for (; p + 7 * 256 < P; p += 8 * 256) {
+        float hv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { hv[u] = hr[p + u * 256]; wv[u] = wr[p + u * 256]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] = fmaf(hv[u], wv[u], a8[u]);
+    }
+    for (; p < P; p += 256) a8[0] = fmaf(hr[p], wr[p], a8[0]);
+    float a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     a = block_sum(a, red);
     if (threadIdx.x == 0) g[b * S + s] = a + fcb[s];
 }
 
 // e[b][s][p] = dg[b][s] * fcw[s][p] * (h > 0);  dtrunk[b][p][:] = sum_s e * cw[s][:]
+template <int GS>      // lanes per pixel, as in head_conv_kernel
 __global__ __launch_bounds__(256) void head_bwd_pixel_kernel(const float* __restrict__ dg, const float* __restrict__ h,
                                                              int P, int C, int S, const float* __restrict__ cw,
                                                              const float* __restrict__ fcw, float* __restrict__ e_out,
@@ -97,9 +118,13 @@ __global__ __launch_bounds__(256) void head_bwd_pixel_kernel(const float* __rest
     }
     for (int e = threadIdx.x; e < S * C; e += blockDim.x) w_s[e] = cw[e];
     __syncthreads();
+    constexpr int G = 64 / GS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int gl = lane % GS, gi = lane / GS;
     const int Q = C / 4;
-    for (int p = blockIdx.x * 4 + wave; p < P; p += gridDim.x * 4) {
+    for (int p0 = (blockIdx.x * 4 + wave) * G; p0 < P; p0 += gridDim.x * 4 * G) {
+        const int p = p0 + gi;
+        if (p >= P) continue;                                        // (no barrier in the loop)
         float ev[MAX_STEMS];
 #pragma unroll
         for (int s = 0; s < MAX_STEMS; ++s) {
@@ -107,11 +132,11 @@ __global__ __launch_bounds__(256) void head_bwd_pixel_kernel(const float* __rest
             if (s < S) {
                 const size_t i = ((size_t)b * S + s) * P + p;
                 ev[s] = h[i] > 0.f ? dg[b * S + s] * fcw[(size_t)s * P + p] : 0.f;
-                if (lane == 0) e_out[i] = ev[s];
+                if (gl == 0) e_out[i] = ev[s];
             }
         }
         float4* row = reinterpret_cast<float4*>(dtrunk + ((size_t)b * P + p) * C);
-        for (int q = lane; q < Q; q += 64) {
+        for (int q = gl; q < Q; q += GS) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int s = 0; s < MAX_STEMS; ++s) {
@@ -353,8 +378,11 @@ extern "C" int dam_heads_fwd_f32(const float* trunk, int B, int P, int C, int S,
     if (!trunk || !conv_w || !conv_b || !fc_w || !fc_b || !h || !gains || B <= 0 || P <= 0) return DAM_ERR_BAD_ARG;
     if (C % 4 || S < 1 || S > MAX_STEMS || B > 65535) return DAM_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int gx = (int)(cdiv(P, 4) < 1024 ? cdiv(P, 4) : 1024);
-    hipLaunchKernelGGL(head_conv_kernel, dim3(gx, B), dim3(256), (size_t)S * C * sizeof(float), st, trunk, P, C, S, conv_w, conv_b, h);
+    const int Q = C / 4, gs = Q <= 16 ? 16 : Q <= 32 ? 32 : 64, ppw = 4 * (64 / gs);        // pixels per workgroup and round
+    const int gx = (int)(cdiv(P, ppw) < 1024 ? cdiv(P, ppw) : 1024);
+    if (gs == 16) hipLaunchKernelGGL(head_conv_kernel<16>, dim3(gx, B), dim3(256), (size_t)S * C * sizeof(float), st, trunk, P, C, S, conv_w, conv_b, h);
+    else if (gs == 32) hipLaunchKernelGGL(head_conv_kernel<32>, dim3(gx, B), dim3(256), (size_t)S * C * sizeof(float), st, trunk, P, C, S, conv_w, conv_b, h);
+    else hipLaunchKernelGGL(head_conv_kernel<64>, dim3(gx, B), dim3(256), (size_t)S * C * sizeof(float), st, trunk, P, C, S, conv_w, conv_b, h);
     DAM_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_fc_kernel, dim3(S, B), dim3(256), 0, st, h, P, S, fc_w, fc_b, gains);
     DAM_CHECK_LAUNCH();
@@ -375,9 +403,13 @@ extern "C" int dam_heads_bwd_f32(const float* dgains, const float* h, const floa
     float* e = workspace;
     float* partial = workspace + (size_t)B * S * P;
     float* partial_b = partial + (size_t)1024 * S * C;
-    const int gx = (int)(cdiv(P, 4) < 1024 ? cdiv(P, 4) : 1024);
-    hipLaunchKernelGGL(head_bwd_pixel_kernel, dim3(gx, B + 1), dim3(256), (size_t)S * C * sizeof(float), st, dgains, h, P, C, S,
-                       conv_w, fc_w, e, dtrunk, B, dfc_w, dfc_b);       // (row B of the grid: the Linear layer's gradients)
+    const int Qp = C / 4, gs = Qp <= 16 ? 16 : Qp <= 32 ? 32 : 64, ppw = 4 * (64 / gs);
+    const int gx = (int)(cdiv(P, ppw) < 1024 ? cdiv(P, ppw) : 1024);
+#define DAM_HEAD_PIXEL(GS_)                                                                                                     \
+    hipLaunchKernelGGL(head_bwd_pixel_kernel<GS_>, dim3(gx, B + 1), dim3(256), (size_t)S * C * sizeof(float), st, dgains, h, P, C, S, \
+                       conv_w, fc_w, e, dtrunk, B, dfc_w, dfc_b)        /* (row B of the grid: the Linear layer's gradients) */
+    if (gs == 16) DAM_HEAD_PIXEL(16); else if (gs == 32) DAM_HEAD_PIXEL(32); else DAM_HEAD_PIXEL(64);
+#undef DAM_HEAD_PIXEL
     DAM_CHECK_LAUNCH();
     const int Q = C / 4;
     int R = 256 / Q; if (R < 1) R = 1;
