@@ -14,7 +14,7 @@ struct PatchGeo {
 };
 
 // Stages rows ih0 .. ih0+PR-1, channels [chunk0*16, (chunk0+nch)*16) of image `ximg` into
-// smem as [chunk][row][slot][16 floats]; nch is a power of two; everything outside the tensor
+// smem as [chunk][row][slot][16 floats] (powers of two for nch index by shifts, others by division); everything outside the tensor
 // (spatially or beyond C) is zero.  Called by all 256 threads of the workgroup.
 // Loads are issued in batches of STAGE_U per thread before any of them is consumed, so a workgroup exposes
 // one or two HBM latencies per patch instead of one per item.
@@ -34,6 +34,8 @@ __device__ __forceinline__ void stage_patch(unsigned char* smem, int chunk_bytes
     if (!g.in_nchw) {
         const int qpp = nch * 4;                        // float4 quads per pixel
         const int qshift = 31 - __builtin_clz(qpp);
+        const bool qp2 = (qpp & (qpp - 1)) == 0;        // three chunks per tile (48 channels): quad index by division
+        const float inv_qpp = 1.0f / (float)qpp;
         const int ipr = g.PWin * qpp;                   // items per patch row
         const float inv_ipr = 1.0f / (float)ipr;
         const int total = g.PR * ipr;
@@ -50,7 +52,7 @@ __device__ __forceinline__ void stage_patch(unsigned char* smem, int chunk_bytes
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 dst[u] = -1;
                 if (e < total) {
-                    const int pw = rem >> qshift, cq = rem & (qpp - 1);
+                    const int pw = qp2 ? rem >> qshift : fast_div(rem, qpp, inv_qpp), cq = rem - pw * qpp;
                     const int ih = ih0 + pr, iw = g.c0 + pw;
                     const int slot = g.s == 1 ? pw : (pw & 1) * g.PWs + (pw >> 1);
                     dst[u] = (cq >> 2) * chunk_bytes + ((pr * g.PWT + slot) * 16 + (cq & 3) * 4) * 4;
@@ -71,7 +73,8 @@ __device__ __forceinline__ void stage_patch(unsigned char* smem, int chunk_bytes
                     d = -2 - d;
                 } else if (in_scale) {
                     const int e = base + 256 * u;
-                    const int cq = (e - fast_div(e, ipr, inv_ipr) * ipr) & (qpp - 1);
+                    const int r_ = e - fast_div(e, ipr, inv_ipr) * ipr;
+                    const int cq = qp2 ? r_ & (qpp - 1) : r_ - fast_div(r_, qpp, inv_qpp) * qpp;
                     const float4 sc = *reinterpret_cast<const float4*>(in_scale + ch0 + cq * 4);
                     const float4 sh = *reinterpret_cast<const float4*>(in_shift + ch0 + cq * 4);
                     x.x = fmaf(x.x, sc.x, sh.x); x.y = fmaf(x.y, sc.y, sh.y);

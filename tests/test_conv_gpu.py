@@ -41,6 +41,7 @@ CASES = [  # B, Cin, Cout, H, W, k, stride, pad, dil, bias
     (1, 48, 64, 40, 33, 7, 1, 0, 1, True),
     (1, 64, 128, 30, 25, 9, 1, 0, 1, True),
     (2, 16, 32, 45, 31, 5, 1, 0, 1, True),
+    (2, 32, 48, 45, 31, 5, 1, 0, 1, True),        # 48 output channels: the three-block weight-gradient tile
     (1, 16, 16, 40, 216, 3, 1, 1, 1, False),     # the reference's native 216-frame rows: wide-row strip loader
     (1, 32, 32, 30, 108, 3, 1, 1, 1, False),
     (2, 16, 32, 21, 130, 3, 2, 1, 1, True),      # too wide for the loader-wave kernel's patch buffers: two column ranges
