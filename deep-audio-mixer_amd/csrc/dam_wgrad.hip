@@ -1390,13 +1390,13 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     g.nchunks = in_nchw ? 1 : C / 16;
     g.nblk = n_chan / 16;
     g.in_nchw = in_nchw; g.relu_in = relu_in;
-    // tile choice: 2x2 channel blocks when both sides have them and LDS allows two workgroups per CU.  48 channels (three blocks: the
-    // scalar models' 5x5 / 32 -> 48 and 7x7 / 48 -> 64 layers) take a three-block tile on that side instead of two tiles of two with
-    // the fourth block empty (a quarter of the MFMAs on zeros: 463 / 167 us, 0.40 / 0.32 of peak); DAM_WG_NO_T3 keeps 2x2 (A/B).
+    // tile choice: 2x2 channel blocks when both sides have them and LDS allows two workgroups per CU.  48 OUTPUT channels (three blocks:
+    // the scalar models' 5x5 / 32 -> 48 layer) take a three-block tile on that side instead of two tiles of two with the fourth block
+    // empty (a quarter of the MFMAs on zeros): 167 -> 115 us; DAM_WG_NO_T3 keeps 2x2 (A/B).  The same on the INPUT side (7x7 / 48 -> 64
+    // as a 1x3 tile) measured 476 us against 463: 22 LDS reads per 21 MFMAs; a 2x3 tile needs 273 VGPRs.  Not instantiated.
     static const bool no_t3 = getenv("DAM_WG_NO_T3") != nullptr;
     int tnb = 2, tkb = 2;
-    if (!no_t3 && kh == 7 && kw == 7 && g.nchunks == 3) { tnb = 1; tkb = 3; }
-    else if (!no_t3 && kh == 5 && kw == 5 && g.nblk == 3 && g.nchunks % 2 == 0) { tnb = 3; tkb = 2; }
+    if (!no_t3 && kh == 5 && kw == 5 && g.nblk == 3 && g.nchunks % 2 == 0) { tnb = 3; tkb = 2; }
     bool small = g.nchunks == 1 || g.nblk == 1;
     set_tile(256);
     if (!small && lds_bytes(tnb, tkb) > 72 * 1024) {
@@ -1415,7 +1415,7 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     if (kw == 3 && kh == 3) { if (small) DAM_WG(1, 1, 3, 3); else DAM_WG(2, 2, 3, 3); }
     if (kw == 1 && kh == 1) { if (small) DAM_WG(1, 1, 1, 1); else DAM_WG(2, 2, 1, 1); }
     if (kw == 5) { if (small) DAM_WG(1, 1, 1, 5); else if (tnb == 3) DAM_WG(3, 2, 1, 5); else DAM_WG(2, 2, 1, 5); }
-    if (kw == 7) { if (small) DAM_WG(1, 1, 1, 7); else if (tkb == 3) DAM_WG(1, 3, 1, 7); else DAM_WG(2, 2, 1, 7); }
+    if (kw == 7) { if (small) DAM_WG(1, 1, 1, 7); else DAM_WG(2, 2, 1, 7); }
     if (kw == 9) { if (small) DAM_WG(1, 1, 1, 9); else DAM_WG(2, 2, 1, 9); }
 #undef DAM_WG
     return DAM_ERR_UNSUPPORTED;
