@@ -36,12 +36,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv_s2_pair_kernel(const float* _
     static_assert(NCH == 1 || NCH == 2, "the operand sets alternate per chunk (NCH == 2) or per unit (NCH == 1)");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    {
-        constexpr int N4 = 9 * NCH * NB * 64, N4P = NCH * NB * 64;
-        for (int e = tid; e < N4; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[e] = Wp[e];
-        for (int e = tid; e < N4P; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[N4 + e] = Wp2[e];
-    }
-    __syncthreads();
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
     const int w_lane = lane * 16;
     float4 xs[2][9], wa[2][NB];
@@ -153,6 +147,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv_s2_pair_kernel(const float* _
     int base0, fl0, base1, fl1;
     DAM_CS2_OFFS(unit, base0, fl0);
     DAM_CS2_LOAD(0, base0, fl0, 0)
+    // (the weight images go to LDS BEHIND the first unit's operand requests: their round trips overlap)
+    {
+        constexpr int N4 = 9 * NCH * NB * 64, N4P = NCH * NB * 64;
+        for (int e = tid; e < N4; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[e] = Wp[e];
+        for (int e = tid; e < N4P; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[N4 + e] = Wp2[e];
+    }
+    __syncthreads();
     while (unit < unit_end) {                                            // wave-uniform
         if constexpr (NCH == 2) {
             DAM_CS2_LOAD(1, base0, fl0, 1)

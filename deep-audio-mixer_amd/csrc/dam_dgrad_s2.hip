@@ -47,13 +47,6 @@ __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __res
     constexpr int Co = 16 * NCH, Ci = 16 * NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    {   // the weight image: one pass, all loads of a thread in flight
-        constexpr int N4 = 9 * NCH * NB * 64, N4P = PAIR ? NCH * NB * 64 : 0;
-        for (int e = tid; e < N4; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[e] = Wp[e];
-        if constexpr (PAIR)
-            for (int e = tid; e < N4P; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[N4 + e] = Wp2[e];
-    }
-    __syncthreads();
     const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DC), 0, (unsigned)((size_t)B * Hd * Wd * Co * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAIR ? DS : DC), 0, (unsigned)((size_t)B * Hd * Wd * Co * 4), 0x00020000);
     const int w_lane = lane * 16;
@@ -137,6 +130,14 @@ __global__ __launch_bounds__(64 * WAVES) void dgrad_s2_kernel(const float* __res
     int unit = u_lo + wave * wg_per_xcd + blockIdx.x / n_xcd;
     DAM_S2_OFFSETS(unit, o00, o01, o10, o11);
     DAM_S2_LOAD(0, o00, o01, o10, o11, 0)
+    // (the weight image goes to LDS BEHIND the first unit's operand requests: their round trips overlap)
+    {   // the weight image: one pass, all loads of a thread in flight
+        constexpr int N4 = 9 * NCH * NB * 64, N4P = PAIR ? NCH * NB * 64 : 0;
+        for (int e = tid; e < N4; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[e] = Wp[e];
+        if constexpr (PAIR)
+            for (int e = tid; e < N4P; e += 64 * WAVES) reinterpret_cast<float4*>(smem)[N4 + e] = Wp2[e];
+    }
+    __syncthreads();
     while (unit < unit_end) {
         v4f acc[4][MB][NB];                 // class (p, q) = 2 p + q
 #pragma unroll
