@@ -320,6 +320,145 @@ int launch_conv_s2_pair(const float* x, const float* wp, const float* wp2, int B
     return DAM_OK;
 }
 
+
+// ---- the wide down-sampling blocks (64 -> 96 ... 128 -> 256 channels): the two weight images (240 KB ... 1.3 MB) do not fit a
+// workgroup's LDS and the outputs are small (<= 17 k pixels).  As in dam_dgrad_s2.hip's streaming form a wave takes exactly ONE unit --
+// 16 flattened output pixels x ONE 16-channel block of both outputs -- and its ten weight fragments per 16-channel chunk of x go
+// straight from L2 into the MFMA's A operand; two register sets keep the next chunk's nineteen loads in flight under the current
+// chunk's 40 MFMAs.  The four waves of a workgroup take four consecutive pixel blocks of the SAME channel block (their weight
+// loads are the same lines: L1), so their statistics merge through LDS into the workgroup's 16 channels of record blockIdx.x / NB:
+// the NB workgroups of a pixel group fill one record between them.
+template <bool STATS>
+__global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* __restrict__ X, unsigned x_bytes, const float4* __restrict__ Wp,
+                                                                  const float4* __restrict__ Wp2, int Hd, int Wd, int H, int W, int NCH,
+                                                                  int NB, float* __restrict__ Y, float* __restrict__ Ys,
+                                                                  float* __restrict__ P1, float* __restrict__ P2, int total_px) {
+    __shared__ float rec[4][2][16][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int nb = blockIdx.x % NB, pgroup = blockIdx.x / NB;
+    const int Ci = 16 * NCH, Co = 16 * NB;
+    const int p = (pgroup * 4 + wave) * 16 + j;                       // this lane's output pixel (flattened [B * Hd * Wd])
+    const bool live = p < total_px;
+    const int row = p / Wd, col = p - row * Wd, img = row / Hd, i = row - img * Hd;
+    const int base = (((img * H + 2 * i) * W + 2 * col) * Ci + kq * 4) * 4;
+    const int fl = live ? (1 | (i > 0 ? 2 : 0) | (2 * i + 1 < H ? 4 : 0) | (col > 0 ? 8 : 0) | (2 * col + 1 < W ? 16 : 0)) : 0;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp), 0, (unsigned)((size_t)9 * NCH * NB * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp2), 0, (unsigned)((size_t)NCH * NB * 1024), 0x00020000);
+    int off[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int need = 1 | (a == 0 ? 2 : a == 2 ? 4 : 0) | (b == 0 ? 8 : b == 2 ? 16 : 0);
+            off[a * 3 + b] = (fl & need) == need ? base + ((a - 1) * W + (b - 1)) * (Ci * 4) : 0x7fffffff;
+        }
+    float4 xs[2][9], wt[2][10];
+    // (the chunk rides in the scalar offset, which the range check ignores: the callers keep CH_ < NCH)
+#define DAM_CS2S_LOAD(S_, CH_)                                                                                                \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                       \
+            xs[S_][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off[t], (CH_) * 64, 0));         \
+            wt[S_][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16, ((t * NCH + (CH_)) * NB + nb) * 1024, 0)); \
+        }                                                                                                                     \
+        wt[S_][9] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w2r, lane * 16, ((CH_) * NB + nb) * 1024, 0)); \
+    } while (0)
+#define DAM_CS2S_CHUNK(S_)                                                                                                    \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                       \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][t].x, xs[S_][t].x, acc1, 0, 0, 0);                             \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][t].y, xs[S_][t].y, acc1, 0, 0, 0);                             \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][t].z, xs[S_][t].z, acc1, 0, 0, 0);                             \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][t].w, xs[S_][t].w, acc1, 0, 0, 0);                             \
+        }                                                                                                                     \
+        accs = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][9].x, xs[S_][4].x, accs, 0, 0, 0);                                 \
+        accs = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][9].y, xs[S_][4].y, accs, 0, 0, 0);                                 \
+        accs = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][9].z, xs[S_][4].z, accs, 0, 0, 0);                                 \
+        accs = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][9].w, xs[S_][4].w, accs, 0, 0, 0);                                 \
+    } while (0)
+    v4f acc1 = (v4f){0.f, 0.f, 0.f, 0.f}, accs = (v4f){0.f, 0.f, 0.f, 0.f};
+    DAM_CS2S_LOAD(0, 0);
+    for (int c = 0; c < NCH; c += 2) {                                   // NCH is even (the entry point checks)
+        DAM_CS2S_LOAD(1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        DAM_CS2S_CHUNK(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) DAM_CS2S_LOAD(0, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        DAM_CS2S_CHUNK(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef DAM_CS2S_LOAD
+#undef DAM_CS2S_CHUNK
+    if (live) {
+        *reinterpret_cast<v4f*>(Y + (size_t)p * Co + nb * 16 + kq * 4) = acc1;
+        *reinterpret_cast<v4f*>(Ys + (size_t)p * Co + nb * 16 + kq * 4) = accs;
+    }
+    if constexpr (STATS) {
+        // one value per lane and channel: the wave's (n, mean, M2) by two shuffle sums over its sixteen pixel lanes (mean first, then
+        // the squared deviations from it), the four waves merged by Chan through LDS
+        float cnt = live ? 1.f : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) cnt += __shfl_xor(cnt, o);
+        const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+        float mean[2][4], m2[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float s1 = live ? acc1[q] : 0.f, s2 = live ? accs[q] : 0.f;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            mean[0][q] = s1 * inv; mean[1][q] = s2 * inv;
+            float d1 = live ? acc1[q] - mean[0][q] : 0.f, d2 = live ? accs[q] - mean[1][q] : 0.f;
+            d1 *= d1; d2 *= d2;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+            m2[0][q] = d1; m2[1][q] = d2;
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rec[wave][0][kq * 4 + q][0] = cnt; rec[wave][0][kq * 4 + q][1] = mean[0][q]; rec[wave][0][kq * 4 + q][2] = m2[0][q];
+                rec[wave][1][kq * 4 + q][0] = cnt; rec[wave][1][kq * 4 + q][1] = mean[1][q]; rec[wave][1][kq * 4 + q][2] = m2[1][q];
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, c = tid & 15;
+            float n = 0.f, mu = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float nw = rec[w][which][c][0], nn = n + nw, rr = nn > 0.f ? nw / nn : 0.f, d = rec[w][which][c][1] - mu;
+                mu = fmaf(d, rr, mu);
+                q2 += rec[w][which][c][2] + d * d * (n * rr);
+                n = nn;
+            }
+            float* o = (which ? P2 : P1) + ((size_t)pgroup * Co + nb * 16 + c) * 3;
+            o[0] = n; o[1] = mu; o[2] = q2;
+        }
+    }
+}
+
+int launch_conv_s2_pair_stream(const float* x, const float* wp, const float* wp2, int B, int H, int W, int Ci, int Co, float* y, float* ys,
+                               float* p1, float* p2, int* parts_host, hipStream_t st) {
+    const int Hd = (H + 1) / 2, Wd = (W + 1) / 2, NCH = Ci / 16, NB = Co / 16;
+    const int64_t px = (int64_t)B * Hd * Wd, xb = (int64_t)B * H * W * Ci * 4;
+    const int64_t groups = cdiv(px, 64);
+    if (px >= (1ll << 26) || xb >= (1ll << 31) || groups * NB >= (1ll << 31) || (int64_t)9 * Ci * Co * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;
+    const bool stats = p1 != nullptr;
+    if (stats && groups > BN_RECORDS_MAX) return DAM_ERR_UNSUPPORTED;      // (one record per group of 64 pixels)
+    if (parts_host) *parts_host = stats ? (int)groups : 0;
+    const dim3 grid((unsigned)(groups * NB)), block(256);
+    if (stats)
+        hipLaunchKernelGGL(conv_s2_pair_stream_kernel<true>, grid, block, 0, st, x, (unsigned)xb, reinterpret_cast<const float4*>(wp),
+                           reinterpret_cast<const float4*>(wp2), Hd, Wd, H, W, NCH, NB, y, ys, p1, p2, (int)px);
+    else
+        hipLaunchKernelGGL(conv_s2_pair_stream_kernel<false>, grid, block, 0, st, x, (unsigned)xb, reinterpret_cast<const float4*>(wp),
+                           reinterpret_cast<const float4*>(wp2), Hd, Wd, H, W, NCH, NB, y, ys, p1, p2, (int)px);
+    DAM_CHECK_LAUNCH();
+    return DAM_OK;
+}
+
 }  // namespace
 }  // namespace dam
 
@@ -336,5 +475,9 @@ extern "C" int dam_conv_s2_pair_fwd_f32(const float* x, const float* w_packed, c
     static const int w4 = [] { const char* e = getenv("DAM_CS2_WAVES4"); return e ? atoi(e) : 0; }();          // A/B knob
     if (Ci == 32 && Co == 64 && w4) return launch_conv_s2_pair<4, 2, 4>(x, w_packed, wsc_packed, B, H, W, y, ysc, partial, partial_sc, parts_host, st);
     if (Ci == 32 && Co == 64) return launch_conv_s2_pair<4, 2, 8>(x, w_packed, wsc_packed, B, H, W, y, ysc, partial, partial_sc, parts_host, st);
+    // the wide blocks: weight fragments streamed from L2 (an even chunk count: the two register sets alternate)
+    static const int no_stream = getenv("DAM_CS2_NO_STREAM") ? 1 : 0;        // A/B knob
+    if (!no_stream && Ci % 32 == 0 && Co % 16 == 0)
+        return launch_conv_s2_pair_stream(x, w_packed, wsc_packed, B, H, W, Ci, Co, y, ysc, partial, partial_sc, parts_host, st);
     return DAM_ERR_UNSUPPORTED;
 }

@@ -190,8 +190,10 @@ int dam_dgrad_s2_3x3_f32(const float* dy, const float* w_packed_t, const float* 
  * training-mode BatchNorm).  x: NHWC [B][H][W][Ci]; w_packed / wsc_packed: dam_conv_pack_weights_f32 images with transpose = 0;
  * y, ysc: NHWC [B][(H+1)/2][(W+1)/2][Co].  partial / partial_sc (both or neither; >= dam_bn_workspace_floats(Co) floats each):
  * records [*parts_host][Co][3] = (n, mean, M2), one per workgroup, for dam_bn_finalize_pair_f32 / dam_bn_finalize_f32 /
- * dam_bn_finalize_apply_f32.  Taken: Ci = 16 -> Co = 32 and Ci = 32 -> Co = 64 (both weight images resident in LDS);
- * DAM_ERR_UNSUPPORTED otherwise: the caller runs dam_conv2d_tapgrid_f32 twice and dam_bn_stats_pair_f32. */
+ * dam_bn_finalize_apply_f32.  Ci = 16 -> Co = 32 and Ci = 32 -> Co = 64 keep both weight images resident in LDS (one record per
+ * workgroup); other layers with Ci % 32 == 0 and Co % 16 == 0 stream the weight fragments from L2 (one (16 pixels, 16 channels) unit
+ * per wave, one record per 64 pixels); DAM_ERR_UNSUPPORTED otherwise: the caller runs dam_conv2d_tapgrid_f32 twice and
+ * dam_bn_stats_pair_f32. */
 int dam_conv_s2_pair_fwd_f32(const float* x, const float* w_packed, const float* wsc_packed, int B, int H, int W, int Ci, int Co,
                              float* y, float* ysc, float* partial, float* partial_sc, int* parts_host, void* stream);
 

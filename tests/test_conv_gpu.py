@@ -588,7 +588,10 @@ def test_strided_dgrad_one_launch(ops, monkeypatch, B, Ci, Co, H, W, pair):
 
 
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 16, 32, 41, 27), (2, 16, 32, 40, 28), (8, 16, 32, 1025, 130), (8, 32, 64, 513, 65),
-                                          (1, 32, 64, 34, 17), (1, 16, 32, 3, 3), (2, 16, 32, 21, 131), (1, 32, 64, 2, 2)])
+                                          (1, 32, 64, 34, 17), (1, 16, 32, 3, 3), (2, 16, 32, 21, 131), (1, 32, 64, 2, 2),
+                                          # the wide blocks (weights streamed from L2): the ResNet's layer4.0 / 5.0 / 6.0, ragged
+                                          (8, 64, 96, 257, 33), (8, 96, 128, 129, 17), (8, 128, 256, 65, 9), (1, 64, 96, 7, 5),
+                                          (3, 32, 48, 19, 23)])
 def test_downsampling_pair_forward_one_launch(ops, B, Ci, Co, H, W):
     """dam_conv_s2_pair_fwd_f32: a down-sampling block's conv1 (3x3 / stride 2 / pad 1) and its 1x1 / stride-2 shortcut convolution
     from one read of x, with the BatchNorm statistics records of both outputs -- against torch's conv2d in float64, odd and even
