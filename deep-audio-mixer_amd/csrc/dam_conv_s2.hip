@@ -323,11 +323,11 @@ int launch_conv_s2_pair(const float* x, const float* wp, const float* wp2, int B
 
 // ---- the wide down-sampling blocks (64 -> 96 ... 128 -> 256 channels): the two weight images (240 KB ... 1.3 MB) do not fit a
 // workgroup's LDS and the outputs are small (<= 17 k pixels).  As in dam_dgrad_s2.hip's streaming form a wave takes exactly ONE unit --
-// 16 flattened output pixels x ONE 16-channel block of both outputs -- and its ten weight fragments per 16-channel chunk of x go
-// straight from L2 into the MFMA's A operand; two register sets keep the next chunk's nineteen loads in flight under the current
-// chunk's 40 MFMAs.  The four waves of a workgroup take four consecutive pixel blocks of the SAME channel block (their weight
-// loads are the same lines: L1), so their statistics merge through LDS into the workgroup's 16 channels of record blockIdx.x / NB:
-// the NB workgroups of a pixel group fill one record between them.
+// 16 flattened output pixels x ONE 16-channel block of both outputs; two operand register sets keep the next chunk's nine loads in
+// flight under the current chunk's 40 MFMAs.  The four waves of a workgroup take four consecutive pixel blocks of the SAME channel
+// block: the ten weight fragments of a chunk are fetched once per workgroup into LDS (two chunk buffers, one barrier per chunk), and
+// the waves' statistics merge through LDS into the workgroup's 16 channels of record blockIdx.x / NB: the NB workgroups of a pixel
+// group fill one record between them.
 template <bool STATS>
 __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* __restrict__ X, unsigned x_bytes, const float4* __restrict__ Wp,
                                                                   const float4* __restrict__ Wp2, int Hd, int Wd, int H, int W, int NCH,
@@ -344,8 +344,6 @@ __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* _
     const int base = (((img * H + 2 * i) * W + 2 * col) * Ci + kq * 4) * 4;
     const int fl = live ? (1 | (i > 0 ? 2 : 0) | (2 * i + 1 < H ? 4 : 0) | (col > 0 ? 8 : 0) | (2 * col + 1 < W ? 16 : 0)) : 0;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp), 0, (unsigned)((size_t)9 * NCH * NB * 1024), 0x00020000);
-    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(Wp2), 0, (unsigned)((size_t)NCH * NB * 1024), 0x00020000);
     int off[9];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -354,42 +352,78 @@ __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* _
             const int need = 1 | (a == 0 ? 2 : a == 2 ? 4 : 0) | (b == 0 ? 8 : b == 2 ? 16 : 0);
             off[a * 3 + b] = (fl & need) == need ? base + ((a - 1) * W + (b - 1)) * (Ci * 4) : 0x7fffffff;
         }
-    float4 xs[2][9], wt[2][10];
-    // (the chunk rides in the scalar offset, which the range check ignores: the callers keep CH_ < NCH)
-#define DAM_CS2S_LOAD(S_, CH_)                                                                                                \
+    // The ten weight fragments of a chunk are the same for the four waves (one channel block per workgroup): each wave fetches a
+    // quarter of them (640 quads over 256 threads) and they meet in LDS, two chunk buffers, one barrier per chunk -- every wave
+    // loading all ten itself kept a CU's texture path ~90 % busy (nineteen 1 KB loads per 40 MFMAs).
+    __shared__ float4 wbuf[2][10 * 64];
+    float4 xs[2][9], wa[2], wr0, wr1, wr2;
+    const int we0 = tid, we1 = tid + 256, we2 = tid < 128 ? tid + 512 : 0;      // this thread's quads of a chunk's 640
+    // weight quad e of chunk CH_: e < 576 -> tap e / 64 of the 3x3 image, else the shortcut's
+#define DAM_CS2S_WSRC(E_, CH_)                                                                                               \
+    ((E_) < 576 ? Wp + ((size_t)(((E_) >> 6) * NCH + (CH_)) * NB + nb) * 64 + ((E_) & 63)                                     \
+                : Wp2 + ((size_t)(CH_) * NB + nb) * 64 + ((E_) & 63))
+#define DAM_CS2S_WFETCH(CH_)                                                                                                  \
     do {                                                                                                                      \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                       \
-            xs[S_][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off[t], (CH_) * 64, 0));         \
-            wt[S_][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16, ((t * NCH + (CH_)) * NB + nb) * 1024, 0)); \
-        }                                                                                                                     \
-        wt[S_][9] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w2r, lane * 16, ((CH_) * NB + nb) * 1024, 0)); \
+        wr0 = *DAM_CS2S_WSRC(we0, CH_); wr1 = *DAM_CS2S_WSRC(we1, CH_); wr2 = *DAM_CS2S_WSRC(we2, CH_);                       \
     } while (0)
-#define DAM_CS2S_CHUNK(S_)                                                                                                    \
+#define DAM_CS2S_WSTORE(BUF_)                                                                                                 \
     do {                                                                                                                      \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                       \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][t].x, xs[S_][t].x, acc1, 0, 0, 0);                             \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][t].y, xs[S_][t].y, acc1, 0, 0, 0);                             \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][t].z, xs[S_][t].z, acc1, 0, 0, 0);                             \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][t].w, xs[S_][t].w, acc1, 0, 0, 0);                             \
+        wbuf[BUF_][we0] = wr0; wbuf[BUF_][we1] = wr1;                                                                         \
+        if (tid < 128) wbuf[BUF_][we2] = wr2;                                                                                 \
+    } while (0)
+    // (the chunk rides in the scalar offset, which the range check ignores: the callers keep CH_ < NCH)
+#define DAM_CS2S_XLOAD(S_, CH_)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                                             \
+        xs[S_][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off[t], (CH_) * 64, 0));
+    // the MFMAs of one chunk: tap t's fragment is read from LDS one tap ahead of its use (tap 9 = the shortcut's)
+#define DAM_CS2S_CHUNK(S_, BUF_)                                                                                              \
+    do {                                                                                                                      \
+        wa[0] = wbuf[BUF_][lane];                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < 10; ++t) {                                                                      \
+            if (t < 9) wa[(t + 1) & 1] = wbuf[BUF_][(t + 1) * 64 + lane];                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
+            const float4 w_ = wa[t & 1], x_ = xs[S_][t < 9 ? t : 4];                                                          \
+            if (t < 9) {                                                                                                      \
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.x, x_.x, acc1, 0, 0, 0);                                       \
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.y, x_.y, acc1, 0, 0, 0);                                       \
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.z, x_.z, acc1, 0, 0, 0);                                       \
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.w, x_.w, acc1, 0, 0, 0);                                       \
+            } else {                                                                                                          \
+                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.x, x_.x, accs, 0, 0, 0);                                       \
+                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.y, x_.y, accs, 0, 0, 0);                                       \
+                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.z, x_.z, accs, 0, 0, 0);                                       \
+                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.w, x_.w, accs, 0, 0, 0);                                       \
+            }                                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
-        accs = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][9].x, xs[S_][4].x, accs, 0, 0, 0);                                 \
-        accs = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][9].y, xs[S_][4].y, accs, 0, 0, 0);                                 \
-        accs = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][9].z, xs[S_][4].z, accs, 0, 0, 0);                                 \
-        accs = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[S_][9].w, xs[S_][4].w, accs, 0, 0, 0);                                 \
     } while (0)
     v4f acc1 = (v4f){0.f, 0.f, 0.f, 0.f}, accs = (v4f){0.f, 0.f, 0.f, 0.f};
-    DAM_CS2S_LOAD(0, 0);
+    DAM_CS2S_XLOAD(0, 0)
+    DAM_CS2S_WFETCH(0);
+    DAM_CS2S_WSTORE(0);
+    __syncthreads();
     for (int c = 0; c < NCH; c += 2) {                                   // NCH is even (the entry point checks)
-        DAM_CS2S_LOAD(1, c + 1);
+        DAM_CS2S_XLOAD(1, c + 1)
+        DAM_CS2S_WFETCH(c + 1);
         __builtin_amdgcn_sched_barrier(0);
-        DAM_CS2S_CHUNK(0);
+        DAM_CS2S_CHUNK(0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < NCH) DAM_CS2S_LOAD(0, c + 2);
+        DAM_CS2S_WSTORE(1);
+        __syncthreads();
+        if (c + 2 < NCH) {
+            DAM_CS2S_XLOAD(0, c + 2)
+            DAM_CS2S_WFETCH(c + 2);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        DAM_CS2S_CHUNK(1);
+        DAM_CS2S_CHUNK(1, 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) { DAM_CS2S_WSTORE(0); }
+        __syncthreads();
     }
-#undef DAM_CS2S_LOAD
+#undef DAM_CS2S_WSRC
+#undef DAM_CS2S_WFETCH
+#undef DAM_CS2S_WSTORE
+#undef DAM_CS2S_XLOAD
 #undef DAM_CS2S_CHUNK
     if (live) {
         *reinterpret_cast<v4f*>(Y + (size_t)p * Co + nb * 16 + kq * 4) = acc1;
