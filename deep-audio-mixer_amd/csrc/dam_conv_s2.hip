@@ -328,7 +328,8 @@ int launch_conv_s2_pair(const float* x, const float* wp, const float* wp2, int B
 // block: the ten weight fragments of a chunk are fetched once per workgroup into LDS (two chunk buffers, one barrier per chunk), and
 // the waves' statistics merge through LDS into the workgroup's 16 channels of record blockIdx.x / NB: the NB workgroups of a pixel
 // group fill one record between them.
-template <bool STATS>
+// MB: pixel blocks of 16 per wave (1 is what ships; 2 = twice the MFMAs under every round of operand requests, measured slower)
+template <bool STATS, int MB>
 __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* __restrict__ X, unsigned x_bytes, const float4* __restrict__ Wp,
                                                                   const float4* __restrict__ Wp2, int Hd, int Wd, int H, int W, int NCH,
                                                                   int NB, float* __restrict__ Y, float* __restrict__ Ys,
@@ -338,25 +339,28 @@ __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* _
     const int j = lane & 15, kq = lane >> 4;
     const int nb = blockIdx.x % NB, pgroup = blockIdx.x / NB;
     const int Ci = 16 * NCH, Co = 16 * NB;
-    const int p = (pgroup * 4 + wave) * 16 + j;                       // this lane's output pixel (flattened [B * Hd * Wd])
-    const bool live = p < total_px;
-    const int row = p / Wd, col = p - row * Wd, img = row / Hd, i = row - img * Hd;
-    const int base = (((img * H + 2 * i) * W + 2 * col) * Ci + kq * 4) * 4;
-    const int fl = live ? (1 | (i > 0 ? 2 : 0) | (2 * i + 1 < H ? 4 : 0) | (col > 0 ? 8 : 0) | (2 * col + 1 < W ? 16 : 0)) : 0;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
-    int off[9];
+    int pix[MB], off[MB][9];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int mb = 0; mb < MB; ++mb) {
+        const int p = ((pgroup * 4 + wave) * MB + mb) * 16 + j;       // this lane's output pixels (flattened [B * Hd * Wd])
+        pix[mb] = p;
+        const int row = p / Wd, col = p - row * Wd, img = row / Hd, i = row - img * Hd;
+        const int base = (((img * H + 2 * i) * W + 2 * col) * Ci + kq * 4) * 4;
+        const int fl = p < total_px ? (1 | (i > 0 ? 2 : 0) | (2 * i + 1 < H ? 4 : 0) | (col > 0 ? 8 : 0) | (2 * col + 1 < W ? 16 : 0)) : 0;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int need = 1 | (a == 0 ? 2 : a == 2 ? 4 : 0) | (b == 0 ? 8 : b == 2 ? 16 : 0);
-            off[a * 3 + b] = (fl & need) == need ? base + ((a - 1) * W + (b - 1)) * (Ci * 4) : 0x7fffffff;
-        }
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int need = 1 | (a == 0 ? 2 : a == 2 ? 4 : 0) | (b == 0 ? 8 : b == 2 ? 16 : 0);
+                off[mb][a * 3 + b] = (fl & need) == need ? base + ((a - 1) * W + (b - 1)) * (Ci * 4) : 0x7fffffff;
+            }
+    }
     // The ten weight fragments of a chunk are the same for the four waves (one channel block per workgroup): each wave fetches a
     // quarter of them (640 quads over 256 threads) and they meet in LDS, two chunk buffers, one barrier per chunk -- every wave
     // loading all ten itself kept a CU's texture path ~90 % busy (nineteen 1 KB loads per 40 MFMAs).
     __shared__ float4 wbuf[2][10 * 64];
-    float4 xs[2][9], wa[2], wr0, wr1, wr2;
+    float4 xs[2][MB][9], wa[2], wr0, wr1, wr2;
     const int we0 = tid, we1 = tid + 256, we2 = tid < 128 ? tid + 512 : 0;      // this thread's quads of a chunk's 640
     // weight quad e of chunk CH_: e < 576 -> tap e / 64 of the 3x3 image, else the shortcut's
 #define DAM_CS2S_WSRC(E_, CH_)                                                                                               \
@@ -373,8 +377,9 @@ __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* _
     } while (0)
     // (the chunk rides in the scalar offset, which the range check ignores: the callers keep CH_ < NCH)
 #define DAM_CS2S_XLOAD(S_, CH_)                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                                             \
-        xs[S_][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off[t], (CH_) * 64, 0));
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                         \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                                         \
+            xs[S_][mb][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off[mb][t], (CH_) * 64, 0));
     // the MFMAs of one chunk: tap t's fragment is read from LDS one tap ahead of its use (tap 9 = the shortcut's)
 #define DAM_CS2S_CHUNK(S_, BUF_)                                                                                              \
     do {                                                                                                                      \
@@ -382,22 +387,27 @@ __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* _
         _Pragma("unroll") for (int t = 0; t < 10; ++t) {                                                                      \
             if (t < 9) wa[(t + 1) & 1] = wbuf[BUF_][(t + 1) * 64 + lane];                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
-            const float4 w_ = wa[t & 1], x_ = xs[S_][t < 9 ? t : 4];                                                          \
-            if (t < 9) {                                                                                                      \
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.x, x_.x, acc1, 0, 0, 0);                                       \
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.y, x_.y, acc1, 0, 0, 0);                                       \
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.z, x_.z, acc1, 0, 0, 0);                                       \
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.w, x_.w, acc1, 0, 0, 0);                                       \
-            } else {                                                                                                          \
-                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.x, x_.x, accs, 0, 0, 0);                                       \
-                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.y, x_.y, accs, 0, 0, 0);                                       \
-                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.z, x_.z, accs, 0, 0, 0);                                       \
-                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.w, x_.w, accs, 0, 0, 0);                                       \
+            const float4 w_ = wa[t & 1];                                                                                      \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                                               \
+                const float4 x_ = xs[S_][mb][t < 9 ? t : 4];                                                                  \
+                if (t < 9) {                                                                                                  \
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.x, x_.x, acc1[mb], 0, 0, 0);                           \
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.y, x_.y, acc1[mb], 0, 0, 0);                           \
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.z, x_.z, acc1[mb], 0, 0, 0);                           \
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.w, x_.w, acc1[mb], 0, 0, 0);                           \
+                } else {                                                                                                      \
+                    accs[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.x, x_.x, accs[mb], 0, 0, 0);                           \
+                    accs[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.y, x_.y, accs[mb], 0, 0, 0);                           \
+                    accs[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.z, x_.z, accs[mb], 0, 0, 0);                           \
+                    accs[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.w, x_.w, accs[mb], 0, 0, 0);                           \
+                }                                                                                                             \
             }                                                                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
     } while (0)
-    v4f acc1 = (v4f){0.f, 0.f, 0.f, 0.f}, accs = (v4f){0.f, 0.f, 0.f, 0.f};
+    v4f acc1[MB], accs[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) { acc1[mb] = (v4f){0.f, 0.f, 0.f, 0.f}; accs[mb] = (v4f){0.f, 0.f, 0.f, 0.f}; }
     DAM_CS2S_XLOAD(0, 0)
     DAM_CS2S_WFETCH(0);
     DAM_CS2S_WSTORE(0);
@@ -425,26 +435,38 @@ __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* _
 #undef DAM_CS2S_WSTORE
 #undef DAM_CS2S_XLOAD
 #undef DAM_CS2S_CHUNK
-    if (live) {
-        *reinterpret_cast<v4f*>(Y + (size_t)p * Co + nb * 16 + kq * 4) = acc1;
-        *reinterpret_cast<v4f*>(Ys + (size_t)p * Co + nb * 16 + kq * 4) = accs;
-    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+        if (pix[mb] < total_px) {
+            *reinterpret_cast<v4f*>(Y + (size_t)pix[mb] * Co + nb * 16 + kq * 4) = acc1[mb];
+            *reinterpret_cast<v4f*>(Ys + (size_t)pix[mb] * Co + nb * 16 + kq * 4) = accs[mb];
+        }
     if constexpr (STATS) {
-        // one value per lane and channel: the wave's (n, mean, M2) by two shuffle sums over its sixteen pixel lanes (mean first, then
-        // the squared deviations from it), the four waves merged by Chan through LDS
-        float cnt = live ? 1.f : 0.f;
+        // <= MB values per lane and channel: the wave's (n, mean, M2) by two shuffle sums over its sixteen pixel lanes (mean first,
+        // then the squared deviations from it), the four waves merged by Chan through LDS
+        float cnt = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) cnt += pix[mb] < total_px ? 1.f : 0.f;
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) cnt += __shfl_xor(cnt, o);
         const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
         float mean[2][4], m2[2][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float s1 = live ? acc1[q] : 0.f, s2 = live ? accs[q] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                if (pix[mb] < total_px) { s1 += acc1[mb][q]; s2 += accs[mb][q]; }
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
             mean[0][q] = s1 * inv; mean[1][q] = s2 * inv;
-            float d1 = live ? acc1[q] - mean[0][q] : 0.f, d2 = live ? accs[q] - mean[1][q] : 0.f;
-            d1 *= d1; d2 *= d2;
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                if (pix[mb] < total_px) {
+                    const float e1 = acc1[mb][q] - mean[0][q], e2 = accs[mb][q] - mean[1][q];
+                    d1 = fmaf(e1, e1, d1); d2 = fmaf(e2, e2, d2);
+                }
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
             m2[0][q] = d1; m2[1][q] = d2;
@@ -477,18 +499,22 @@ int launch_conv_s2_pair_stream(const float* x, const float* wp, const float* wp2
                                float* p1, float* p2, int* parts_host, hipStream_t st) {
     const int Hd = (H + 1) / 2, Wd = (W + 1) / 2, NCH = Ci / 16, NB = Co / 16;
     const int64_t px = (int64_t)B * Hd * Wd, xb = (int64_t)B * H * W * Ci * 4;
-    const int64_t groups = cdiv(px, 64);
+    // one pixel block per wave; two (DAM_CS2_STREAM_MB=2: A/B) measured slower on the one layer with the units for it: 48.9 us
+    // against 41.8 on the 64 -> 96 block (230 VGPRs: two waves per SIMD instead of three)
+    static const int mb_forced = [] { const char* e = getenv("DAM_CS2_STREAM_MB"); return e ? atoi(e) : 0; }();
+    const int mb = mb_forced == 2 ? 2 : 1;
+    const int64_t groups = cdiv(px, 64 * mb);
     if (px >= (1ll << 26) || xb >= (1ll << 31) || groups * NB >= (1ll << 31) || (int64_t)9 * Ci * Co * 4 >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;
     const bool stats = p1 != nullptr;
-    if (stats && groups > BN_RECORDS_MAX) return DAM_ERR_UNSUPPORTED;      // (one record per group of 64 pixels)
+    if (stats && groups > BN_RECORDS_MAX) return DAM_ERR_UNSUPPORTED;      // (one record per group of 64 * mb pixels)
     if (parts_host) *parts_host = stats ? (int)groups : 0;
     const dim3 grid((unsigned)(groups * NB)), block(256);
-    if (stats)
-        hipLaunchKernelGGL(conv_s2_pair_stream_kernel<true>, grid, block, 0, st, x, (unsigned)xb, reinterpret_cast<const float4*>(wp),
-                           reinterpret_cast<const float4*>(wp2), Hd, Wd, H, W, NCH, NB, y, ys, p1, p2, (int)px);
-    else
-        hipLaunchKernelGGL(conv_s2_pair_stream_kernel<false>, grid, block, 0, st, x, (unsigned)xb, reinterpret_cast<const float4*>(wp),
-                           reinterpret_cast<const float4*>(wp2), Hd, Wd, H, W, NCH, NB, y, ys, p1, p2, (int)px);
+#define DAM_CS2S_GO(ST_, MB_)                                                                                                   \
+    hipLaunchKernelGGL((conv_s2_pair_stream_kernel<ST_, MB_>), grid, block, 0, st, x, (unsigned)xb, reinterpret_cast<const float4*>(wp), \
+                       reinterpret_cast<const float4*>(wp2), Hd, Wd, H, W, NCH, NB, y, ys, p1, p2, (int)px)
+    if (stats) { if (mb == 2) DAM_CS2S_GO(true, 2); else DAM_CS2S_GO(true, 1); }
+    else { if (mb == 2) DAM_CS2S_GO(false, 2); else DAM_CS2S_GO(false, 1); }
+#undef DAM_CS2S_GO
     DAM_CHECK_LAUNCH();
     return DAM_OK;
 }
