@@ -426,6 +426,113 @@ __global__ __launch_bounds__(256) void dgrad_s2_stream_kernel(const float* __res
 #undef DAM_S2S_CHUNK
 }
 
+// The same with a chunk's weight fragments fetched ONCE per workgroup into LDS: the four waves of a workgroup take four consecutive
+// pixel blocks of the SAME channel block of dx, every wave fetches a quarter of the chunk's 9 (+ 1) x 64 quads, two chunk buffers, one
+// barrier per chunk (each wave loading all ten itself kept a CU's texture path ~75 % busy).  One pixel block per wave.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void dgrad_s2_stream_lds_kernel(const float* __restrict__ DC, const float4* __restrict__ Wp,
+                                                                  const float* __restrict__ DS, const float4* __restrict__ Wp2, int Hd,
+                                                                  int Wd, float* __restrict__ DX, int H, int W, int total_px, int NCH,
+                                                                  int NB) {
+    constexpr int NT = PAIR ? 10 : 9, NQ = NT * 64;
+    __shared__ float4 wbuf[2][NQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = blockIdx.x % NB, pg = (blockIdx.x / NB) * 4 + wave;
+    const int j = lane & 15, kq = lane >> 4;
+    const int Co = 16 * NCH, Ci = 16 * NB;
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DC), 0, (unsigned)((size_t)total_px * Co * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAIR ? DS : DC), 0, (unsigned)((size_t)total_px * Co * 4), 0x00020000);
+    const int p = pg * 16 + j;
+    const int row = p / Wd, col = p - row * Wd, img = row / Hd, i = row - img * Hd;
+    int ov[4];
+    {
+        const int base = (p * Co + kq * 4) * 4;
+        const bool c0 = p < total_px, c1 = c0 && col + 1 < Wd, row1 = i + 1 < Hd;
+        ov[0] = c0 ? base : 0x7fffffff;
+        ov[1] = c1 ? base + Co * 4 : 0x7fffffff;
+        ov[2] = (c0 && row1) ? base + Wd * Co * 4 : 0x7fffffff;
+        ov[3] = (c1 && row1) ? base + (Wd + 1) * Co * 4 : 0x7fffffff;
+    }
+    float4 xo[2][PAIR ? 5 : 4], wa[2], wr0, wr1, wr2;       // operands: 0 = dc[i][j], 1 = dc[i][j+1], 2 = dc[i+1][j], 3 = dc[i+1][j+1], 4 = ds[i][j]
+    const int we0 = tid, we1 = tid + 256, we2 = tid + 512 < NQ ? tid + 512 : 0;        // this thread's quads of a chunk
+#define DAM_S2L_WSRC(E_, CH_)                                                                                                \
+    ((E_) < 576 ? Wp + ((size_t)(((E_) >> 6) * NCH + (CH_)) * NB + nb) * 64 + ((E_) & 63)                                     \
+                : Wp2 + ((size_t)(CH_) * NB + nb) * 64 + ((E_) & 63))
+#define DAM_S2L_WFETCH(CH_)                                                                                                   \
+    do {                                                                                                                      \
+        wr0 = *DAM_S2L_WSRC(we0, CH_); wr1 = *DAM_S2L_WSRC(we1, CH_); wr2 = *DAM_S2L_WSRC(we2, CH_);                          \
+    } while (0)
+#define DAM_S2L_WSTORE(BUF_)                                                                                                  \
+    do {                                                                                                                      \
+        wbuf[BUF_][we0] = wr0; wbuf[BUF_][we1] = wr1;                                                                         \
+        if (tid + 512 < NQ) wbuf[BUF_][we2] = wr2;                                                                            \
+    } while (0)
+    // (the chunk rides in the scalar offset, which the range check ignores: the callers keep CH_ < NCH)
+#define DAM_S2L_XLOAD(S_, CH_)                                                                                                \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                                         \
+            xo[S_][v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr, ov[v], (CH_) * 64, 0));          \
+        if constexpr (PAIR) xo[S_][4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sr, ov[0], (CH_) * 64, 0)); \
+    } while (0)
+    // taps in issue order: {weight tap (9 = the shortcut's), output class 2 p + q, operand}; fragments read one tap ahead
+    constexpr int TAPS[10][3] = {{4, 0, 0}, {3, 1, 1}, {5, 1, 0}, {1, 2, 2}, {7, 2, 0}, {0, 3, 3}, {2, 3, 2}, {6, 3, 1}, {8, 3, 0}, {9, 0, 4}};
+#define DAM_S2L_CHUNK(S_, BUF_)                                                                                               \
+    do {                                                                                                                      \
+        wa[0] = wbuf[BUF_][TAPS[0][0] * 64 + lane];                                                                           \
+        _Pragma("unroll") for (int s = 0; s < NT; ++s) {                                                                      \
+            if (s + 1 < NT) wa[(s + 1) & 1] = wbuf[BUF_][TAPS[s + 1 < NT ? s + 1 : 0][0] * 64 + lane];                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
+            const float4 w_ = wa[s & 1], x_ = xo[S_][TAPS[s][2]];                                                             \
+            v4f& a_ = acc[TAPS[s][1]];                                                                                        \
+            a_ = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.x, x_.x, a_, 0, 0, 0);                                               \
+            a_ = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.y, x_.y, a_, 0, 0, 0);                                               \
+            a_ = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.z, x_.z, a_, 0, 0, 0);                                               \
+            a_ = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.w, x_.w, a_, 0, 0, 0);                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
+        }                                                                                                                     \
+    } while (0)
+    v4f acc[4];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) acc[cl] = (v4f){0.f, 0.f, 0.f, 0.f};
+    DAM_S2L_XLOAD(0, 0);
+    DAM_S2L_WFETCH(0);
+    DAM_S2L_WSTORE(0);
+    __syncthreads();
+    for (int c = 0; c < NCH; c += 2) {                                 // NCH is even (the entry point checks)
+        DAM_S2L_XLOAD(1, c + 1);
+        DAM_S2L_WFETCH(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        DAM_S2L_CHUNK(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DAM_S2L_WSTORE(1);
+        __syncthreads();
+        if (c + 2 < NCH) {
+            DAM_S2L_XLOAD(0, c + 2);
+            DAM_S2L_WFETCH(c + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DAM_S2L_CHUNK(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) { DAM_S2L_WSTORE(0); }
+        __syncthreads();
+    }
+#undef DAM_S2L_WSRC
+#undef DAM_S2L_WFETCH
+#undef DAM_S2L_WSTORE
+#undef DAM_S2L_XLOAD
+#undef DAM_S2L_CHUNK
+    if (p < total_px) {
+        const bool orow1 = 2 * i + 1 < H, ocol1 = 2 * col + 1 < W;
+        float* o = DX + (((size_t)img * H + 2 * i) * W + 2 * col) * Ci + nb * 16 + kq * 4;
+        *reinterpret_cast<v4f*>(o) = acc[0];
+        if (ocol1) *reinterpret_cast<v4f*>(o + Ci) = acc[1];
+        if (orow1) {
+            *reinterpret_cast<v4f*>(o + (size_t)W * Ci) = acc[2];
+            if (ocol1) *reinterpret_cast<v4f*>(o + (size_t)W * Ci + Ci) = acc[3];
+        }
+    }
+}
+
 template <int MB>
 int launch_dgrad_s2_stream(const float* dc, const float* wpt, const float* ds, const float* wpt2, int B, int Hd, int Wd, int Co, int Ci,
                            float* dx, int H, int W, hipStream_t st) {
@@ -433,6 +540,18 @@ int launch_dgrad_s2_stream(const float* dc, const float* wpt, const float* ds, c
     const int NCH = Co / 16, NB = Ci / 16;
     const int64_t units = cdiv(px, 16 * MB) * NB;
     if (px >= (1ll << 26) || units >= (1ll << 30)) return DAM_ERR_UNSUPPORTED;
+    static const int no_lds = getenv("DAM_S2_STREAM_NO_LDS") ? 1 : 0;       // A/B knob: every wave loads all its weight fragments
+    if (MB == 1 && !no_lds) {
+        const dim3 grid_l((unsigned)(cdiv(px, 64) * NB)), block_l(256);
+        if (ds)
+            hipLaunchKernelGGL((dgrad_s2_stream_lds_kernel<true>), grid_l, block_l, 0, st, dc, reinterpret_cast<const float4*>(wpt), ds,
+                               reinterpret_cast<const float4*>(wpt2), Hd, Wd, dx, H, W, (int)px, NCH, NB);
+        else
+            hipLaunchKernelGGL((dgrad_s2_stream_lds_kernel<false>), grid_l, block_l, 0, st, dc, reinterpret_cast<const float4*>(wpt),
+                               (const float*)nullptr, (const float4*)nullptr, Hd, Wd, dx, H, W, (int)px, NCH, NB);
+        DAM_CHECK_LAUNCH();
+        return DAM_OK;
+    }
     const dim3 grid((unsigned)cdiv(units, 4)), block(256);
     if (ds)
         hipLaunchKernelGGL((dgrad_s2_stream_kernel<MB, true>), grid, block, 0, st, dc, reinterpret_cast<const float4*>(wpt), ds,
