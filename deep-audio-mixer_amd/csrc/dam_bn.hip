@@ -948,7 +948,8 @@ inline bool fa_enabled() {
 
 // records a partial pass may leave for a fused consumer: a workgroup's slice table stays <= 64 KB
 inline int fa_max_parts(int C, int rec_floats) {
-    int m = 65536 / (fa_cs(C) * rec_floats * 4);
+    static const int kb = [] { const char* e = getenv("DAM_BN_FA_PARTS_KB"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 80 ? v : 64; }();   // A/B knob
+    int m = kb * 1024 / (fa_cs(C) * rec_floats * 4);
     if (m > BN_MAX_PARTS) m = BN_MAX_PARTS;
     return m < 64 ? 64 : m;
 }
