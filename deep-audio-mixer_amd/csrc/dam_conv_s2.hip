@@ -337,7 +337,13 @@ __global__ __launch_bounds__(256) void conv_s2_pair_stream_kernel(const float* _
     __shared__ float rec[4][2][16][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    const int nb = blockIdx.x % NB, pgroup = blockIdx.x / NB;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch; every XCD has its own L2) and the NB workgroups of a
+    // pixel group read the same x -- dealt b -> (group, block) in plain order they sat on NB different XCDs and FETCH_SIZE was 6.8 x
+    // the bytes of x on the 64 -> 96 block.  Here the groups are dealt to the XCDs (group g on XCD g % 8) and an XCD's workgroups
+    // walk (group, block) pairs in order: the grid is padded to whole rounds of eight groups, the surplus workgroups leave.
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int nb = seq % NB, pgroup = (seq / NB) * 8 + xcd;
+    if (pgroup * (64 * MB) >= total_px) return;                       // (whole workgroup: no barrier is left waiting)
     const int Ci = 16 * NCH, Co = 16 * NB;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
     int pix[MB], off[MB][9];
@@ -508,7 +514,7 @@ int launch_conv_s2_pair_stream(const float* x, const float* wp, const float* wp2
     const bool stats = p1 != nullptr;
     if (stats && groups > BN_RECORDS_MAX) return DAM_ERR_UNSUPPORTED;      // (one record per group of 64 * mb pixels)
     if (parts_host) *parts_host = stats ? (int)groups : 0;
-    const dim3 grid((unsigned)(groups * NB)), block(256);
+    const dim3 grid((unsigned)(cdiv(groups, 8) * 8 * NB)), block(256);        // whole rounds of eight groups (one per XCD)
 #define DAM_CS2S_GO(ST_, MB_)                                                                                                   \
     hipLaunchKernelGGL((conv_s2_pair_stream_kernel<ST_, MB_>), grid, block, 0, st, x, (unsigned)xb, reinterpret_cast<const float4*>(wp), \
                        reinterpret_cast<const float4*>(wp2), Hd, Wd, H, W, NCH, NB, y, ys, p1, p2, (int)px)

@@ -437,7 +437,12 @@ __global__ __launch_bounds__(256) void dgrad_s2_stream_lds_kernel(const float* _
     constexpr int NT = PAIR ? 10 : 9, NQ = NT * 64;
     __shared__ float4 wbuf[2][NQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = blockIdx.x % NB, pg = (blockIdx.x / NB) * 4 + wave;
+    // XCD-aware order (as in dam_conv_s2.hip's streaming kernel): the NB workgroups of a 64-pixel group read the same dc / ds, so a
+    // group's workgroups stay on ONE XCD (group g on XCD g % 8; the grid is padded to whole rounds of eight groups)
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int nb = seq % NB, grp = (seq / NB) * 8 + xcd;
+    if (grp * 64 >= total_px) return;                                  // (whole workgroup: no barrier is left waiting)
+    const int pg = grp * 4 + wave;
     const int j = lane & 15, kq = lane >> 4;
     const int Co = 16 * NCH, Ci = 16 * NB;
     const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DC), 0, (unsigned)((size_t)total_px * Co * 4), 0x00020000);
@@ -542,7 +547,7 @@ int launch_dgrad_s2_stream(const float* dc, const float* wpt, const float* ds, c
     if (px >= (1ll << 26) || units >= (1ll << 30)) return DAM_ERR_UNSUPPORTED;
     static const int no_lds = getenv("DAM_S2_STREAM_NO_LDS") ? 1 : 0;       // A/B knob: every wave loads all its weight fragments
     if (MB == 1 && !no_lds) {
-        const dim3 grid_l((unsigned)(cdiv(px, 64) * NB)), block_l(256);
+        const dim3 grid_l((unsigned)(cdiv(cdiv(px, 64), 8) * 8 * NB)), block_l(256);      // whole rounds of eight groups (one per XCD)
         if (ds)
             hipLaunchKernelGGL((dgrad_s2_stream_lds_kernel<true>), grid_l, block_l, 0, st, dc, reinterpret_cast<const float4*>(wpt), ds,
                                reinterpret_cast<const float4*>(wpt2), Hd, Wd, dx, H, W, (int)px, NCH, NB);

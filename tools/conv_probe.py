@@ -81,15 +81,16 @@ elif which in ('layer2s2_wgrad', 'layer3s2_wgrad', 'layer4s2_wgrad', 'layer5s2_w
     x = torch.randn((B, hw[0], hw[1], ci), device=dev)
     dy = torch.randn((B, (hw[0] + 1) // 2, (hw[1] + 1) // 2, co), device=dev)
     fn = lambda: ops.conv2d_wgrad(x, dy, co, 3, 3, 2, 1, 1)
-elif which in ('l2s2_pair', 'l3s2_pair'):                              # a down-sampling block's conv1 + shortcut + statistics, one launch
-    hw, ci, co = {'l2s2_pair': ((1025, 130), 16, 32), 'l3s2_pair': ((513, 65), 32, 64)}[which]
+elif which in ('l2s2_pair', 'l3s2_pair', 'l4s2_pair', 'l5s2_pair', 'l6s2_pair'):                              # a down-sampling block's conv1 + shortcut + statistics, one launch
+    hw, ci, co = {'l2s2_pair': ((1025, 130), 16, 32), 'l3s2_pair': ((513, 65), 32, 64), 'l4s2_pair': ((257, 33), 64, 96),
+                  'l5s2_pair': ((129, 17), 96, 128), 'l6s2_pair': ((65, 9), 128, 256)}[which]
     x = torch.randn((B, hw[0], hw[1], ci), device=dev)
     wp = ops.pack_weights(torch.randn((co, ci, 3, 3), device=dev) * 0.05)
     wps = ops.pack_weights(torch.randn((co, ci, 1, 1), device=dev) * 0.05)
     fn = lambda: ops.conv_s2_pair_fwd(x, wp, wps, co)
-elif which in ('l2s2_dgrad', 'l3s2_dgrad', 'l4s2_dgrad', 'l6s2_dgrad'):    # its data gradient (conv1's four parity classes + the shortcut's tap)
+elif which in ('l2s2_dgrad', 'l3s2_dgrad', 'l4s2_dgrad', 'l5s2_dgrad', 'l6s2_dgrad'):    # its data gradient (conv1's four parity classes + the shortcut's tap)
     hw, ci, co = {'l2s2_dgrad': ((1025, 130), 16, 32), 'l3s2_dgrad': ((513, 65), 32, 64), 'l4s2_dgrad': ((257, 33), 64, 96),
-                  'l6s2_dgrad': ((65, 9), 128, 256)}[which]
+                  'l5s2_dgrad': ((129, 17), 96, 128), 'l6s2_dgrad': ((65, 9), 128, 256)}[which]
     hd, wd = (hw[0] + 1) // 2, (hw[1] + 1) // 2
     dy = torch.randn((B, hd, wd, co), device=dev)
     ds = torch.randn((B, hd, wd, co), device=dev)
