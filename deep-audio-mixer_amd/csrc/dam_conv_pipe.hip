@@ -100,7 +100,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
                                                                  const float* __restrict__ in_shift, float* __restrict__ Y,
                                                                  const float* __restrict__ res, const float* __restrict__ res_mask,
                                                                  float* __restrict__ stamps, float* __restrict__ stats,
-                                                                 const BnBwdEpi bwd, const int stats_acc) {
+                                                                 const BnBwdEpi bwd, const int stats_acc, const int xcd_aware) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,7 +114,16 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     const int stage_bytes = chunk_bytes * KS;
     const int nst = g.nchunks / KS;             // stages of a unit
     const int nby = g.N / 16 / NB;
-    const int G = gridDim.x;
+    // XCD-aware unit walk: workgroup b runs on XCD b % 8 and every XCD has its own L2.  Each XCD takes one CONTIGUOUS eighth of the
+    // units and its workgroups walk it side by side, so that neighbouring tiles (they share halo rows) and the channel-block groups
+    // of one tile meet in ONE L2 (plain stride walk: FETCH_SIZE 2.6 x the input on the 257 x 33 stage, 6 x on 33 x 5).
+    const bool xa = xcd_aware && (gridDim.x & 7) == 0;
+    const int G = xa ? (int)gridDim.x >> 3 : (int)gridDim.x;
+    const int per_xcd = xa ? (nunits + 7) >> 3 : nunits;
+    const int u_lo = xa ? (int)(blockIdx.x & 7) * per_xcd : 0;
+    const int unit_end = u_lo + per_xcd < nunits ? u_lo + per_xcd : nunits;
+    const int unit0 = u_lo + (xa ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    if (unit0 >= unit_end) return;                 // (the whole workgroup, in front of its first barrier)
     const size_t img_floats = (size_t)g.H * g.W * g.C;
 #ifdef DAM_PIPE_STAMPS
     unsigned long long* stamp_p = reinterpret_cast<unsigned long long*>(stamps) + (size_t)blockIdx.x * 128;
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         // check: no memory traffic), so the wait in front of a commit is the compile-time vmcnt(PIPE_U), not 0.
         const float relu_lo = g.relu_in ? 0.f : -__builtin_inff();
         float4 v[2][PIPE_U];
-        int unit = blockIdx.x;                                   // head of the stream: the next chunk to request
+        int unit = unit0;                                        // head of the stream: the next chunk to request
         PipeUnit cur = pipe_decode<UPX, NB>(g, unit, nby, inv_wo);
         int icg = 0;
         int rowb = (cur.oh_first * g.s + g.r0) * WC * 4;         // byte offset of patch row 0 in the image (negative above it)
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
         if (head) {                                         /* advance the head */                                         \
             if (icg + 1 < nst) {                                                                                           \
                 ++icg;                                                                                                     \
-            } else if (unit + G < nunits) {                                                                                \
+            } else if (unit + G < unit_end) {                                                                                \
                 unit += G;                                                                                                 \
                 cur = pipe_decode<UPX, NB>(g, unit, nby, inv_wo);                                                          \
                 icg = 0;                                                                                                   \
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     v4f acc[MB][NB];
     float4 wa[WSETS][NB], xv[3][MB];
     int base_b[MB];
-    int unit = blockIdx.x;
+    int unit = unit0;
     PipeUnit cur = pipe_decode<UPX, NB>(g, unit, nby, inv_wo);
     int sbuf = 0;
 #define DAM_PIPE_W(S_, CPART_, T_)                                                                                         \
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
     DAM_PIPE_BARRIER();                             // (1) the first chunk is staged
     DAM_PSTAMP(0, 5);
     for (;;) {
-        const bool has_next = unit + G < nunits;
+        const bool has_next = unit + G < unit_end;
         const PipeUnit nxt = has_next ? pipe_decode<UPX, NB>(g, unit + G, nby, inv_wo) : cur;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -653,9 +662,10 @@ int launch_pipe(const ConvGeo& g, size_t lds, const float* X, const float* Wp, c
     if (wgs < 1) wgs = 1;
     if (wgs > nunits) wgs = nunits;
     if (acc && stats_parts) *stats_parts = wgs;
+    static const int xcd_aware = getenv("DAM_PIPE_NO_XCD") ? 0 : 1;      // A/B knob
 #define DAM_PIPE_LAUNCH(S_)                                                                                                 \
     hipLaunchKernelGGL((conv_pipe_kernel<MB, NB, PU, S_, KS>), dim3((unsigned)wgs), dim3(PIPE_THREADS), lds, st, g, nunits, X,  \
-                       reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats, bwd, acc)
+                       reinterpret_cast<const float4*>(Wp), bias, sc, sh, Y, res, res_mask, workspace, stats, bwd, acc, xcd_aware)
     if (mode == 2) DAM_PIPE_LAUNCH(2); else if (mode == 1) DAM_PIPE_LAUNCH(1); else DAM_PIPE_LAUNCH(0);
 #undef DAM_PIPE_LAUNCH
     DAM_CHECK_LAUNCH();
