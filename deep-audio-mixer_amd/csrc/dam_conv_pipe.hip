@@ -12,7 +12,8 @@
 //     (which packed-weight block is next?) cost the pipe ~7 clocks per MFMA.
 // Here:
 //   * a workgroup = 4 compute waves + 4 LOADER waves (one per SIMD), and it is PERSISTENT: it walks work units (tile x
-//     output-block group) blockIdx.x, blockIdx.x + gridDim.x, ...  The stream of (unit, 16-channel chunk) stages flows through
+//     output-block group) of its XCD's contiguous eighth of the units, side by side with the XCD's other workgroups (round 4; before:
+//     blockIdx.x, blockIdx.x + gridDim.x, ...).  The stream of (unit, 16-channel chunk) stages flows through
 //     two alternating LDS buffers without a break at unit boundaries: while the compute waves run the last chunk of a unit and
 //     write its tile out, the loaders already stage the first chunks of the next one.  One raw barrier per chunk;
 //   * a loader thread's items (LDS offset, byte offset in the image) are computed once per launch; everything that changes from
