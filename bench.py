@@ -619,8 +619,19 @@ def run_via_trainer(name, cfg, args):
     # contains the front-end and reads it in place -- measured 0.07-0.3 ms per step SLOWER (the 50 us front-end moves from beside
     # the step into it; profiles/r04_via_trainer_ab.txt)
     pcm_fed = args.pcm_loader
-    train = ds.batch_loader(B, drop_last=True, workers=args.workers, pcm=pcm_fed)
-    val = ds.batch_loader(B, indices=list(range(B)), workers=args.workers, pcm=pcm_fed)
+    if args.dataloader_workers:
+        # training.ipynb cell 6 as written: torch's DataLoader with worker PROCESSES and pin_memory=True.  The workers decode on
+        # the host (no GPU API), the batches arrive as page-locked HostPcmBatch objects; ModelTrainer uploads them beside the
+        # running step and binds them to the PCM-fed captured step
+        from torch.utils.data import DataLoader, Subset
+        pcm_fed = True
+        train = DataLoader(ds, batch_size=B, shuffle=False, num_workers=args.dataloader_workers, pin_memory=True,
+                           drop_last=True, timeout=0, worker_init_fn=None)
+        val = DataLoader(Subset(ds, list(range(B))), batch_size=B, shuffle=False, num_workers=args.dataloader_workers,
+                         pin_memory=True, drop_last=False, timeout=0, worker_init_fn=None)
+    else:
+        train = ds.batch_loader(B, drop_last=True, workers=args.workers, pcm=pcm_fed)
+        val = ds.batch_loader(B, indices=list(range(B)), workers=args.workers, pcm=pcm_fed)
     model = build_model(cfg, device)
     # training.ipynb cell 11, as written: torch's own Adam -- ModelTrainer adopts it into the fused launch
     opt = Adam(model.parameters(), weight_decay=1e-5) if args.own_adam else torch.optim.Adam(model.parameters(), weight_decay=1e-5)
@@ -660,11 +671,15 @@ def run_via_trainer(name, cfg, args):
         'metric': 'stem-spectrogram-frames/sec (train, via ModelTrainer.fit)', 'value': frames * steps / train_s,
         'unit': 'stem-spectrogram-frames/s', 'n_gpus': 1, 'steps': steps, 'ms_per_step': 1e3 * train_s / steps,
         'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic', 'diagnostic': True,
-        'config': {'workload': cfg['workload'] + ' -- through ModelTrainer.fit(Dataset.batch_loader(8)) from in-memory songs (%s)' % ('float32' if args.float_pcm else '16-bit PCM'),
+        'config': {'workload': cfg['workload'] + ' -- through ModelTrainer.fit(%s) from in-memory songs (%s)' % (
+                       'torch DataLoader(num_workers=%d, pin_memory=True)' % args.dataloader_workers if args.dataloader_workers
+                       else 'Dataset.batch_loader(8)', 'float32' if args.float_pcm else '16-bit PCM'),
+                   'dataloader_workers': args.dataloader_workers,
                    'sync_per_step': 'every batch\'s loss is read on the host and logged, one batch late (ModelTrainer._run)',
                    'decode_threads': args.workers, 'pcm': 'float32' if args.float_pcm else 'int16 (16-bit PCM)',
                    'optimizer_passed': 'deep_audio_mixer_amd.optim.Adam' if args.own_adam else 'torch.optim.Adam (adopted by ModelTrainer)',
-                   'loader': 'PcmBatch (front-end inside the captured step)' if pcm_fed else 'features (front-end per batch on the copy stream)',
+                   'loader': 'torch.utils.data.DataLoader worker processes -> HostPcmBatch (page-locked) -> upload on a copy stream -> front-end inside the captured step' if args.dataloader_workers
+                   else 'PcmBatch (front-end inside the captured step)' if pcm_fed else 'features (front-end per batch on the copy stream)',
                    'graph_steps': trainer.graph_steps, 'epoch_s': epoch_s[1:],
                    'host_ms_per_step': {k: 1e3 * v / steps for k, v in trainer.host_times.items()},
                    'eager_steps': trainer.eager_steps, 'epochs_timed': n_epochs, 'batches_per_epoch': len(train),
@@ -839,6 +854,8 @@ def main():
     ap.add_argument('--workers', type=int, default=8, help='--ingest / --via-trainer: decode threads')
     ap.add_argument('--float-pcm', action='store_true', help='--via-trainer: float32 in-memory songs instead of 16-bit PCM')
     ap.add_argument('--pcm-loader', action='store_true', help='--via-trainer: loader yields uploaded PCM, front-end inside the captured step')
+    ap.add_argument('--dataloader-workers', type=int, default=0,
+                    help='--via-trainer: torch DataLoader(num_workers=N, pin_memory=True) over the Dataset (training.ipynb cell 6 as written)')
     ap.add_argument('--own-adam', action='store_true', help='--via-trainer: pass optim.Adam instead of torch.optim.Adam')
     args = ap.parse_args()
     if args.gpus < 1:

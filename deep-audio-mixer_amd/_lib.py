@@ -4,6 +4,7 @@ import ctypes
 import os
 
 import torch
+import torch.utils.data
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DAM_LIB_PATH') or os.path.join(_HERE, 'libdam_hip.so')   # override: diagnostic builds only
@@ -100,8 +101,15 @@ _lib = None
 
 
 def lib():
-    """Loads libdam_hip.so once; raises (never falls back) if it is not built."""
+    """Loads libdam_hip.so once; raises (never falls back) if it is not built -- and in a process that must not touch the
+    GPU (a DataLoader worker, any fork of a GPU-initialised parent): the HIP runtime does not survive a fork, a launch from
+    there would hang or fault instead of failing."""
     global _lib
+    if torch.cuda._is_in_bad_fork() or torch.utils.data.get_worker_info() is not None:
+        raise RuntimeError('deep_audio_mixer_amd: a GPU kernel was asked for in a DataLoader worker / forked child process '
+                           '(pid %d).  The GPU belongs to the parent: workers of MultitrackAudioDataset return host PCM '
+                           '(PcmItem / HostPcmBatch) and the front-end runs in the main process -- see '
+                           'features.batch_features(batch)' % os.getpid())
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libdam_hip.so is not built (%s): run `python __graft_entry__.py` or '

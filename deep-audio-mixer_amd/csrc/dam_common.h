@@ -58,4 +58,28 @@ __device__ __forceinline__ float wave_sum64(float v) {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Launch-side caches.  A kernel's raised LDS limit (hipFuncSetAttribute), the CU count and an occupancy answer belong to ONE
+// device: a process that drives a second GPU must not reuse what it learnt on the first.  PerDevice<T> is a zero-initialised
+// slot per device ordinal, read through the calling thread's current device.
+constexpr int MAX_DEVICES = 32;
+static inline int device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d % MAX_DEVICES;
+}
+template <class T>
+struct PerDevice {
+    T v[MAX_DEVICES] = {};
+    T& operator()() { return v[device_slot()]; }
+};
+static inline int device_cus() {
+    static PerDevice<int> cus;
+    int& n = cus();
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    }
+    return n;
+}
+
 }  // namespace dam

@@ -270,7 +270,7 @@ int launch_conv_pack(const ConvGeoPack& pk, size_t lds, const float* X, const fl
                      const float* sh, float* Y, const float* res, const float* res_mask, float* splitk_ws, hipStream_t st) {
     constexpr int TM = 64 * MB;
     if (lds > 64 * 1024) {
-        static bool raised = false;   // per instantiation
+        static PerDevice<bool> raised_pd; bool& raised = raised_pd();
         if (!raised) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MB, NB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

@@ -616,15 +616,12 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const ConvGeo g
 // resident workgroups per launch: occupancy x CUs, asked once per instance and LDS size
 template <int MB, int NB, int PU, int STATS, int KS>
 int pipe_slots(size_t lds) {
-    static int cus = 0;
-    static size_t cached_lds = ~(size_t)0;
-    static int cached = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 256;
-    }
-    if (cached_lds != lds) {
+    const int cus = device_cus();
+    static PerDevice<size_t> cached_lds_pd;          // (0 = nothing cached yet: the kernel always asks for LDS)
+    static PerDevice<int> cached_pd;
+    size_t& cached_lds = cached_lds_pd();
+    int& cached = cached_pd();
+    if (cached_lds != lds || !cached) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_pipe_kernel<MB, NB, PU, STATS, KS>), PIPE_THREADS,
                                                          lds) != hipSuccess || per_cu < 1)

@@ -267,16 +267,12 @@ int launch_conv_s2_pair(const float* x, const float* wp, const float* wp2, int B
     if (px >= (1ll << 26) || xb >= (1ll << 31)) return DAM_ERR_UNSUPPORTED;      // byte offsets of the range-checked loads
     const int64_t units = cdiv(px, 16);
     const size_t lds = (size_t)10 * NCH * NB * 1024;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    }
+    const int cus = device_cus();
     // Workgroups per CU by makespan, as in dam_dgrad_s2.hip: n resident waves per SIMD share its MFMA pipe; more waves hide the operand
     // latency better, which decides while the costs are within ~15 %.  One statistics record per workgroup, <= BN_RECORDS_MAX.
     const bool stats = p1 != nullptr;
-    static int occ[2] = {0, 0};       // resident workgroups per CU of this instantiation (registers and LDS; asked once)
-    int& oc = occ[stats ? 1 : 0];
+    static PerDevice<int> occ[2];       // resident workgroups per CU of this instantiation (registers and LDS; asked once per device)
+    int& oc = occ[stats ? 1 : 0]();
     if (!oc) {
         int n = 0;
         const hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_s2_pair_kernel<NB, NCH, true, WAVES>, 64 * WAVES, lds)
@@ -301,12 +297,13 @@ int launch_conv_s2_pair(const float* x, const float* wp, const float* wp2, int B
     if (wgs > cdiv(units, WAVES)) wgs = cdiv(units, WAVES);
     static const int xcd_aware = getenv("DAM_S2_NO_XCD") ? 0 : 1;      // A/B knob
     if (parts_host) *parts_host = stats ? (int)wgs : 0;
-    static bool raised[2] = {false, false};
-    if (lds > 64 * 1024 && !raised[stats ? 1 : 0]) {
+    static PerDevice<bool> raised_pd[2];
+    bool& raised = raised_pd[stats ? 1 : 0]();
+    if (lds > 64 * 1024 && !raised) {
         const void* fn = stats ? reinterpret_cast<const void*>(&conv_s2_pair_kernel<NB, NCH, true, WAVES>)
                                : reinterpret_cast<const void*>(&conv_s2_pair_kernel<NB, NCH, false, WAVES>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;
-        raised[stats ? 1 : 0] = true;
+        raised = true;
     }
     if (stats)
         hipLaunchKernelGGL((conv_s2_pair_kernel<NB, NCH, true, WAVES>), dim3((unsigned)wgs), dim3(64 * WAVES), lds, st, x, (unsigned)xb,

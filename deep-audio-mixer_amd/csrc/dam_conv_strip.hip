@@ -1253,7 +1253,7 @@ static int launch_strip(ConvGeo& g, StripGeo& sg, size_t lds, const float* X, co
                         const float* res, const float* res_mask, float* stats, const float* in_scale, const float* in_shift,
                         const BnFinArgs& fin, const BnBwdEpi& bwd, hipStream_t st) {
     if (lds > 64 * 1024) {
-        static bool raised = false;
+        static PerDevice<bool> raised_pd; bool& raised = raised_pd();
         if (!raised) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_strip_kernel<MB, NB, NCH, T33, LW, EPI, SO>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

@@ -272,14 +272,10 @@ int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const fl
     if (px >= (1ll << 30)) return DAM_ERR_UNSUPPORTED;
     const int64_t units = cdiv(px, 16 * MB);
     const size_t lds = (size_t)(9 + (ds ? 1 : 0)) * NCH * NB * 1024;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    }
+    const int cus = device_cus();
     // resident workgroups per CU of THIS instantiation (registers and LDS; asked once): a grid beyond it would run a second, partial round
-    static int occ[2][2] = {{0, 0}, {0, 0}};
-    int& oc = occ[ds ? 1 : 0][sums.u ? 1 : 0];
+    static PerDevice<int> occ[2][2];
+    int& oc = occ[ds ? 1 : 0][sums.u ? 1 : 0]();
     if (!oc) {
         int n = 0;
         hipError_t e;
@@ -308,7 +304,7 @@ int launch_dgrad_s2(const float* dc, const float* wpt, const float* ds, const fl
     if (sums.u && wgs > BN_BWD_RECORDS_MAX) return DAM_ERR_UNSUPPORTED;
 #define DAM_S2_GO(PAIR_, SUMS_)                                                                                                   \
     do {                                                                                                                          \
-        static bool raised = false;                                                                                               \
+        static PerDevice<bool> raised_pd; bool& raised = raised_pd();\
         if (!raised && lds > 64 * 1024) {                                                                                         \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_s2_kernel<NB, NCH, MB, PAIR_, WAVES, SUMS_>),              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;     \

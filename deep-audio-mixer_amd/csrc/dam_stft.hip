@@ -521,7 +521,7 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
 #define DAM_STFT_GENERIC(T, C, P)                                                                                     \
     do {                                                                                                              \
         if (lds > 48 * 1024) {                                     /* 8192 / 16384-point windows: raise the kernel's LDS limit once */ \
-            static bool raised = false;                                                                               \
+            static PerDevice<bool> raised_pd; bool& raised = raised_pd();\
             if (!raised) {                                                                                            \
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_generic_kernel<T, C, P>),                 \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024) != hipSuccess)        \

@@ -784,7 +784,7 @@ int launch_wgrad_rows(int B, int H, int W, int C, const float* X, const float* d
     }
     const int nsplit = B * g.spi;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
-    static bool raised = false;
+    static PerDevice<bool> raised_pd; bool& raised = raised_pd();
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_kernel<TNB, TKB, STEPS, KP, GPP, HV, NL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1100,7 +1100,7 @@ int launch_wgrad_rows_s2(int B, int H, int W, int C, int Ho, int Wo, int N, cons
     }
     const int nsplit = B * g.spi;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
-    static bool raised = false;
+    static PerDevice<bool> raised_pd; bool& raised = raised_pd();
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rows_s2_kernel<TNB, STEPS, KP, GPPX, GPPD, HV>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1261,7 +1261,7 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
     if (lds < (size_t)NBLK * 1024) lds = (size_t)NBLK * 1024;
     if (lds > 160 * 1024) return DAM_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        static bool raised = false;
+        static PerDevice<bool> raised_pd; bool& raised = raised_pd();
         if (!raised) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNB, TKB, TA, TB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

@@ -5,7 +5,14 @@ Same constructor, ``__getitem__(i) -> (train_features [S,1025,T], gt_features [1
 ``compute_features(audio, window_size=2048, hop_length=1024)``, ``get_tracklist`` / ``get_num_songs`` /
 ``get_song_durations`` and the same chunk <-> song index arithmetic (:97-113).  Differences, all explicit:
   * items are float32 CUDA tensors (the reference yields float64 CPU tensors that its own ModelTrainer cannot
-    consume, SURVEY F4): use ``DataLoader(..., num_workers=0, pin_memory=False)``;
+    consume, SURVEY F4) when ``__getitem__`` runs in the process that owns the GPU;
+  * inside a DataLoader WORKER (``DataLoader(d_train, batch_size=48, num_workers=6, pin_memory=True)``, training.ipynb
+    cell 6 as written) ``__getitem__`` touches no GPU API: it returns the decoded chunk as a ``PcmItem`` (host PCM, the
+    file's own sample type); the default collate turns a list of them into ONE ``HostPcmBatch`` ([B, S+1, n, ch], in
+    shared memory), the loader's pin-memory thread page-locks it, and in the main process the batch either goes to
+    ``ModelTrainer`` (upload on a copy stream + the PCM-fed captured step: the front-end runs inside the graph) or is
+    unpacked like the reference's ``(train_features, gt_features)`` pair -- the upload and ONE front-end launch then happen
+    on the spot (``features.batch_features(batch)`` is the same as a function);
   * audio comes from MedleyDB-layout WAV files read with the stdlib (``soundfile`` is not required), or from
     in-memory arrays via ``MultitrackAudioDataset.from_arrays``;
   * the per-item prints of the reference (:284,287-289) are behind ``verbose=True``;
@@ -20,6 +27,7 @@ Same constructor, ``__getitem__(i) -> (train_features [S,1025,T], gt_features [1
 import os
 import random
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -28,6 +36,17 @@ from torch.utils import data
 from .. import features, staging
 from .dataset_utils import (cached_files_begin, close_cached_files, native_dtype, read_wav, read_wav_native, wav_header,
                             wav_num_frames)
+
+
+def in_loader_worker():
+    """True where no GPU API may be touched: a DataLoader worker process, or any fork of a GPU-initialised parent (the HIP
+    runtime does not survive a fork: torch refuses to re-initialise it, and a raw HIP call there would hang or fault)."""
+    return data.get_worker_info() is not None or torch.cuda._is_in_bad_fork()
+
+
+# datasets alive in THIS process by their token: a HostPcmBatch that comes back from a worker finds the dataset object
+# the main process holds (the workers' copies are forks whose read counters die with them)
+_live_datasets = weakref.WeakValueDictionary()
 
 
 class MultitrackAudioDataset(data.Dataset):
@@ -49,6 +68,8 @@ class MultitrackAudioDataset(data.Dataset):
         # reproducible given the seed; without a seed the base is random, like numpy's unseeded global state
         self._aug_seed = seed if seed else int.from_bytes(os.urandom(8), 'little') >> 2
         self._aug_reads, self._aug_epoch = {}, 0
+        self._token = int.from_bytes(os.urandom(8), 'little') >> 1
+        _live_datasets[self._token] = self
         if _arrays is not None and not songlist:
             songlist = list(_arrays.keys())
         if not songlist:
@@ -173,20 +194,28 @@ class MultitrackAudioDataset(data.Dataset):
             out.append(c.astype(np.float64))
         return np.stack(out)
 
-    def _process_on_the_fly(self, song_i: int, chunk_i: int, index: int = None) -> tuple:
-        """data/dataset.py:185-210: all S+1 tracks of the chunk go through ONE front-end launch."""
+    def _read_item_pcm(self, song_i: int, chunk_i: int):
+        """data/dataset.py:192-196: the S+1 tracks of one chunk as ONE host array [S+1, n, channels] (their common sample
+        type).  Host work only -- this is all a DataLoader worker does for an item."""
         song_name = self.songlist[song_i]
         lo, hi = chunk_i * self._chunk_length * self._sr, (chunk_i + 1) * self._chunk_length * self._sr
         chunks = [self._read_chunk(song_name, t, lo, hi) for t in self._tracklist]
         chunks = [c[:, None] if c.ndim == 1 else c for c in chunks]
-        pcm = torch.from_numpy(self._common_pcm(chunks)).to(self._device)          # [S+1, n, channels]
+        return self._common_pcm(chunks)
+
+    def _global_index(self, song_i, chunk_i):
+        return sum(int(d / self._chunk_length) for d in self.song_durations[:song_i]) + chunk_i
+
+    def _process_on_the_fly(self, song_i: int, chunk_i: int, index: int = None) -> tuple:
+        """data/dataset.py:185-210: all S+1 tracks of the chunk go through ONE front-end launch."""
+        pcm = torch.from_numpy(self._read_item_pcm(song_i, chunk_i)).to(self._device)          # [S+1, n, channels]
         gain = None
         if self._augment:        # one draw per track, the mix included (data/dataset.py:198-199): drawn on the device,
             # reproducibly, keyed by (dataset seed, global item index, read count, track) instead of numpy's global state
-            item = index if index is not None else sum(int(d / self._chunk_length) for d in self.song_durations[:song_i]) + chunk_i
-            gain = features.augment_gains(self._aug_seed, len(chunks), items=self._aug_keys([item]), device=self._device)[0]
+            item = index if index is not None else self._global_index(song_i, chunk_i)
+            gain = features.augment_gains(self._aug_seed, pcm.shape[0], items=self._aug_keys([item]), device=self._device)[0]
         feats = features.stft_logmag(pcm, 2048, 1024, gain=gain, normalize=self._normalize)
-        return feats[:-1], feats[-1]
+        return DeviceItem((feats[:-1], feats[-1]))
 
     # ---- batched ingest: decode threads -> page-locked staging -> copy stream -> one front-end launch per batch
     def staging_format(self):
@@ -423,11 +452,14 @@ class MultitrackAudioDataset(data.Dataset):
 
     def _process_precomputed(self, song_i, chunk_i) -> tuple:
         _, p_train, p_gt = self._feature_paths(song_i, chunk_i)
-        train = torch.from_numpy(np.load(p_train)).to(self._device)
-        gt = torch.from_numpy(np.load(p_gt)).to(self._device)
+        train, gt = torch.from_numpy(np.load(p_train)), torch.from_numpy(np.load(p_gt))
+        if in_loader_worker():       # a DataLoader worker: CPU tensors (default collate stacks them, the pin thread page-locks
+            # them, ModelTrainer's / the caller's .to(device) uploads them -- the reference's own arrangement)
+            return (MultitrackAudioDataset._augment_features(train) if self._augment else train), gt
+        train, gt = train.to(self._device), gt.to(self._device)
         if self._augment:
             train = MultitrackAudioDataset._augment_features(train)
-        return train, gt
+        return DeviceItem((train, gt))
 
     def __getitem__(self, index: int) -> tuple:
         song_i, chunk_i = self._calculate_song_index(index)
@@ -435,6 +467,12 @@ class MultitrackAudioDataset(data.Dataset):
             print('Song {}, chunk {}'.format(self.songlist[song_i], chunk_i))
         if not self._compute_features:
             return self._process_precomputed(song_i, chunk_i)
+        if in_loader_worker():
+            # training.ipynb cell 6: DataLoader(d_train, num_workers=6, pin_memory=True).  No GPU API here: the decoded
+            # chunk travels as host PCM; the augmentation draw (keyed by item and read count) and the front-end happen
+            # in the process that owns the GPU (HostPcmBatch)
+            return PcmItem(torch.from_numpy(self._read_item_pcm(song_i, chunk_i)), int(index), self._token,
+                           self._aug_seed if self._augment else None, self._normalize, str(self._device))
         tic = time.time()
         train_features, gt_features = self._process_on_the_fly(song_i, chunk_i, index)
         if self._verbose:
@@ -443,6 +481,13 @@ class MultitrackAudioDataset(data.Dataset):
 
     def __len__(self) -> int:
         return self._len
+
+    def __getstate__(self):
+        """Pickled for DataLoader workers started by spawn / forkserver: the page-locked staging slots and their lock stay
+        behind (iter_batches rebuilds them)."""
+        state = dict(self.__dict__)
+        state.pop('_staging_cache', None)
+        return state
 
     def get_num_songs(self) -> int:
         return len(self.songlist)
@@ -488,6 +533,148 @@ class PcmBatch:
 
     def __iter__(self):
         return iter(self.features())
+
+
+class DeviceItem(tuple):
+    """``(train_features, gt_features)`` as ``__getitem__`` yields them in the process that owns the GPU (data/dataset.py:292):
+    a plain 2-tuple of CUDA tensors to every caller.  Its own type only so that the default collate produces a DeviceBatch,
+    which ``DataLoader(..., num_workers=0, pin_memory=True)`` leaves alone (torch's pin step raises on CUDA tensors)."""
+    __slots__ = ()
+
+
+class DeviceBatch:
+    """The collated ``(train_features [B,S,F,T], gt_features [B,F,T])`` pair of DeviceItems: unpacks, indexes and measures
+    like the 2-tuple the default collate would have made; ``pin_memory()`` is the identity (the tensors are in HBM)."""
+    __slots__ = ('pair',)
+
+    def __init__(self, train_features, gt_features):
+        self.pair = (train_features, gt_features)
+
+    def __iter__(self):
+        return iter(self.pair)
+
+    def __getitem__(self, i):
+        return self.pair[i]
+
+    def __len__(self):
+        return 2
+
+    def pin_memory(self):
+        return self
+
+
+class PcmItem:
+    """What ``__getitem__`` returns inside a DataLoader worker: one item's decoded chunk on the HOST -- `pcm` [S+1, n, ch]
+    (mix last; the file's own sample type, data/dataset.py:192-196 without the float64 conversion), the item's global index
+    (the key of its augmentation draw), the dataset's token / augmentation seed (None: no augmentation) / normalise flag /
+    device.  A batch of them collates into a HostPcmBatch (registered with torch's default collate below)."""
+    __slots__ = ('pcm', 'index', 'token', 'aug_seed', 'normalize', 'device')
+
+    def __init__(self, pcm, index, token, aug_seed, normalize, device):
+        self.pcm, self.index, self.token, self.aug_seed, self.normalize, self.device = pcm, index, token, aug_seed, normalize, device
+
+    def __iter__(self):
+        """(train_features [S,F,T], gt_features [F,T]) -- in the process that owns the GPU; raises in a worker."""
+        x, gt = collate_pcm_items([self]).features()
+        return iter((x[0], gt[0]))
+
+
+def _as_float64(pcm):
+    if pcm.dtype == torch.int16:
+        return pcm.to(torch.float64) / 32768.0
+    if pcm.dtype == torch.int32:
+        return pcm.to(torch.float64) / 2147483648.0
+    return pcm.to(torch.float64)
+
+
+def collate_pcm_items(batch, *, collate_fn_map=None):
+    """torch.utils.data.default_collate for a list of PcmItems -> ONE HostPcmBatch.  Inside a worker the [B, S+1, n, ch]
+    block is allocated in shared memory (what torch's own tensor collate does), so the batch crosses the process boundary
+    as a file descriptor, not as a pickled copy."""
+    pcms = [b.pcm for b in batch]
+    if len({p.dtype for p in pcms}) > 1:         # files of different sample types in one batch: float64 in [-1, 1),
+        pcms = [_as_float64(p) for p in pcms]    # what soundfile.read yields at data/dataset.py:194
+    elem = pcms[0]
+    if any(p.shape != elem.shape for p in pcms):
+        raise ValueError('items of one batch must have one shape (chunk length x channels): %s'
+                         % sorted({tuple(p.shape) for p in pcms}))
+    out = None
+    if data.get_worker_info() is not None:
+        storage = elem._typed_storage()._new_shared(elem.numel() * len(pcms), device=elem.device)
+        out = elem.new(storage).resize_(len(pcms), *elem.shape)
+    clips = torch.stack(pcms, 0, out=out)
+    first = batch[0]
+    return HostPcmBatch(clips, torch.tensor([b.index for b in batch], dtype=torch.int64), first.token, first.aug_seed,
+                        first.normalize, first.device)
+
+
+class HostPcmBatch:
+    """One batch of decoded clips in HOST memory, as it comes out of ``DataLoader(dataset, num_workers>0)``: `clips`
+    [B, S+1, n, ch] (mix last), `items` int64 [B] global item indices.  ``pin_memory()`` is what the loader's pin thread
+    calls (``pin_memory=True``).  In the process that owns the GPU:
+      * ``to_device()`` -> PcmBatch: the upload (asynchronous when the clips are page-locked) and the items' augmentation
+        draws (data/dataset.py:198-199; keyed by seed, item and how often the item has been read -- the counters of the
+        dataset object this process holds, so the draws are those of the ``num_workers=0`` loader in the same order);
+      * unpacking (``train_features, gt_features = batch``, model_trainer.py:31-33 / training_ignite.ipynb cell 12) or
+        ``features()`` runs the front-end on the uploaded batch: ONE launch for its B*(S+1) tracks."""
+    __slots__ = ('clips', 'items', 'token', 'aug_seed', 'normalize', 'device', 'n_fft', 'hop', '_dev')
+
+    def __init__(self, clips, items, token, aug_seed, normalize, device, n_fft=2048, hop=1024):
+        self.clips, self.items, self.token, self.aug_seed, self.normalize, self.device = clips, items, token, aug_seed, normalize, device
+        self.n_fft, self.hop, self._dev = n_fft, hop, None
+
+    def __getstate__(self):
+        return (self.clips, self.items, self.token, self.aug_seed, self.normalize, self.device, self.n_fft, self.hop)
+
+    def __setstate__(self, state):
+        (self.clips, self.items, self.token, self.aug_seed, self.normalize, self.device, self.n_fft, self.hop), self._dev = state, None
+
+    def pin_memory(self):
+        if self.clips.is_pinned():
+            return self
+        return HostPcmBatch(self.clips.pin_memory(), self.items, self.token, self.aug_seed, self.normalize, self.device,
+                            self.n_fft, self.hop)
+
+    def draw_gains(self, device):
+        """[B, S+1] augmentation gains of this batch's items on `device` (None without augmentation).  Advances the read
+        counters of the live dataset: call once per batch."""
+        if self.aug_seed is None:
+            return None
+        ds = _live_datasets.get(self.token)
+        items = [int(i) for i in self.items]
+        keys = ds._aug_keys(items) if ds is not None else items
+        return features.augment_gains(self.aug_seed, self.clips.shape[1], items=keys, device=device)
+
+    def to_device(self, device=None, out=None):
+        """The batch in HBM as a PcmBatch (front-end not run yet).  out: a device buffer [>= B, S+1, n, ch] of the clips'
+        dtype to upload into (ModelTrainer's staging slots); the copy is enqueued on the current stream."""
+        if in_loader_worker():
+            raise RuntimeError('HostPcmBatch.to_device() in a DataLoader worker / forked child: the GPU belongs to the '
+                               'parent process -- hand the batch to the main process (that is what the loader does)')
+        if self._dev is None:
+            dev = torch.device(device if device is not None else self.device)
+            B = self.clips.shape[0]
+            if out is None:
+                out = torch.empty(self.clips.shape, dtype=self.clips.dtype, device=dev)
+            dst = out[:B]
+            dst.copy_(self.clips, non_blocking=True)
+            self._dev = PcmBatch(dst, self.draw_gains(dst.device), self.normalize, self.n_fft, self.hop)
+        return self._dev
+
+    def features(self, device=None):
+        return self.to_device(device).features()
+
+    def __iter__(self):
+        return iter(self.features())
+
+
+# DataLoader's default collate looks an item's type up here before its generic rules (a documented extension point):
+# importing this module -- which unpickling / forking the dataset in a worker implies -- is what registers the two types
+from torch.utils.data._utils.collate import default_collate_fn_map as _collate_map     # noqa: E402
+
+_collate_map[PcmItem] = collate_pcm_items
+_collate_map[DeviceItem] = lambda batch, *, collate_fn_map=None: DeviceBatch(torch.stack([b[0] for b in batch]),
+                                                                             torch.stack([b[1] for b in batch]))
 
 
 class _BatchLoader:

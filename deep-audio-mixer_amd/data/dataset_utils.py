@@ -49,31 +49,66 @@ _fd_of_path = {}               # path -> the key its cached descriptor was opene
 _FDS_MAX = 256
 _fds_lock = threading.Lock()
 _fd_users = 0                  # ingest passes (MultitrackAudioDataset.iter_batches) currently reading through the cache
+_fd_pins = {}                  # descriptor -> readers that hold it right now (between _get_fd and _put_fd)
+_fd_doomed = set()             # descriptors taken out of the cache while pinned: the last reader closes them
+
+
+def _retire(fd):
+    """(lock held) A descriptor leaves the cache: closed now, or by its last reader if someone is inside a pread on it --
+    never under a reader (EBADF, or, once the number has been reused, bytes of another file)."""
+    if _fd_pins.get(fd):
+        _fd_doomed.add(fd)
+    else:
+        os.close(fd)
 
 
 def _get_fd(path, h):
-    """(descriptor, close it after use?): cached for the first _FDS_MAX files, a fresh one beyond that.  A cached descriptor
-    is closed when the file behind its path has changed (new mtime / size: a re-rendered stem) and by close_cached_files()
-    when the last ingest pass ends -- never while a pass that may be reading through it is running."""
+    """(descriptor, cached?): cached for the first _FDS_MAX files, a fresh one beyond that.  Every reader -- an ingest pass'
+    decode threads, __getitem__ on another thread, a second dataset -- PINS the descriptor it was handed until _put_fd():
+    close_cached_files() and the stale-path check retire a pinned descriptor instead of closing it."""
     key = h['_key']
-    fd = _fds.get(key)
-    if fd is not None:
-        return fd, False
     with _fds_lock:
         fd = _fds.get(key)
-        if fd is not None:
-            return fd, False
-        stale = _fd_of_path.get(path)
-        if stale is not None and stale != key and _fd_users <= 1:
-            old = _fds.pop(stale, None)            # the path was rewritten: its old descriptor points at a dead inode
-            if old is not None:
-                os.close(old)
-            _headers.pop(stale, None)
-        if len(_fds) < _FDS_MAX:
+        if fd is None:
+            stale = _fd_of_path.get(path)
+            if stale is not None and stale != key:
+                old = _fds.pop(stale, None)            # the path was rewritten: its old descriptor points at a dead inode
+                if old is not None:
+                    _retire(old)
+                _headers.pop(stale, None)
+            if len(_fds) >= _FDS_MAX:
+                return os.open(path, os.O_RDONLY), False
             fd = _fds[key] = os.open(path, os.O_RDONLY)
             _fd_of_path[path] = key
-            return fd, False
-    return os.open(path, os.O_RDONLY), True
+        _fd_pins[fd] = _fd_pins.get(fd, 0) + 1
+        return fd, True
+
+
+def _put_fd(fd, cached):
+    if not cached:
+        os.close(fd)
+        return
+    with _fds_lock:
+        n = _fd_pins[fd] - 1
+        if n:
+            _fd_pins[fd] = n
+        else:
+            del _fd_pins[fd]
+            if fd in _fd_doomed:
+                _fd_doomed.discard(fd)
+                os.close(fd)
+
+
+def _after_fork_in_child():
+    """A DataLoader worker is a fork taken while decode threads of the parent may sit inside _get_fd: the child gets a fresh
+    lock and no pins (the inherited descriptors stay valid: positioned reads share no file offset)."""
+    global _fds_lock
+    _fds_lock = threading.Lock()
+    _fd_pins.clear()
+    _fd_doomed.clear()
+
+
+os.register_at_fork(after_in_child=_after_fork_in_child)
 
 
 def cached_files_begin():
@@ -84,15 +119,16 @@ def cached_files_begin():
 
 
 def close_cached_files(force=False):
-    """End of an ingest pass: when no other pass is running, every cached descriptor is closed (a long-lived process that
-    walks many datasets, or rewrites its files between passes, would otherwise hold up to _FDS_MAX of them for good).
-    force=True closes regardless of the pass count (tests; the caller guarantees no reader is running)."""
+    """End of an ingest pass: when no other pass is running, the cache is emptied (a long-lived process that walks many
+    datasets, or rewrites its files between passes, would otherwise hold up to _FDS_MAX descriptors for good); a descriptor
+    some reader outside the passes still holds is closed by that reader.  force=True empties the cache regardless of the
+    pass count (tests)."""
     global _fd_users
     with _fds_lock:
         _fd_users = max(0, _fd_users - 1)
         if _fd_users == 0 or force:
             for fd in _fds.values():
-                os.close(fd)
+                _retire(fd)
             _fds.clear()
             _fd_of_path.clear()
 
@@ -196,7 +232,7 @@ def read_wav_native(path, start=0, stop=None, out=None):
     if width != 3 and out is not None and out.dtype == kind and out.shape == (stop - start, ch) and out.flags.c_contiguous:
         # the ingest path: positioned read on a cached descriptor straight into the caller's (page-locked) buffer -- no
         # open / seek / close per chunk, no file position shared between the decode threads
-        fd, owned = _get_fd(path, h)
+        fd, cached = _get_fd(path, h)
         try:
             buf, off, want = memoryview(out).cast('B'), h['data_offset'] + start * h['frame_bytes'], out.nbytes
             got = 0
@@ -206,8 +242,7 @@ def read_wav_native(path, start=0, stop=None, out=None):
                     raise ValueError('%s: short read' % path)
                 got += r
         finally:
-            if owned:
-                os.close(fd)
+            _put_fd(fd, cached)
         return out, h['rate']
     with open(path, 'rb') as fh:
         fh.seek(h['data_offset'] + start * h['frame_bytes'])

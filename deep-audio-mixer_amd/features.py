@@ -161,3 +161,18 @@ def augment_gains(seed, n_tracks, items=None, first_item=0, n_items=None, lo=0.6
                                                 int(n_tracks), float(lo), float(hi), _lib.ptr(out), _lib.stream()),
                'dam_augment_gains_f32')
     return out
+
+
+def batch_features(batch, device=None):
+    """One call for caller-owned training loops (training_ignite.ipynb cell 12: ``train_features, gt_features = batch``):
+    whatever a loader over MultitrackAudioDataset yields -> ``(train_features [B,S,F,T], gt_features [B,F,T])`` float32 dB
+    on the GPU.  A HostPcmBatch (``DataLoader(dataset, num_workers>0)``: decoded clips in host memory) is uploaded and goes
+    through ONE front-end launch; a PcmBatch (``batch_loader(pcm=True)``) through the launch only; a pair of feature
+    tensors (``num_workers=0``, the feature cache, ``iter_batches``) is moved to the device if it is not there."""
+    if hasattr(batch, 'to_device'):
+        return batch.to_device(device).features()
+    if hasattr(batch, 'clips'):
+        return batch.features()
+    x, gt = batch
+    dev = torch.device(device if device is not None else 'cuda')
+    return x.to(dev, torch.float32), gt.to(dev, torch.float32)

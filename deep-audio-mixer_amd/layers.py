@@ -388,7 +388,8 @@ class BasicBlockFn(torch.autograd.Function):
         first = (keep(dw1, s_w1), keep(dg1, s_g1), keep(db1, s_b1), keep(dw2, s_w2), keep(dg2, s_g2), keep(db2, s_b2))
         if ctx.has_sc:
             dws = blk.spec_sc.wgrad(x, dcs, out=wview(s_ws, wsc))
-            if ops.PAIR_1X1 and blk.spec1.k == 3 and blk.spec1.stride == 2 and blk.spec_sc.stride == 2:
+            if (ops.PAIR_1X1 and blk.spec1.k == 3 and blk.spec1.stride == 2 and blk.spec1.pad == 1 and blk.spec1.dil == 1
+                    and blk.spec_sc.k == 1 and blk.spec_sc.stride == 2 and blk.spec_sc.pad == 0):      # (the forward's gate)
                 # the shortcut's whole data gradient and the centre tap of conv1's land on the same (even, even) pixels: one launch
                 up = ctx.upstream
                 pair = (dcs, blk.spec_sc.packed(wsc, transpose=True))

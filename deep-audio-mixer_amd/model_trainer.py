@@ -20,6 +20,9 @@ What is different underneath:
     uploaded PCM in place; batches of another shape (a ragged last
     batch) run eagerly.  The reference's per-batch ``loss.item()`` and prints stay.  ``graph=False`` keeps everything eager;
     when the captured path was wanted but cannot be taken (another criterion, another optimizer), ONE warning says why;
+  * ``DataLoader(dataset, batch_size, num_workers=6, pin_memory=True)`` over this package's MultitrackAudioDataset (training.ipynb
+    cell 6 as written) yields HostPcmBatch objects -- decoded clips in page-locked host memory, no GPU work in the workers;
+    they are uploaded on a copy stream into alternating device slots (``_upload``) and bound to the same PCM-fed captured step;
   * loaders without ``__len__`` (generators such as ``MultitrackAudioDataset.iter_batches``) are accepted: the epoch mean
     is taken over the batches seen;
   * like the reference, the trainer never switches the model between train and eval mode: validation runs
@@ -124,10 +127,42 @@ class ModelTrainer:
             old = st.get('step')
             st['step'] = torch.tensor(step, dtype=torch.float32, device=old.device if isinstance(old, torch.Tensor) else 'cpu')
 
-    def _pull_adopted_step(self):
-        """If the caller stepped its own optimizer between two fit() calls, the fused one continues from that count."""
+    def _adoption_intact(self, deep=True):
+        """Is the caller's torch.optim.Adam still ONE optimizer with the fused one?  ``optimizer.load_state_dict(...)`` AFTER
+        this trainer was built (the usual resume order) replaces ``param_groups[0]`` by a new dict and every ``exp_avg`` /
+        ``exp_avg_sq`` by a fresh tensor: lr edits would no longer reach the fused launch and the loaded moments would be
+        ignored -- and overwritten at the end of fit()."""
+        orig, opt = self._adopted_from, self.optimizer
+        if orig.param_groups[0] is not opt.param_groups[0]:
+            return False
+        for i, p in enumerate(opt._params if deep else opt._params[:1]):
+            st = orig.state.get(p)
+            if not st:
+                return False
+            off = 4 * opt._offsets[i]
+            if (st['exp_avg'].data_ptr() != opt._exp_avg.data_ptr() + off
+                    or st['exp_avg_sq'].data_ptr() != opt._exp_avg_sq.data_ptr() + off):
+                return False
+        return True
+
+    def _pull_adopted_step(self, deep=True):
+        """Whatever the caller did to its own optimizer since the last batch this trainer ran reaches the fused one: a
+        ``load_state_dict`` (hyper-parameters, moments, step count: loaded into the flat buffers, then re-shared as views),
+        or plain ``step()`` calls between two fit()s (the fused one continues from that count)."""
         orig, opt = self._adopted_from, self.optimizer
         if orig is None:
+            return
+        if not self._adoption_intact(deep):
+            if orig.state:
+                opt.load_state_dict(orig.state_dict())
+            else:                                        # state cleared: a fresh optimizer
+                opt._exp_avg.zero_()
+                opt._exp_avg_sq.zero_()
+                opt._step.zero_()
+            opt.param_groups[0] = orig.param_groups[0]
+            opt._hyper_host = None
+            opt.sync_hyper()
+            self._push_adopted_state()
             return
         steps = {int(st['step']) for st in orig.state.values() if 'step' in st}
         if len(steps) == 1:
@@ -171,7 +206,49 @@ class ModelTrainer:
             model.train(training)
         return step
 
+    # ---- batches that arrive as decoded clips in HOST memory (DataLoader(dataset, num_workers>0, pin_memory=True))
+    PCM_SLOTS = 2
+
+    def _upload(self, host):
+        """data.dataset.HostPcmBatch -> PcmBatch in one of PCM_SLOTS device buffers, the copy on a private stream: batch k + 1
+        travels while the step on batch k runs (the host is one batch ahead of the device, see _run), and the step -- whose
+        captured front-end reads the clips in place -- waits for it on the device only.  What ``.to(self.device)`` is to the
+        reference's loop (model_trainer.py:34), without the 38 MB feature copy and without blocking the training stream."""
+        dev = torch.device(self.device)
+        B, rest, dtype = host.clips.shape[0], tuple(host.clips.shape[1:]), host.clips.dtype
+        st = getattr(self, '_pcm_stage', None)
+        if st is None or st['key'] != (rest, dtype) or st['cap'] < B:
+            st = self._pcm_stage = {
+                'key': (rest, dtype), 'cap': B, 'k': 0, 'stream': torch.cuda.Stream(device=dev),
+                'bufs': [torch.empty((B,) + rest, dtype=dtype, device=dev) for _ in range(self.PCM_SLOTS)],
+                'ready': [torch.cuda.Event() for _ in range(self.PCM_SLOTS)],
+                'consumed': [torch.cuda.Event() for _ in range(self.PCM_SLOTS)]}
+        slot = st['k'] % self.PCM_SLOTS
+        st['k'] += 1
+        cur = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(st['stream']):
+            st['stream'].wait_event(st['consumed'][slot])        # the step that read this slot's previous batch has finished
+            pcm = host.to_device(dev, out=st['bufs'][slot])
+            st['ready'][slot].record(st['stream'])
+        cur.wait_event(st['ready'][slot])
+        if pcm.gain is not None:
+            pcm.gain.record_stream(cur)
+        st['busy'] = slot
+        return pcm
+
+    def _uploaded_batch_enqueued(self):
+        """Everything that reads the slot of the last _upload() is on the current stream now."""
+        st = getattr(self, '_pcm_stage', None)
+        if st is not None and st.get('busy') is not None:
+            st['consumed'][st['busy']].record(torch.cuda.current_stream(torch.device(self.device)))
+            st['busy'] = None
+
     def _train_batch(self, batch):
+        if hasattr(batch, 'to_device'):                        # data.dataset.HostPcmBatch: decoded clips in host memory
+            try:
+                return self._train_batch(self._upload(batch))
+            finally:
+                self._uploaded_batch_enqueued()
         pcm = batch if hasattr(batch, 'clips') else None       # data.dataset.PcmBatch: uploaded PCM, front-end not run yet
         if pcm is not None:
             feats = target = None
@@ -180,8 +257,11 @@ class ModelTrainer:
         else:
             feats, target = (t.to(self.device) for t in batch)
             shape = (tuple(feats.shape), tuple(target.shape), feats.dtype, self.model.training)
+        if self._adopted_from is not None and not self._adoption_intact(deep=False):
+            self._pull_adopted_step()                # optimizer.load_state_dict() since the last batch
         if self._graphable and shape == self._shape and (self._step is not None or self._seen >= self.EAGER_BATCHES):
             if self._step is None:
+                self._pull_adopted_step()
                 self._step = self._capture(feats, target, pcm)
             if pcm is not None:
                 self._step.bind_clips(pcm.clips, pcm.gain)       # an 8-byte address word (+ the gain table): no PCM / feature copy
@@ -209,6 +289,11 @@ class ModelTrainer:
 
     # ---- one batch -> loss tensor (on the device)
     def _batch_loss(self, batch):
+        if hasattr(batch, 'to_device'):
+            try:
+                return self._batch_loss(self._upload(batch).features())
+            finally:
+                self._uploaded_batch_enqueued()
         if hasattr(batch, 'clips'):
             batch = batch.features()
         feats, target = (t.to(self.device) for t in batch)

@@ -364,3 +364,88 @@ def test_bench_counts_gpus_from_sysfs_without_a_gpu_runtime(tmp_path, monkeypatc
     assert bench.visible_gpu_count() == 2
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '1')
     assert bench.visible_gpu_count() == 1
+
+
+def _write_wav_song(root, name, n, sr, rng):
+    song = root / name / (name + '_STEMS_JOINED')
+    song.mkdir(parents=True)
+    out = {}
+    for track, fn in (('bass', '%s_STEM_BASS.wav'), ('drums', '%s_STEM_DRUMS.wav'), ('vocals', '%s_STEM_VOCALS.wav'),
+                      ('other', '%s_STEM_OTHER.wav'), ('mix', '../%s_MIX.wav')):
+        x = (rng.uniform(-0.5, 0.5, (n, 2)) * 32767).astype('<i2')
+        with wave.open(str(song / (fn % name)), 'wb') as w:
+            w.setnchannels(2), w.setsampwidth(2), w.setframerate(sr)
+            w.writeframes(x.tobytes())
+        out[track] = x
+    return out
+
+
+def test_dataloader_workers_return_host_pcm_and_touch_no_gpu(tmp_path):
+    """training.ipynb cell 6 as written -- DataLoader(d_train, batch_size, shuffle=False, num_workers=6, pin_memory=True,
+    ...) -- over data/dataset.py:270-292: inside a worker __getitem__ returns the decoded chunk as host PCM, the default
+    collate makes ONE HostPcmBatch per batch (shared memory), in order, ragged last batch included.  Runs here, without a
+    GPU: that the workers touch no GPU API is the point (pin_memory is off only because this container has no device to
+    page-lock for; the -m gpu twin of this test runs the cell verbatim)."""
+    from torch.utils.data import DataLoader
+    from deep_audio_mixer_amd.data.dataset import HostPcmBatch
+    sr = 8000
+    rng = np.random.default_rng(5)
+    files = {'A': _write_wav_song(tmp_path, 'A', sr * 4 + 100, sr, rng), 'B': _write_wav_song(tmp_path, 'B', sr * 3 + 5, sr, rng)}
+    d = MultitrackAudioDataset(str(tmp_path), chunk_length=1, sr=sr, seed=11, augment_data=True, device='cpu')
+    assert len(d) == 7
+    loader = DataLoader(d, batch_size=3, shuffle=False, num_workers=2, pin_memory=False, drop_last=False, timeout=0,
+                        worker_init_fn=None)
+    got = list(loader)
+    assert [type(b) for b in got] == [HostPcmBatch] * 3 and [b.clips.shape[0] for b in got] == [3, 3, 1]
+    assert all(b.clips.dtype == torch.int16 and tuple(b.clips.shape[1:]) == (5, sr, 2) for b in got)
+    assert all(b.clips.is_shared() for b in got)
+    assert torch.cat([b.items for b in got]).tolist() == list(range(7))
+    assert all(b.token == d._token and b.aug_seed == d._aug_seed and b.normalize is False for b in got)
+    clips = torch.cat([b.clips for b in got]).numpy()
+    for i in range(7):
+        song_i, chunk_i = d._calculate_song_index(i)
+        for k, t in enumerate(d.get_tracklist()):
+            np.testing.assert_array_equal(clips[i, k], files[d.songlist[song_i]][t][chunk_i * sr:(chunk_i + 1) * sr])
+    # the draws' read counters live in THIS process' dataset object, untouched by the workers' forks
+    assert d._aug_reads == {}
+    # a worker that would reach the GPU library raises a clear error instead of initialising a runtime in the fork
+
+    class Wrong(torch.utils.data.Dataset):
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return d.compute_features(np.zeros(4096))
+
+    with pytest.raises(RuntimeError, match='DataLoader worker'):
+        list(DataLoader(Wrong(), batch_size=1, num_workers=1))
+    # a PcmItem unpacked inside a worker (= asking for features there) is the same error
+    class Unpacks(torch.utils.data.Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            x, gt = d[i]
+            return x
+
+    with pytest.raises(RuntimeError, match='DataLoader worker'):
+        list(DataLoader(Unpacks(), batch_size=1, num_workers=1))
+
+
+def test_pcm_items_collate_mixed_sample_types_and_pickle():
+    """Items whose files hold different sample types collate to float64 in [-1, 1) (what soundfile.read yields,
+    data/dataset.py:194); a HostPcmBatch survives pickling (spawned workers) without its device cache."""
+    import pickle
+    from deep_audio_mixer_amd.data.dataset import HostPcmBatch, PcmItem, collate_pcm_items
+    from torch.utils.data import default_collate
+    a = PcmItem(torch.tensor([[[16384, -32768]]], dtype=torch.int16), 4, 77, None, False, 'cuda')
+    b = PcmItem(torch.tensor([[[0.25, -0.5]]], dtype=torch.float32), 5, 77, None, False, 'cuda')
+    hb = default_collate([a, b])
+    assert isinstance(hb, HostPcmBatch) and hb.clips.dtype == torch.float64 and hb.items.tolist() == [4, 5]
+    np.testing.assert_array_equal(hb.clips.numpy(), [[[[0.5, -1.0]]], [[[0.25, -0.5]]]])
+    same = collate_pcm_items([a, a])
+    assert same.clips.dtype == torch.int16 and same.aug_seed is None
+    back = pickle.loads(pickle.dumps(same))
+    assert torch.equal(back.clips, same.clips) and back.token == 77 and back._dev is None
+    with pytest.raises(ValueError, match='one shape'):
+        collate_pcm_items([a, PcmItem(torch.zeros((1, 2, 2), dtype=torch.int16), 6, 77, None, False, 'cuda')])

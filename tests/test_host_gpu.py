@@ -610,3 +610,154 @@ def test_train_step_missing_gradient_raises_before_the_update(dam):
     step2.load_features(bad, gt)
     step2.capture(warmup=1)            # must not raise 'wrote no gradient'
     step2.close()
+
+
+def _write_wav_song(root, name, n, sr, rng):
+    import wave
+    song = root / name / (name + '_STEMS_JOINED')
+    song.mkdir(parents=True)
+    for fn in ('%s_STEM_BASS.wav', '%s_STEM_DRUMS.wav', '%s_STEM_VOCALS.wav', '%s_STEM_OTHER.wav', '../%s_MIX.wav'):
+        x = (rng.uniform(-0.5, 0.5, (n, 2)) * 32767).astype('<i2')
+        with wave.open(str(song / (fn % name)), 'wb') as w:
+            w.setnchannels(2), w.setsampwidth(2), w.setframerate(sr)
+            w.writeframes(x.tobytes())
+
+
+@pytest.mark.parametrize('augment', [False, True])
+def test_notebook_loader_cell_with_six_workers_matches_num_workers_0(dam, tmp_path, monkeypatch, capsys, augment):
+    """training.ipynb cells 4, 6, 9, 11-13 AS WRITTEN: ``DataLoader(d_train, batch_size, shuffle=False,
+    num_workers=6, pin_memory=True, drop_last=False, timeout=0, worker_init_fn=None)`` over MultitrackAudioDataset
+    (data/dataset.py:270-292) on WAV files, ``torch.optim.Adam(model.parameters(), weight_decay=1e-5)``,
+    ``ModelTrainer(model, criterion, optimizer, device).fit(train_loader, val_loader, 0, 2)``.  The six workers decode on the
+    host and touch no GPU API; the batches arrive page-locked, are uploaded beside the running step and feed the PCM-bound
+    captured step.  Same loss list -- per batch, per epoch, validation -- as the ``num_workers=0`` loader (whose items are
+    CUDA feature tensors; ``pin_memory=True`` is kept there too), augmentation draws included."""
+    from torch.utils.data import DataLoader
+    from deep_audio_mixer_amd.data.dataset import DeviceBatch, HostPcmBatch, MultitrackAudioDataset
+    from deep_audio_mixer_amd.model_trainer import ModelTrainer
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    sr = 16384
+    rng = np.random.default_rng(21)
+    _write_wav_song(tmp_path, 'A', sr * 8 + 100, sr, rng)
+    _write_wav_song(tmp_path, 'B', sr * 7 + 5, sr, rng)
+    monkeypatch.chdir(tmp_path)
+    os.mkdir('weights')
+    device = torch.device('cuda')
+    runs = []
+    for workers in (0, 6):
+        d_train = MultitrackAudioDataset(str(tmp_path), songlist=['A', 'B'], chunk_length=1, sr=sr, seed=321, normalize=False,
+                                         compute_features=True, augment_data=augment)
+        d_val = MultitrackAudioDataset(str(tmp_path), songlist=['B'], chunk_length=1, sr=sr, seed=321, normalize=False,
+                                       compute_features=True, augment_data=False)
+        assert len(d_train) == 15
+        train_loader = DataLoader(d_train, batch_size=2, shuffle=False, num_workers=workers, pin_memory=True,
+                                  drop_last=False, timeout=0, worker_init_fn=None)
+        val_loader = DataLoader(d_val, batch_size=2, shuffle=False, num_workers=workers, pin_memory=True,
+                                drop_last=False, timeout=0, worker_init_fn=None)
+        first = next(iter(train_loader))
+        assert type(first) is (HostPcmBatch if workers else DeviceBatch)
+        if workers:
+            assert first.clips.is_pinned() and first.clips.dtype == torch.int16 and tuple(first.clips.shape) == (2, 5, sr, 2)
+            d_train.set_epoch(0)            # (the peek above took the first draw of items 0 and 1)
+        else:
+            assert first[0].is_cuda and tuple(first[0].shape) == (2, 4, 1025, 17) and len(first) == 2
+            d_train.set_epoch(0)
+        torch.manual_seed(3)
+        model = ResNet18(n_stems=4, input_shape=(1025, 17)).to(device).train()
+        criterion = torch.nn.MSELoss()
+        optimizer = torch.optim.Adam(model.parameters(), weight_decay=1e-5)
+        trainer = ModelTrainer(model, criterion, optimizer, device)
+        per_batch = []
+        real = trainer._train_batch
+        trainer._train_batch = lambda b, real=real, acc=per_batch: acc.append(real(b).item()) or torch.tensor(acc[-1])
+        train_loss, val_loss = trainer.fit(train_loader, val_loader, 0, 2)
+        assert (trainer.graph_steps, trainer.eager_steps) == (12, 4)          # 8 batches: 2 eager + 5 captured + ragged; 7 + ragged
+        assert trainer._step.from_features == (workers == 0)
+        assert (trainer._step.gain is not None) == (augment and workers > 0)
+        runs.append((per_batch, train_loss, val_loss))
+        trainer.close()
+    np.testing.assert_allclose(runs[1][0], runs[0][0], rtol=2e-5)
+    np.testing.assert_allclose(runs[1][1], runs[0][1], rtol=2e-5)
+    np.testing.assert_allclose(runs[1][2], runs[0][2], rtol=2e-5)
+    assert len(runs[0][0]) == 16 and runs[0][0][-1] < runs[0][0][0]
+    capsys.readouterr()
+
+
+def test_caller_owned_loop_over_worker_batches(dam):
+    """training_ignite.ipynb cell 12 (``train_features, gt_features = batch``; ``model(train_features.float().to(device))``)
+    over a DataLoader with workers: unpacking a HostPcmBatch uploads it and runs ONE front-end launch; the pair equals the
+    items of the GPU-owning process bit for bit; features.batch_features(batch) is the same as a function and also takes
+    the (features, target) pairs of the other loaders."""
+    from torch.utils.data import DataLoader
+    from deep_audio_mixer_amd import features
+    from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
+    rng = np.random.default_rng(4)
+    sr = 16000
+    songs = {'s%d' % i: {t: (0.1 * rng.standard_normal((int(d * sr), 2))).astype(np.float32)
+                         for t in ('bass', 'drums', 'vocals', 'other', 'mix')} for i, d in enumerate([3.2, 2.1])}
+    d = MultitrackAudioDataset.from_arrays(songs, chunk_length=1, sr=sr)
+    items = [d[i] for i in range(len(d))]
+    loader = DataLoader(d, batch_size=2, shuffle=False, num_workers=2, pin_memory=True)
+    device = torch.device('cuda')
+    seen = 0
+    for batch in loader:
+        train_features, gt_features = batch
+        x, gt = train_features.float().to(device), gt_features.float().to(device)
+        assert x.is_cuda and x.dtype == torch.float32
+        x2, gt2 = features.batch_features(batch)
+        assert x2.data_ptr() != 0 and torch.equal(x2, x) and torch.equal(gt2, gt)
+        for j in range(x.shape[0]):
+            assert torch.equal(x[j], items[seen][0]) and torch.equal(gt[j], items[seen][1])
+            seen += 1
+    assert seen == len(d) == 5
+    cpu_pair = (items[0][0][None].cpu().double(), items[0][1][None].cpu().double())      # the reference's own item type
+    x3, gt3 = features.batch_features(cpu_pair)
+    assert x3.is_cuda and x3.dtype == torch.float32 and torch.equal(x3[0], items[0][0]) and torch.equal(gt3[0], items[0][1])
+
+
+def test_trainer_follows_load_state_dict_on_the_adopted_adam(dam):
+    """the usual resume order -- build the trainer, THEN ``optimizer.load_state_dict(checkpoint)`` -- replaces the
+    caller's param_groups[0] dict and moment tensors.  The trainer notices before its next batch, loads the moments and
+    the step count into the fused buffers and re-shares them: the next update is the one torch.optim.Adam would make
+    from the checkpoint, and lr edits on the caller's object still reach the fused launch."""
+    from deep_audio_mixer_amd.model_trainer import ModelTrainer
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    shape = (2, 1025, 17)
+    batches = [tuple(torch.from_numpy(a).cuda() for a in model_input(2, *shape, seed=60 + k)) for k in range(4)]
+    torch.manual_seed(8)
+    model = ResNet18(n_stems=2, input_shape=shape[1:]).cuda().train()
+    opt = torch.optim.Adam(model.parameters(), weight_decay=1e-5)
+    tr = ModelTrainer(model, torch.nn.MSELoss(), opt, torch.device('cuda'))
+    for b in batches[:3]:
+        tr._train_batch(b)
+    tr._push_adopted_state()
+    ckpt_opt = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+    import copy
+    ckpt_opt = copy.deepcopy(opt.state_dict())
+    ckpt_model = copy.deepcopy(model.state_dict())
+    tr._train_batch(batches[3])                                      # the continuation to reproduce
+    torch.cuda.synchronize()
+    want = tr.optimizer._flat.clone()
+    tr.close()
+    # resume: fresh model + optimizer + trainer, the checkpoint loaded AFTER the trainer exists
+    torch.manual_seed(9)
+    model2 = ResNet18(n_stems=2, input_shape=shape[1:]).cuda().train()
+    opt2 = torch.optim.Adam(model2.parameters(), weight_decay=1e-5)
+    tr2 = ModelTrainer(model2, torch.nn.MSELoss(), opt2, torch.device('cuda'))
+    model2.load_state_dict(ckpt_model)
+    opt2.load_state_dict(ckpt_opt)
+    assert opt2.param_groups[0] is not tr2.optimizer.param_groups[0]          # the hazard: torch swapped the dict
+    tr2._train_batch(batches[3])
+    torch.cuda.synchronize()
+    assert int(tr2.optimizer._step.item()) == 4
+    assert opt2.param_groups[0] is tr2.optimizer.param_groups[0]
+    assert torch.allclose(tr2.optimizer._flat, want, rtol=1e-5, atol=1e-7)
+    p0 = tr2.optimizer._params[0]
+    assert opt2.state[p0]['exp_avg'].data_ptr() == tr2.optimizer._exp_avg.data_ptr()
+    opt2.param_groups[0]['lr'] = 0.0                                           # still one optimizer
+    before = tr2.optimizer._flat.clone()
+    tr2._train_batch(batches[0])
+    torch.cuda.synchronize()
+    assert torch.equal(tr2.optimizer._flat, before)
+    tr2.close()
+    assert float(opt2.state[p0]['step']) == 5.0
