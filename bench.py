@@ -607,6 +607,7 @@ def run_via_trainer(name, cfg, args):
     import tempfile
     import torch
     device = _setup_single()
+    from deep_audio_mixer_amd import staging as _staging
     from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
     from deep_audio_mixer_amd.model_trainer import ModelTrainer
     from deep_audio_mixer_amd.optim import Adam
@@ -625,7 +626,11 @@ def run_via_trainer(name, cfg, args):
         # running step and binds them to the PCM-fed captured step
         from torch.utils.data import DataLoader, Subset
         pcm_fed = True
-        train = DataLoader(ds, batch_size=B, shuffle=False, num_workers=args.dataloader_workers, pin_memory=True,
+        # an epoch of the in-memory set is 48 batches = 0.2 s of GPU time; the loader forks its six workers at every epoch start
+        # (as any DataLoader without persistent_workers does), which a real epoch -- MedleyDB at this clip length: some 800
+        # batches -- amortises.  --epoch-repeat walks the same clips R times per epoch; the epoch-start cost is reported beside it
+        train_set = Subset(ds, list(range(len(ds))) * args.epoch_repeat) if args.epoch_repeat > 1 else ds
+        train = DataLoader(train_set, batch_size=B, shuffle=False, num_workers=args.dataloader_workers, pin_memory=True,
                            drop_last=True, timeout=0, worker_init_fn=None)
         val = DataLoader(Subset(ds, list(range(B))), batch_size=B, shuffle=False, num_workers=args.dataloader_workers,
                          pin_memory=True, drop_last=False, timeout=0, worker_init_fn=None)
@@ -674,7 +679,9 @@ def run_via_trainer(name, cfg, args):
         'config': {'workload': cfg['workload'] + ' -- through ModelTrainer.fit(%s) from in-memory songs (%s)' % (
                        'torch DataLoader(num_workers=%d, pin_memory=True)' % args.dataloader_workers if args.dataloader_workers
                        else 'Dataset.batch_loader(8)', 'float32' if args.float_pcm else '16-bit PCM'),
-                   'dataloader_workers': args.dataloader_workers,
+                   'dataloader_workers': args.dataloader_workers, 'epoch_repeat': args.epoch_repeat,
+                   'epoch_start_ms_per_epoch': 1e3 * trainer.host_times.get('epoch_start', 0.0) / n_epochs,
+                   'fork_guard': {k: v for k, v in _staging._fork_guard.items() if k != 'wanted'},
                    'sync_per_step': 'every batch\'s loss is read on the host and logged, one batch late (ModelTrainer._run)',
                    'decode_threads': args.workers, 'pcm': 'float32' if args.float_pcm else 'int16 (16-bit PCM)',
                    'optimizer_passed': 'deep_audio_mixer_amd.optim.Adam' if args.own_adam else 'torch.optim.Adam (adopted by ModelTrainer)',
@@ -856,6 +863,7 @@ def main():
     ap.add_argument('--pcm-loader', action='store_true', help='--via-trainer: loader yields uploaded PCM, front-end inside the captured step')
     ap.add_argument('--dataloader-workers', type=int, default=0,
                     help='--via-trainer: torch DataLoader(num_workers=N, pin_memory=True) over the Dataset (training.ipynb cell 6 as written)')
+    ap.add_argument('--epoch-repeat', type=int, default=1, help='--dataloader-workers: the clip set is walked R times per epoch')
     ap.add_argument('--own-adam', action='store_true', help='--via-trainer: pass optim.Adam instead of torch.optim.Adam')
     args = ap.parse_args()
     if args.gpus < 1:

@@ -47,6 +47,9 @@ def in_loader_worker():
 # datasets alive in THIS process by their token: a HostPcmBatch that comes back from a worker finds the dataset object
 # the main process holds (the workers' copies are forks whose read counters die with them)
 _live_datasets = weakref.WeakValueDictionary()
+# a DataLoader over one of them forks its workers from the GPU-owning process at the start of every epoch: page-locked host
+# buffers are taken out of what the children inherit (staging.install_fork_guard, include/dam_hip.h dam_host_dontfork_pinned)
+staging.install_fork_guard(lambda: len(_live_datasets) > 0)
 
 
 class MultitrackAudioDataset(data.Dataset):
@@ -474,10 +477,74 @@ class MultitrackAudioDataset(data.Dataset):
             return PcmItem(torch.from_numpy(self._read_item_pcm(song_i, chunk_i)), int(index), self._token,
                            self._aug_seed if self._augment else None, self._normalize, str(self._device))
         tic = time.time()
-        train_features, gt_features = self._process_on_the_fly(song_i, chunk_i, index)
+        item = self._process_on_the_fly(song_i, chunk_i, index)          # (train_features, gt_features)
         if self._verbose:
             print('Features: {}'.format(time.time() - tic))
-        return train_features, gt_features
+        return item
+
+    def __getitems__(self, indices):
+        """What a DataLoader's fetcher calls with the indices of one batch (torch >= 2.0).  In a worker the whole batch is
+        decoded into ONE shared-memory block [B, S+1, n, ch] -- every track read straight to its place, as iter_batches
+        reads into its page-locked slots: no per-item stack, no batch stack (a C3 batch is 38 MB; the two copies were two
+        thirds of a worker's time) -- and the items are its rows; elsewhere, and for anything the block form does not cover
+        (mixed channel counts, the feature cache), the items one by one."""
+        if not (self._compute_features and in_loader_worker()):
+            return [self[i] for i in indices]
+        try:
+            fmt = getattr(self, '_worker_format', None)
+            if fmt is None:
+                fmt = self._worker_format = self.staging_format()
+        except ValueError:
+            return [self[i] for i in indices]
+        kind, ch = fmt
+        K, n = len(self._tracklist), self._chunk_length * self._sr
+        elem = torch.from_numpy(np.empty(0, dtype=kind))
+        shape = (len(indices), K, n, ch)
+        block, state = self._worker_block(elem, shape)
+        view = block.numpy()
+        items = []
+        for b, index in enumerate(indices):
+            song_i, chunk_i = self._calculate_song_index(index)
+            if self._verbose:
+                print('Song {}, chunk {}'.format(self.songlist[song_i], chunk_i))
+            for k, track in enumerate(self._tracklist):
+                self._read_chunk_into(view[b, k], self.songlist[song_i], track, chunk_i * n, (chunk_i + 1) * n)
+            items.append(PcmItem(block[b], int(index), self._token, self._aug_seed if self._augment else None, self._normalize,
+                                 str(self._device), block=(block, b, state)))
+        return items
+
+    SHM_RING = 3          # reusable shared-memory blocks per worker: two prefetched batches + the one the pin thread is copying
+
+    def _worker_block(self, elem, shape):
+        """-> (block [B, S+1, n, ch], state): where a worker decodes a batch.  A FRESH shared-memory segment per batch is what
+        torch's own collate allocates -- and costs a worker more than the decoding: 38 MB = 9,300 first-touch page faults
+        (allocate, zero, charge) per C3 batch, ~40 ms, i.e. six workers deliver a batch every 8 ms to a step that takes 4.3
+        (profiles/r05_dataloader_workers.txt).  So each worker keeps SHM_RING blocks and re-uses one once the consumer has
+        said it is done with it: `state` is a shared int32 word, 1 while the batch is in flight, set back to 0 by
+        HostPcmBatch.pin_memory() after it has copied the block into page-locked memory (the loader's pin thread:
+        pin_memory=True, the notebooks' setting).  A consumer that never pins never releases: the ring's blocks stay with
+        their batches and every further batch gets a fresh segment, as before (state None)."""
+        if data.get_worker_info() is None:
+            return torch.empty(shape, dtype=elem.dtype), None
+
+        def shared(e, sh):
+            numel = 1
+            for d in sh:
+                numel *= d
+            return e.new(e._typed_storage()._new_shared(numel, device=e.device)).resize_(*sh)
+        ring = self.__dict__.setdefault('_shm_ring', [])
+        if ring and (tuple(ring[0][0].shape) != tuple(shape) or ring[0][0].dtype != elem.dtype):
+            return shared(elem, shape), None                      # another shape (a ragged last batch): a one-off segment
+        for block, state in ring:
+            if int(state[0]) == 0:
+                state[0] = 1
+                return block, state
+        if len(ring) < self.SHM_RING:
+            state = shared(torch.empty(0, dtype=torch.int32), (1,))
+            state[0] = 1
+            ring.append((shared(elem, shape), state))
+            return ring[-1]
+        return shared(elem, shape), None
 
     def __len__(self) -> int:
         return self._len
@@ -487,6 +554,8 @@ class MultitrackAudioDataset(data.Dataset):
         behind (iter_batches rebuilds them)."""
         state = dict(self.__dict__)
         state.pop('_staging_cache', None)
+        state.pop('_worker_format', None)
+        state.pop('_shm_ring', None)
         return state
 
     def get_num_songs(self) -> int:
@@ -568,10 +637,13 @@ class PcmItem:
     (mix last; the file's own sample type, data/dataset.py:192-196 without the float64 conversion), the item's global index
     (the key of its augmentation draw), the dataset's token / augmentation seed (None: no augmentation) / normalise flag /
     device.  A batch of them collates into a HostPcmBatch (registered with torch's default collate below)."""
-    __slots__ = ('pcm', 'index', 'token', 'aug_seed', 'normalize', 'device')
+    __slots__ = ('pcm', 'index', 'token', 'aug_seed', 'normalize', 'device', 'block')
 
-    def __init__(self, pcm, index, token, aug_seed, normalize, device):
+    def __init__(self, pcm, index, token, aug_seed, normalize, device, block=None):
         self.pcm, self.index, self.token, self.aug_seed, self.normalize, self.device = pcm, index, token, aug_seed, normalize, device
+        # (batch tensor, position): `pcm` is row `position` of a [B, S+1, n, ch] block that __getitems__ decoded the whole
+        # batch into (shared memory) -- the collate then hands the block on as it is
+        self.block = block
 
     def __iter__(self):
         """(train_features [S,F,T], gt_features [F,T]) -- in the process that owns the GPU; raises in a worker."""
@@ -591,6 +663,12 @@ def collate_pcm_items(batch, *, collate_fn_map=None):
     """torch.utils.data.default_collate for a list of PcmItems -> ONE HostPcmBatch.  Inside a worker the [B, S+1, n, ch]
     block is allocated in shared memory (what torch's own tensor collate does), so the batch crosses the process boundary
     as a file descriptor, not as a pickled copy."""
+    first = batch[0]
+    if first.block is not None and first.block[0].shape[0] == len(batch) and all(
+            b.block is not None and b.block[0] is first.block[0] and b.block[1] == i for i, b in enumerate(batch)):
+        # __getitems__ decoded this very batch straight into one (shared-memory) block: nothing to stack
+        return HostPcmBatch(first.block[0], torch.tensor([b.index for b in batch], dtype=torch.int64), first.token,
+                            first.aug_seed, first.normalize, first.device, release=first.block[2])
     pcms = [b.pcm for b in batch]
     if len({p.dtype for p in pcms}) > 1:         # files of different sample types in one batch: float64 in [-1, 1),
         pcms = [_as_float64(p) for p in pcms]    # what soundfile.read yields at data/dataset.py:194
@@ -603,7 +681,6 @@ def collate_pcm_items(batch, *, collate_fn_map=None):
         storage = elem._typed_storage()._new_shared(elem.numel() * len(pcms), device=elem.device)
         out = elem.new(storage).resize_(len(pcms), *elem.shape)
     clips = torch.stack(pcms, 0, out=out)
-    first = batch[0]
     return HostPcmBatch(clips, torch.tensor([b.index for b in batch], dtype=torch.int64), first.token, first.aug_seed,
                         first.normalize, first.device)
 
@@ -617,23 +694,34 @@ class HostPcmBatch:
         dataset object this process holds, so the draws are those of the ``num_workers=0`` loader in the same order);
       * unpacking (``train_features, gt_features = batch``, model_trainer.py:31-33 / training_ignite.ipynb cell 12) or
         ``features()`` runs the front-end on the uploaded batch: ONE launch for its B*(S+1) tracks."""
-    __slots__ = ('clips', 'items', 'token', 'aug_seed', 'normalize', 'device', 'n_fft', 'hop', '_dev')
+    __slots__ = ('clips', 'items', 'token', 'aug_seed', 'normalize', 'device', 'n_fft', 'hop', 'release', '_dev')
 
-    def __init__(self, clips, items, token, aug_seed, normalize, device, n_fft=2048, hop=1024):
+    def __init__(self, clips, items, token, aug_seed, normalize, device, n_fft=2048, hop=1024, release=None):
         self.clips, self.items, self.token, self.aug_seed, self.normalize, self.device = clips, items, token, aug_seed, normalize, device
-        self.n_fft, self.hop, self._dev = n_fft, hop, None
+        # release: the shared int32 word of a worker's re-usable block (MultitrackAudioDataset._worker_block), or None
+        self.n_fft, self.hop, self.release, self._dev = n_fft, hop, release, None
 
     def __getstate__(self):
-        return (self.clips, self.items, self.token, self.aug_seed, self.normalize, self.device, self.n_fft, self.hop)
+        return (self.clips, self.items, self.token, self.aug_seed, self.normalize, self.device, self.n_fft, self.hop, self.release)
 
     def __setstate__(self, state):
-        (self.clips, self.items, self.token, self.aug_seed, self.normalize, self.device, self.n_fft, self.hop), self._dev = state, None
+        (self.clips, self.items, self.token, self.aug_seed, self.normalize, self.device, self.n_fft, self.hop, self.release) = state
+        self._dev = None
 
     def pin_memory(self):
+        """Called by the DataLoader's pin-memory thread (``pin_memory=True``).  Page-locked memory from torch's caching
+        host allocator, filled by a few plain copy threads -- NOT ``Tensor.pin_memory()``: its copy fans out over every
+        OpenMP thread torch was given (128 on a box whose cgroup grants a 16-core share), the spinning team burns the
+        process's CPU quota and the kernel throttles the whole process for the rest of each 100 ms period (measured here:
+        115 ms per training step instead of 4.4; the same trap as staging._host_copy's)."""
         if self.clips.is_pinned():
             return self
-        return HostPcmBatch(self.clips.pin_memory(), self.items, self.token, self.aug_seed, self.normalize, self.device,
-                            self.n_fft, self.hop)
+        src = self.clips.contiguous()
+        dst = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        staging._host_copy(dst.view(-1).view(torch.uint8), src.view(-1).view(torch.uint8))
+        if self.release is not None:
+            self.release[0] = 0                # the worker may decode its next batch into this block
+        return HostPcmBatch(dst, self.items, self.token, self.aug_seed, self.normalize, self.device, self.n_fft, self.hop)
 
     def draw_gains(self, device):
         """[B, S+1] augmentation gains of this batch's items on `device` (None without augmentation).  Advances the read
@@ -658,6 +746,10 @@ class HostPcmBatch:
                 out = torch.empty(self.clips.shape, dtype=self.clips.dtype, device=dev)
             dst = out[:B]
             dst.copy_(self.clips, non_blocking=True)
+            if self.release is not None and not self.clips.is_pinned():
+                # (a pageable source has been read out when copy_ returns: the worker may re-use its block.  A consumer that
+                # wants the host samples after this call keeps a copy -- `clips` of an un-pinned batch is the worker's block)
+                self.release[0] = 0
             self._dev = PcmBatch(dst, self.draw_gains(dst.device), self.normalize, self.n_fft, self.hop)
         return self._dev
 

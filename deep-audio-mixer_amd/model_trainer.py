@@ -109,8 +109,9 @@ class ModelTrainer:
         self._seen = 0
         self.graph_steps = self.eager_steps = 0       # diagnostic: how the training batches were run
         # diagnostic: where the HOST spent a training epoch's wall time (seconds, summed over fit()): waiting for the loader,
-        # enqueuing the batch's work, waiting for the previous batch's loss
-        self.host_times = {'loader': 0.0, 'enqueue': 0.0, 'loss_wait': 0.0}
+        # enqueuing the batch's work, waiting for the previous batch's loss; 'epoch_start' = the part of 'loader' before an epoch's
+        # FIRST batch arrived (a DataLoader with workers forks them there, every epoch)
+        self.host_times = {'loader': 0.0, 'enqueue': 0.0, 'loss_wait': 0.0, 'epoch_start': 0.0}
 
     # ---- an adopted torch.optim.Adam stays usable by its owner
     def _push_adopted_state(self):
@@ -145,24 +146,30 @@ class ModelTrainer:
                 return False
         return True
 
-    def _pull_adopted_step(self, deep=True):
-        """Whatever the caller did to its own optimizer since the last batch this trainer ran reaches the fused one: a
-        ``load_state_dict`` (hyper-parameters, moments, step count: loaded into the flat buffers, then re-shared as views),
-        or plain ``step()`` calls between two fit()s (the fused one continues from that count)."""
+    def _resync_adopted(self, deep=True):
+        """An ``optimizer.load_state_dict(...)`` on the caller's object since the last batch (hyper-parameters, moments, step
+        count) is loaded into the fused optimizer's flat buffers and re-shared as views.  True if that happened."""
         orig, opt = self._adopted_from, self.optimizer
-        if orig is None:
-            return
-        if not self._adoption_intact(deep):
-            if orig.state:
-                opt.load_state_dict(orig.state_dict())
-            else:                                        # state cleared: a fresh optimizer
-                opt._exp_avg.zero_()
-                opt._exp_avg_sq.zero_()
-                opt._step.zero_()
-            opt.param_groups[0] = orig.param_groups[0]
-            opt._hyper_host = None
-            opt.sync_hyper()
-            self._push_adopted_state()
+        if orig is None or self._adoption_intact(deep):
+            return False
+        if orig.state:
+            opt.load_state_dict(orig.state_dict())
+        else:                                        # state cleared: a fresh optimizer
+            opt._exp_avg.zero_()
+            opt._exp_avg_sq.zero_()
+            opt._step.zero_()
+        opt.param_groups[0] = orig.param_groups[0]
+        opt._hyper_host = None
+        opt.sync_hyper()
+        self._push_adopted_state()
+        return True
+
+    def _pull_adopted_step(self):
+        """Start of a fit(): whatever the caller did to its own optimizer since the last one reaches the fused one -- a
+        ``load_state_dict``, or plain ``step()`` calls (the fused one continues from that count; the caller's per-parameter
+        counts are current here: they are written back at the end of every fit() and by close())."""
+        orig, opt = self._adopted_from, self.optimizer
+        if orig is None or self._resync_adopted():
             return
         steps = {int(st['step']) for st in orig.state.values() if 'step' in st}
         if len(steps) == 1:
@@ -246,9 +253,12 @@ class ModelTrainer:
     def _train_batch(self, batch):
         if hasattr(batch, 'to_device'):                        # data.dataset.HostPcmBatch: decoded clips in host memory
             try:
-                return self._train_batch(self._upload(batch))
+                return self._train_device_batch(self._upload(batch))
             finally:
                 self._uploaded_batch_enqueued()
+        return self._train_device_batch(batch)
+
+    def _train_device_batch(self, batch):
         pcm = batch if hasattr(batch, 'clips') else None       # data.dataset.PcmBatch: uploaded PCM, front-end not run yet
         if pcm is not None:
             feats = target = None
@@ -257,11 +267,10 @@ class ModelTrainer:
         else:
             feats, target = (t.to(self.device) for t in batch)
             shape = (tuple(feats.shape), tuple(target.shape), feats.dtype, self.model.training)
-        if self._adopted_from is not None and not self._adoption_intact(deep=False):
-            self._pull_adopted_step()                # optimizer.load_state_dict() since the last batch
+        self._resync_adopted(deep=False)             # optimizer.load_state_dict() since the last batch?
         if self._graphable and shape == self._shape and (self._step is not None or self._seen >= self.EAGER_BATCHES):
             if self._step is None:
-                self._pull_adopted_step()
+                self._resync_adopted()
                 self._step = self._capture(feats, target, pcm)
             if pcm is not None:
                 self._step.bind_clips(pcm.clips, pcm.gain)       # an 8-byte address word (+ the gain table): no PCM / feature copy
@@ -328,15 +337,17 @@ class ModelTrainer:
 
         step = 0
         ht, clock = self.host_times, time.perf_counter
-        it = iter(loader)
+        t0 = clock()
+        it = iter(loader)                 # (a DataLoader with num_workers > 0 forks its workers here, every epoch)
         while True:
-            t0 = clock()
             try:
                 batch = next(it)
             except StopIteration:
                 break
             step += 1
             t1 = clock()
+            if train and step == 1:
+                ht['epoch_start'] += t1 - t0
             loss = self._train_batch(batch) if train else self._batch_loss(batch)
             if train:
                 ht['loader'] += t1 - t0
@@ -346,6 +357,7 @@ class ModelTrainer:
                 if train and step % _LOG_EVERY == 0 and not quiet:
                     print('[%d/%4d] loss: %.3f' % (step, n, value) if n is not None else '[%d/   ?] loss: %.3f' % (step, value))
                 total += value
+                t0 = clock()
                 continue
             slot = step & 1
             self._loss_host[slot:slot + 1].copy_(loss.detach().reshape(1), non_blocking=True)
@@ -356,6 +368,7 @@ class ModelTrainer:
                 flush()
                 if train:
                     ht['loss_wait'] += clock() - t2
+            t0 = clock()
         while pending:
             flush()
         return total / (n if n is not None else step)

@@ -7,10 +7,13 @@ engine moves buffer k on a dedicated copy stream, and the compute stream only wa
 reverse brings results back.  PyTorch supplies the page-locked memory, the streams and the events; nothing is
 computed here.
 """
+import ctypes
+import os
 import threading
 
 import numpy as np
 import torch
+import torch.utils.data
 
 PIECE_BYTES = 32 << 20
 
@@ -165,3 +168,45 @@ class BatchStager:
         self._issue(k + 1)                                  # travels while the caller's step k runs
         self.k = k + 1
         return self.bufs[k % 2]
+
+
+# ---- fork guard (include/dam_hip.h: dam_host_dontfork_pinned) ---------------------------------------------------------------
+def dontfork_pinned_host_memory():
+    """Marks every page-locked, GPU-mapped host buffer of this process MADV_DONTFORK -> (mappings, bytes) marked.  A no-op
+    (0, 0) where there is nothing to protect or nothing may be asked of the GPU runtime: before it is initialised, and in a
+    forked child."""
+    if not torch.cuda.is_initialized() or torch.cuda._is_in_bad_fork() or torch.utils.data.get_worker_info() is not None:
+        return 0, 0
+    from . import _lib
+    n, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().dam_host_dontfork_pinned(ctypes.byref(n), ctypes.byref(b)), 'dam_host_dontfork_pinned')
+    return n.value, b.value
+
+
+_fork_guard = {'installed': False, 'wanted': [], 'calls': 0, 'mappings': 0, 'bytes': 0}
+
+
+def _before_fork():
+    """os.register_at_fork(before=...): runs in the forking (GPU-owning) process for every os.fork() -- the start of each
+    DataLoader worker.  Without it every fork write-protects torch's pinned blocks (user-pointer memory to the GPU driver),
+    the driver evicts the process's queues and the device idles for hundreds of milliseconds per fork."""
+    g = _fork_guard
+    if os.environ.get('DAM_FORK_GUARD', '1') == '0' or not any(w() for w in g['wanted']):
+        return
+    try:
+        n, b = dontfork_pinned_host_memory()
+    except Exception:            # noqa: BLE001 -- a fork must never fail because of the guard
+        return
+    g['calls'] += 1
+    g['mappings'], g['bytes'] = n, b
+
+
+def install_fork_guard(wanted):
+    """wanted: a callable -> bool, asked at every fork (data.dataset: "is a MultitrackAudioDataset alive in this process?").
+    With ``DAM_FORK_GUARD=0`` in the environment the guard stays off (a program that hands PINNED tensors to forked
+    children to read needs that: the children would not inherit them)."""
+    g = _fork_guard
+    g['wanted'].append(wanted)
+    if not g['installed']:
+        os.register_at_fork(before=_before_fork)
+        g['installed'] = True

@@ -50,9 +50,24 @@ struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 /* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
  * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
  * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
-#define DAM_ABI_VERSION 12
+#define DAM_ABI_VERSION 13
 const char* dam_arch(void);
 int dam_abi_version(void);
+
+/* Host-side fork guard for the loaders of the reference's notebooks: training.ipynb cell 6 / training_ignite.ipynb cell 6 build
+ * DataLoader(d_train, num_workers=6, pin_memory=True) over data/dataset.py:270-292, i.e. the process that owns the GPU forks
+ * six workers at the start of EVERY epoch.  On this stack page-locked host memory (hipHostMalloc: torch's pinned tensors,
+ * the runtime's staging buffers) is anonymous memory registered with the GPU as user pointers and NOT marked MADV_DONTFORK:
+ * a fork write-protects it for copy-on-write, the driver's MMU notifier evicts the process's GPU queues and restores them
+ * only later -- measured 0.2-0.6 s of GPU stall per fork batch in a toy process, 4-5 s per epoch in the C3 training loop
+ * (profiles/r05_fork_stall.txt).  This call marks the private anonymous mappings of the calling process that ARE page-locked
+ * data buffers handed out by the HIP layer (hipPointerGetAttributes: hipMemoryTypeHost; extent from hsa_amd_pointer_info)
+ * MADV_DONTFORK: children forked afterwards do not inherit those buffers (they cannot use the GPU anyway) and the fork no
+ * longer write-protects them.  The runtime's internal pools are left alone (a child that runs a destructor of an inherited
+ * GPU object reads them).  No device pointers, no stream, nothing enqueued; call it from the GPU-owning process only, after
+ * the runtime is initialised.
+ *   n_mappings_host / n_bytes_host : optional outputs, ranges and bytes marked by this call (re-marking is harmless). */
+int dam_host_dontfork_pinned(int64_t* n_mappings_host, int64_t* n_bytes_host);
 
 /* ---------------------------------------------------------------------------------
  * Feature front-end.  Replaces data/dataset.py:132-162 (compute_features: torch.stft ->
