@@ -60,6 +60,46 @@ def free_port():
     return p
 
 
+class ProgressWatchdog:
+    """An N-rank run must not hang a whole node silently: every rank names the phase it enters (`phase(...)`); if NO new
+    phase is entered for `timeout_s` seconds a daemon thread prints the rank and its last phase to stderr and ends the
+    process with exit code 3 (os._exit from a plain thread: no GPU call, no re-exec; torch.distributed.run then stops the
+    other ranks and the parent returns non-zero).  The collectives' own timeout (init_process_group(timeout=)) is set to
+    the same figure; this is the backstop for a hang that is not inside a collective.  timeout_s <= 0: off."""
+
+    def __init__(self, timeout_s, rank=0):
+        import threading
+        self.timeout_s, self.rank = float(timeout_s), rank
+        self.last, self.since, self.history = 'start', time.monotonic(), []
+        self._lock = threading.Lock()
+        if self.timeout_s > 0:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def phase(self, name):
+        with self._lock:
+            self.history.append((self.last, round(time.monotonic() - self.since, 3)))
+            self.last, self.since = name, time.monotonic()
+
+    def _watch(self):
+        while True:
+            time.sleep(min(1.0, max(0.05, self.timeout_s / 4)))
+            with self._lock:
+                idle, last = time.monotonic() - self.since, self.last
+            if idle > self.timeout_s:
+                sys.stderr.write('bench.py: rank %d made no progress for %.0f s in phase "%s" (phases so far: %s) -- giving up '
+                                 '(exit 3)\n' % (self.rank, idle, last, ', '.join('%s %.1fs' % h for h in self.history[-8:])))
+                sys.stderr.flush()
+                os._exit(3)
+
+
+def dist_timeout_s():
+    """Seconds a rank may sit in one phase / one collective (DAM_DIST_TIMEOUT_S, default 300)."""
+    try:
+        return float(os.environ.get('DAM_DIST_TIMEOUT_S', '300'))
+    except ValueError:
+        return 300.0
+
+
 def visible_gpu_count():
     """GPUs this process may use, WITHOUT touching a GPU runtime (the parent of an N-rank run must not initialise the
     device before it starts its children): the KFD topology nodes that have SIMDs (CPUs have none) and whose DRM render
@@ -428,12 +468,17 @@ def run_train(name, cfg, args):
     dev_index = local % max(n_dev, 1)                  # gloo rehearsal only: more ranks than GPUs share a device
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
+    dog = ProgressWatchdog(dist_timeout_s() if world > 1 else 0, rank)
     if world > 1:
+        import datetime
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dog.phase('init_process_group(%s)' % backend)
+        limit = datetime.timedelta(seconds=max(1.0, dist_timeout_s()))
         if backend == 'nccl':
-            torch.distributed.init_process_group('nccl', device_id=device)
+            torch.distributed.init_process_group('nccl', device_id=device, timeout=limit)
         else:
-            torch.distributed.init_process_group(backend)
+            torch.distributed.init_process_group(backend, timeout=limit)
+    dog.phase('build + first barrier')
 
     import deep_audio_mixer_amd  # noqa: F401
     from deep_audio_mixer_amd import build
@@ -448,6 +493,7 @@ def run_train(name, cfg, args):
     S, B, hop = cfg['n_stems'], cfg['batch'], cfg['hop']
     n = cfg['sr'] * cfg['seconds']
     t_frames = 1 + n // hop
+    dog.phase('model + broadcast')
     model = build_model(cfg, device)
     if world > 1:     # identical replicas: broadcast rank 0's parameters and buffers
         for t in list(model.parameters()) + list(model.buffers()):
@@ -457,6 +503,7 @@ def run_train(name, cfg, args):
     clips = synth_clips(n_resident, S, n, device, 1234 + rank)
     step = TrainStep(model, opt, S, n, CHANNELS, B, N_FFT, hop, use_graph=not args.no_graph, overlap=not args.no_overlap)
     step.load_clips(clips[:B])
+    dog.phase('eager warm-up steps + graph capture')
     step.capture(warmup=2)
 
     def run(k, first):
@@ -489,8 +536,10 @@ def run_train(name, cfg, args):
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
+    dog.phase('warm-up steps')
     run(args.warmup, 0)
     step.measure_exposed = world > 1
+    dog.phase('timed region (%d steps)' % args.steps)
     dt = timed(run, args.steps, args.warmup)
     exposed = step.exposed_wait_ms()
     step.measure_exposed = False
@@ -498,6 +547,7 @@ def run_train(name, cfg, args):
     frames_per_step = step.frames_per_step * world
     value = frames_per_step * args.steps / dt
     # the same region repeated (diagnostic: run-to-run spread of a 0.1 s region; `value` stays the region above)
+    dog.phase('repeat regions + per-rank clocks')
     reps = [1e3 * timed(run, args.steps, args.warmup + (r + 1) * args.steps) / args.steps for r in range(args.repeat)]
     rank_ms = 1e3 * local_time(run, args.steps, 0) / args.steps
     if world > 1:
@@ -506,6 +556,30 @@ def run_train(name, cfg, args):
     else:
         allr = [(rank_ms, exposed)]
     gflop_step = cfg['gflop_fwd'] * 2.98 * B            # fwd+bwd algorithmic FLOPs per rank and step (SURVEY 8d ratio)
+    # N > 1, staged step: does overlapping the big bucket's all-reduce with graph A2 PAY?  The strip kernels of A2 are sized 248
+    # workgroups for 256 CUs and a kernel that shares their CUs slows them (side-stream weight gradients, every
+    # big kernel 1.3-1.7x longer) -- RCCL's kernels will sit exactly there.  So the same invocation times two more regions over
+    # the SAME three graphs: the all-reduces beside A2 (as `value` was measured) and both started only after A2, each with
+    # HIP events around graph A2.  One SCALE record then says which schedule the node prefers and what the overlap cost A2.
+    overlap_ab = None
+    if world > 1 and step.staged and step._graphs is not None and len(step._graphs) == 3:
+        dog.phase('overlap A/B regions')
+        ab = {}
+        for label, ov in (('overlapped', True), ('serialized', False)):
+            step.overlap_reduce, step.measure_a2, step.measure_exposed = ov, True, True
+            d = timed(run, args.steps, args.warmup)
+            a2, ex = step.a2_ms(), step.exposed_wait_ms()
+            got = [None] * world
+            torch.distributed.all_gather_object(got, (a2, ex))
+            ab[label] = {'ms_per_step': 1e3 * d / args.steps, 'graph_A2_ms': [g[0] for g in got],
+                         'exposed_allreduce_wait_ms': [g[1] for g in got]}
+        step.overlap_reduce, step.measure_a2, step.measure_exposed = True, False, False
+        a2o, a2s = max(ab['overlapped']['graph_A2_ms']), max(ab['serialized']['graph_A2_ms'])
+        overlap_ab = dict(ab, overlap_pays=bool(ab['overlapped']['ms_per_step'] < ab['serialized']['ms_per_step']),
+                          graph_A2_slowdown_from_overlap=(a2o / a2s if a2s else None),
+                          note='same three graphs; "serialized" starts both all-reduces after graph A2 has been enqueued; '
+                               'graph_A2_ms = HIP events around graph A2 per rank (events are recorded in these two regions only)')
+    dog.phase('replica sync proof')
     sync = replica_sync_proof(model, opt, device, dev_index, world)
 
     result = {
@@ -535,11 +609,17 @@ def run_train(name, cfg, args):
                               # device time between the end of backward (graph A2) and both buckets having arrived: the part of
                               # the all-reduce that did NOT hide behind backward, per step
                               'exposed_allreduce_wait_ms': [a[1] for a in allr]}
+    if overlap_ab is not None:
+        result['overlap_ab'] = overlap_ab
+    if world > 1:
+        result['config']['dist_timeout_s'] = dist_timeout_s()
     if args.breakdown and world > 1:
+        dog.phase('breakdown')
         result['breakdown'] = ddp_breakdown(step, device)
     # the same steps fed from page-locked HOST memory (512 clips in pinned host memory): batch k+1 is uploaded on
     # a copy stream while step k runs.  PCIe-inclusive: reported beside `value`, never as `value`.
     if not args.no_host_stream:
+        dog.phase('host-streamed region')
         n_host = max(2 * B, min(N_HOST_CLIPS, args.host_clips) // B * B)
         host = torch.empty((n_host, S + 1, n, CHANNELS), dtype=torch.float32, pin_memory=True)
         for lo in range(0, n_host, n_resident):
@@ -557,6 +637,7 @@ def run_train(name, cfg, args):
                                     'host_clips_pinned': n_host, 'h2d_bytes_per_step': float(host[:B].numel() * 4),
                                     'note': 'batch k+1 uploaded from page-locked host memory on a copy stream during step k'}
         del host, stager
+    dog.phase('roofline probe / cpu baseline (rank 0)')
     if rank == 0 and not args.no_roofline:
         result['roofline'] = roofline_object(name, cfg, device, t_frames)
         result['roofline_extra'] = {'whole_step_tflops': gflop_step * 1e9 * args.steps / dt / 1e12,
@@ -564,8 +645,12 @@ def run_train(name, cfg, args):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(cfg)
     if rank == 0:
+        result['config']['phases_s'] = {h[0]: h[1] for h in dog.history[1:]}
         print(json.dumps(result), flush=True)
     if world > 1:
+        dog.phase('final barrier + destroy_process_group')
+        # the other ranks wait here while rank 0 runs its roofline probe: the watchdog covers it, the barrier has the timeout
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -69,6 +69,9 @@ class TrainStep:
         # kept alive here, so after a replay they hold that step's values (read them before the next step)
         self.masked = self.gains = None
         self.measure_exposed, self._exposed = False, []
+        # N-rank diagnostics (bench.py's overlap_ab): overlap_reduce=False starts BOTH all-reduces only after graph A2 has been
+        # enqueued (the same three graphs, the exchange not beside backward); measure_a2 brackets graph A2 with HIP events
+        self.overlap_reduce, self.measure_a2, self._a2 = True, False, []
         self.frames_per_step = batch * n_stems * t          # BASELINE metric unit: stem-spectrogram frames
         self.staged = optimizer.world_size > 1 and overlap
         if self.staged:
@@ -291,6 +294,17 @@ class TrainStep:
         self._exposed = []
         return ms
 
+    def a2_ms(self):
+        """Mean device time of graph A2 (backward of the shallow layers) per step while measure_a2 was on; None if nothing was
+        measured.  With the big bucket's all-reduce beside it (overlap_reduce) against alone: what the overlap costs backward.
+        Synchronises."""
+        if not self._a2:
+            return None
+        torch.cuda.synchronize(self.device)
+        ms = sum(a.elapsed_time(b) for a, b in self._a2) / len(self._a2)
+        self._a2 = []
+        return ms
+
     def __call__(self):
         """Runs one step on the data currently in the static buffers; returns the (device) loss tensor."""
         self.opt.sync_hyper()
@@ -305,8 +319,16 @@ class TrainStep:
             g[1].replay()
         else:
             g[0].replay()
-            w1 = self.opt.all_reduce_grads(1, async_op=True)      # RCCL's stream: runs beside graph A2
+            w1 = self.opt.all_reduce_grads(1, async_op=True) if self.overlap_reduce else None     # RCCL's stream: runs beside graph A2
+            if self.measure_a2:
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
             g[1].replay()
+            if self.measure_a2:
+                a1.record()
+                self._a2.append((a0, a1))
+            if w1 is None:
+                w1 = self.opt.all_reduce_grads(1, async_op=True)
             w0 = self.opt.all_reduce_grads(0, async_op=True)
             if self.measure_exposed:      # device time from the end of backward to both buckets being there
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

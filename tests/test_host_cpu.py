@@ -449,3 +449,28 @@ def test_pcm_items_collate_mixed_sample_types_and_pickle():
     assert torch.equal(back.clips, same.clips) and back.token == 77 and back._dev is None
     with pytest.raises(ValueError, match='one shape'):
         collate_pcm_items([a, PcmItem(torch.zeros((1, 2, 2), dtype=torch.int16), 6, 77, None, False, 'cuda')])
+
+
+def test_bench_watchdog_names_the_phase_and_exits_nonzero():
+    """bench.py's backstop for a multi-rank hang: a rank that enters no new phase within the limit prints its rank and last
+    phase and ends with exit code 3 (a plain os._exit from a watcher thread -- no GPU call, no re-exec); a rank that keeps
+    moving is left alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, time; sys.path.insert(0, %r); import bench\n'
+            'w = bench.ProgressWatchdog(0.4, rank=5)\n'
+            'for k in range(4):\n'
+            '    w.phase("moving %%d" %% k); time.sleep(0.2)\n'
+            'w.phase("all-reduce that never returns"); time.sleep(30)\n' % root)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert 'rank 5' in r.stderr and 'all-reduce that never returns' in r.stderr and 'moving 3' in r.stderr
+    import bench
+    os.environ['DAM_DIST_TIMEOUT_S'] = '12.5'
+    try:
+        assert bench.dist_timeout_s() == 12.5
+    finally:
+        del os.environ['DAM_DIST_TIMEOUT_S']
+    assert bench.dist_timeout_s() == 300.0
+    assert bench.ProgressWatchdog(0, rank=0).timeout_s == 0          # off: no thread, phase() still records

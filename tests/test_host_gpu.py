@@ -482,6 +482,14 @@ def _bench_two_ranks(backend):
     # gradient buckets were summed over both ranks
     assert cfg['replicas_in_sync'] is True and len(cfg['replica_checksums']['flat_params_weighted']) == 2
     assert len(cfg['rank_devices']) == 2
+    # one record answers "does the overlap pay on this node": the same three graphs timed with the all-reduces beside graph A2
+    # and after it, graph A2's own device time in both, per rank
+    ab = out['overlap_ab']
+    for label in ('overlapped', 'serialized'):
+        assert ab[label]['ms_per_step'] > 0 and len(ab[label]['graph_A2_ms']) == 2 and all(v > 0 for v in ab[label]['graph_A2_ms'])
+        assert len(ab[label]['exposed_allreduce_wait_ms']) == 2
+    assert isinstance(ab['overlap_pays'], bool) and ab['graph_A2_slowdown_from_overlap'] > 0
+    assert cfg['dist_timeout_s'] > 0 and 'timed region (3 steps)' in cfg['phases_s']
     return out
 
 
