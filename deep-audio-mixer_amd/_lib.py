@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('DAM_LIB_PATH') or os.path.join(_HERE, 'libdam_hip.so'
 # include/dam_hip.h: bumped whenever a C signature changes (together with dam_abi_version() in csrc/dam_api.hip and
 # DAM_ABI_VERSION in the header).  libdam_hip.so is git-ignored and travels prebuilt: a stale one would read device pointers
 # as streams, so lib() refuses it instead of launching.
-EXPECTED_ABI = 13
+EXPECTED_ABI = 14
 
 _STATUS = {0: 'DAM_OK', -1: 'DAM_ERR_BAD_ARG', -2: 'DAM_ERR_UNSUPPORTED', -3: 'DAM_ERR_LAUNCH',
            -4: 'DAM_ERR_WORKSPACE'}
@@ -46,6 +46,7 @@ SIGNATURES = {
     'dam_wgrad_queue_init': (c_i, [c_p]),
     'dam_wgrad_queue_pending': (c_i, [c_p]),
     'dam_wgrad_queue_flush': (c_i, [c_p, c_p]),
+    'dam_wgrad_queue_set_batching': (c_i, [c_p, c_i]),
     'dam_bn_workspace_floats': (c_i64, [c_i]),
     'dam_bn_stats_f32': (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'dam_bn_finalize_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),

@@ -142,8 +142,16 @@ __device__ __forceinline__ void rows_commit(unsigned char* smem, const float4 (&
 // pinned between the MFMAs with sched_group_barrier), so what the write-out does is compile time: with EPI == 0, SO = 1 raw
 // store, 2 raw + BatchNorm partial statistics, 3 + bias, max(., floor) [folded inference convolution], 4 as 3 + residual,
 // 5 + residual * (mask > 0); with EPI >= 1 the sums epilogues as above (SO = 1).
+// DAM_STRIP_2WG (experiment, profiles/r05_strip_two_per_cu.txt): the self-overlapped 16-channel forms compiled for FOUR waves per
+// SIMD (<= 128 registers; the second __launch_bounds__ argument is HIP's minimum waves per execution unit) so that two 8-wave
+// workgroups share a CU -- one's prologue, loader stalls and tail under the other's MFMA stream.
+#ifdef DAM_STRIP_2WG
+#define DAM_STRIP_WAVES_PER_EU(SO_, EPI_, NCH_) (((SO_) && (EPI_) <= DAM_STRIP_2WG && (NCH_) == 1) ? 4 : 1)
+#else
+#define DAM_STRIP_WAVES_PER_EU(SO_, EPI_, NCH_) 1
+#endif
 template <int MB, int NB, int NCH, bool T33, bool LW, int EPI, int SO>
-__global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
+__global__ __launch_bounds__(SO ? 512 : STRIP_THREADS, DAM_STRIP_WAVES_PER_EU(SO, EPI, NCH)) void conv_strip_kernel(const ConvGeo g, const StripGeo sg, const float* __restrict__ X,
                                                          const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                          float* __restrict__ Y, const float* __restrict__ res,
                                                          const float* __restrict__ res_mask, float* __restrict__ stats,
@@ -398,8 +406,12 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
         // are there long before slot 0 ends (requested after the prologue, the first barrier waited 1.3-3.4 k cycles for them)
         DAM_STRIP_REQUEST0(lv0, dst0, cc0, lvc0);
         if (grp == LGRP) {
+#ifdef DAM_STRIP_ONE_SET       // experiment: ONE register set, the rows of tile s+2 are requested in slot s (one slot ahead, not two)
+            DAM_STRIP_REQUEST(1, lvA, dstA, ccA, lvcA);
+#else
             DAM_STRIP_REQUEST(1, lvB, dstB, ccB, lvcB);
             DAM_STRIP_REQUEST(2, lvA, dstA, ccA, lvcA);
+#endif
         }
     } else {
         rows_issue(rl, lo0, hi0, 0, wave, NT / 64, lane, lv, ldst, laff);
@@ -500,6 +512,23 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
         }
         // slots come in pairs (n_slots is even) so that no load sits inside a conditional: the compiler then knows that the
         // set being written is the older of the two in flight and waits with vmcnt(pieces of the other set), not vmcnt(0)
+#ifdef DAM_STRIP_ONE_SET
+        if constexpr (SO != 0) {
+        for (int s = 0; s < n_slots; s += 2) {
+            DAM_STRIP_COMMIT(lvA, dstA, ccA, lvcA);       // tile s+1
+            DAM_STRIP_REQUEST(s + 2, lvA, dstA, ccA, lvcA);
+            SO_TABLE(s + 2);
+            DAM_STAMP(4);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            DAM_STRIP_COMMIT(lvA, dstA, ccA, lvcA);       // tile s+2
+            DAM_STRIP_REQUEST(s + 3, lvA, dstA, ccA, lvcA);
+            SO_TABLE(s + 3);
+            DAM_STAMP(4);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        } else
+#endif
+        {
         for (int s = 0; s < n_slots; s += 2) {
             DAM_STRIP_COMMIT(lvB, dstB, ccB, lvcB);       // tile s+1
             DAM_STRIP_REQUEST(s + 3, lvB, dstB, ccB, lvcB);
@@ -511,6 +540,7 @@ __global__ __launch_bounds__(SO ? 512 : STRIP_THREADS) void conv_strip_kernel(co
             if constexpr (SO != 0) SO_TABLE(s + 3);
             DAM_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         }
 #undef DAM_STRIP_REQUEST
 #undef DAM_STRIP_REQUEST0
@@ -1324,6 +1354,13 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
     // workgroup, at most 64) gave C5's batch of 59 chunks 295 and 531 workgroups -- a second and third round for a fraction of
     // the chip: 512 and 384 us per launch where 236 workgroups of 66 tiles / 472 of 66 need 290 / 270.
     int tpw = sg.tiles_m;
+    int64_t slots = 256;
+#ifdef DAM_STRIP_2WG
+    // two co-resident workgroups per CU for the instantiations compiled that way (16 channels, self-overlapped, LDS <= 80 KB)
+    if (g.nchunks == 1 && MB == 4 && NB == 1 && g.nA == 3 && g.nB == 3 && g.s == 1 && g.step_w == 1 && !wide && !getenv("DAM_STRIP_PINGPONG") &&
+        (lds + 2048) * 2 <= 160 * 1024 && (bwd.x ? (res ? (bwd.mask_bits ? 3 : 2) : 1) : 0) <= DAM_STRIP_2WG)
+        slots = 512;
+#endif
     {
         const int64_t per_image = cdiv(nblk, NB);
         int64_t best = INT64_MAX;
@@ -1331,7 +1368,7 @@ int conv_strip_try(ConvGeo& g_in, int h_lo, int h_hi, const float* X, const floa
             const int t = (int)cdiv(sg.tiles_m, strips);
             if (t < 2 && sg.tiles_m >= 2) break;                      // the loaders' slot loop wants two tiles per workgroup
             const int64_t wgs = (int64_t)cdiv(sg.tiles_m, t) * g.B * per_image;
-            const int64_t cost = cdiv(wgs, 256) * (t + 2);
+            const int64_t cost = cdiv(wgs, slots) * (t + 2);
             if (cost < best) { best = cost; tpw = t; }
         }
     }

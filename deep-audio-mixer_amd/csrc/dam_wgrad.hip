@@ -17,6 +17,7 @@
 //   * a second kernel sums the slabs in a fixed order (deterministic, no float atomics) and writes
 //     torch's [O][I][KH][KW] layout.
 #include <cstdlib>
+#include <string.h>
 #include "dam_common.h"
 #include "dam_conv_stage.h"
 
@@ -38,16 +39,32 @@ struct WgradGeo {
     int TMW;                 // pixels per tile (a multiple of 16, <= 256): 4 waves x TMW/4 pixels
 };
 
+// Weight gradients of ONE geometry batched into one launch of the tile kernel (blockIdx.z = job): the three equal convolutions of
+// a deep ResNet stage (models/model_resnet.py:14-21 at 256 / 128 channels) are 20-28 us launches of which ~13 us are launch and
+// pipeline fill; one launch of three jobs pays that once and needs a third of the pixel splits (slabs) to fill the chip.
+constexpr int WG_MAX_JOBS = 4;
+struct WgradJobs {
+    const float* X[WG_MAX_JOBS];
+    const float* dY[WG_MAX_JOBS];
+    const float* sc[WG_MAX_JOBS];
+    const float* sh[WG_MAX_JOBS];
+    float* partial[WG_MAX_JOBS];
+    int relu_in[WG_MAX_JOBS];             // per job (with sc): a block's conv2 reads relu(bn1(c1)), its conv1 the plain block input
+};
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 template <int TNB, int TKB, int TA, int TB>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const float* __restrict__ X,
-                                                    const float* __restrict__ dY, const float* __restrict__ in_scale,
-                                                    const float* __restrict__ in_shift, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const WgradJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const float* __restrict__ X = jobs.X[blockIdx.z];
+    const float* __restrict__ dY = jobs.dY[blockIdx.z];
+    const float* __restrict__ in_scale = jobs.sc[blockIdx.z];
+    const float* __restrict__ in_shift = jobs.sh[blockIdx.z];
+    float* __restrict__ partial = jobs.partial[blockIdx.z];
     constexpr int NBLK = TNB * TKB * TA * TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -63,7 +80,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const floa
 
     PatchGeo pg;
     pg.H = g.H; pg.W = g.W; pg.C = g.C; pg.s = g.s; pg.c0 = g.c0; pg.PR = g.PR; pg.PWin = g.PWin; pg.PWs = g.PWs;
-    pg.PWT = g.PWT; pg.in_nchw = g.in_nchw; pg.relu_in = g.relu_in;
+    pg.PWT = g.PWT; pg.in_nchw = g.in_nchw; pg.relu_in = jobs.relu_in[blockIdx.z];
 
     v4f acc[NBLK];
 #pragma unroll
@@ -298,9 +315,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBat
 }
 
 // Host side of a caller-owned queue of deferred reductions (include/dam_hip.h: dam_wgrad_queue_*).
+struct WgradQueue;
+// tile-kernel launches of one geometry recorded, not yet launched (dam_wgrad_queue_set_batching)
+struct PendingTile {
+    int njobs;                               // 0: nothing pending
+    int sig;                                 // the instantiation: TNB | TKB << 4 | TA << 8 | TB << 12
+    WgradGeo g;                              // shared geometry, nsplit = 0 (decided at launch from the number of jobs)
+    WgradJobs jobs;
+    float* dw[WG_MAX_JOBS];
+    int64_t ws_floats[WG_MAX_JOBS];
+    int n_real[WG_MAX_JOBS], k_real[WG_MAX_JOBS];
+    int (*launch)(WgradQueue*, hipStream_t);
+};
 struct WgradQueue {
     unsigned magic;
+    int batching;                            // 1: same-geometry tile launches may wait for each other until the flush
     ReduceBatch batch;
+    PendingTile pend;
 };
 constexpr unsigned WGRAD_QUEUE_MAGIC = 0x57475251u;     // "WGRQ"
 
@@ -1220,19 +1251,18 @@ int launch_wgrad_direct(int B, int H, int W, int C, int Ho, int Wo, int N, int s
     return reduce_submit(queue, partial, dw, nsplit, nx, TNB, TKB, KH, KW, n_real, k_real, KH, KW, 1, tiles_k, st);
 }
 
+// One launch of the tile kernel for `njobs` weight gradients of geometry g (blockIdx.z = job), then their slab reductions.
 template <int TNB, int TKB, int TA, int TB>
-int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, const float* sh, float* partial,
-                 int64_t ws_floats, float* dw, int n_real, int k_real, void* queue, hipStream_t st) {
+int launch_wgrad_jobs(WgradGeo g, const WgradJobs& jobs, int njobs, int64_t ws_floats, float* const* dw, const int* n_real,
+                      const int* k_real, void* queue, hipStream_t st) {
     constexpr int NBLK = TNB * TKB * TA * TB;
-    g.tiles_n = (int)cdiv(g.nblk, TNB);
-    g.tiles_k = (int)cdiv(g.nchunks, TKB);
-    g.tap_groups = (int)cdiv(g.KH, TA);
     const int nx = g.tiles_n * g.tiles_k * g.tap_groups;
     // Pixel split by MAKESPAN: every CU works through ceil(workgroups / 256) workgroups of ceil(total_tiles / nsplit) tiles each
     // (co-resident workgroups share the matrix pipe, so it is the count per CU that matters).  The first rule -- at least 512
     // workgroups -- gave the 9x9 / 64 -> 128 layer of the scalar models 72 x 8 = 576 workgroups of 40 tiles: a third round for a
     // quarter of the chip (1.64 ms); 72 x 7 = 504 of 46 tiles is two rounds.  DAM_WG_NSPLIT_OLD keeps the first rule (A/B).
-    int nsplit = (int)cdiv(512, nx);
+    // Batched jobs multiply the workgroups, not the tiles of one: three jobs need a third of the splits -- and slabs.
+    int nsplit = (int)cdiv(512, (int64_t)nx * njobs);
     if (nsplit > g.total_tiles) nsplit = g.total_tiles;
     if (nsplit < 1) nsplit = 1;
     static const bool old_rule = getenv("DAM_WG_NSPLIT_OLD") != nullptr;
@@ -1248,8 +1278,8 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
         // under the former cap of 64: 170 us for 0.15 GFLOP)
         const int hi = g.total_tiles < 512 ? g.total_tiles : 512;
         for (int ns = 1; ns <= hi; ++ns) {
-            const int64_t wgs = (int64_t)nx * ns;
-            if (wgs * NBLK * 256 > ws_floats && ns > 1) break;
+            const int64_t wgs = (int64_t)nx * ns * njobs;
+            if ((int64_t)nx * ns * NBLK * 256 > ws_floats && ns > 1) break;
             const double cost = (double)cdiv(wgs, slots) * ((double)cdiv(g.total_tiles, ns) + 1.0);   // + 1: per-workgroup fixed part
             if (cost < best * 0.999) { best = cost; nsplit = ns; }
         }
@@ -1269,9 +1299,59 @@ int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, 
             raised = true;
         }
     }
-    hipLaunchKernelGGL((wgrad_kernel<TNB, TKB, TA, TB>), dim3(nx, nsplit), dim3(256), lds, st, g, X, dY, sc, sh, partial);
+    hipLaunchKernelGGL((wgrad_kernel<TNB, TKB, TA, TB>), dim3(nx, nsplit, njobs), dim3(256), lds, st, g, jobs);
     DAM_CHECK_LAUNCH();
-    return reduce_submit(queue, partial, dw, g.nsplit, nx, TNB, TKB, TA, TB, n_real, k_real, g.KH, g.KW, g.tap_groups, g.tiles_k, st);
+    for (int i = 0; i < njobs; ++i) {
+        const int rc = reduce_submit(queue, jobs.partial[i], dw[i], g.nsplit, nx, TNB, TKB, TA, TB, n_real[i], k_real[i], g.KH, g.KW,
+                                     g.tap_groups, g.tiles_k, st);
+        if (rc != DAM_OK) return rc;
+    }
+    return DAM_OK;
+}
+
+// The recorded tile launches of a queue, as one launch (and nothing pending afterwards, whatever the outcome).
+template <int TNB, int TKB, int TA, int TB>
+int launch_pending_tile(WgradQueue* q, hipStream_t st) {
+    PendingTile& p = q->pend;
+    const int n = p.njobs;
+    p.njobs = 0;
+    if (n <= 0) return DAM_OK;
+    int64_t ws = p.ws_floats[0];
+    for (int i = 1; i < n; ++i) ws = p.ws_floats[i] < ws ? p.ws_floats[i] : ws;
+    return launch_wgrad_jobs<TNB, TKB, TA, TB>(p.g, p.jobs, n, ws, p.dw, p.n_real, p.k_real, q, st);
+}
+
+template <int TNB, int TKB, int TA, int TB>
+int launch_wgrad(WgradGeo& g, const float* X, const float* dY, const float* sc, const float* sh, float* partial,
+                 int64_t ws_floats, float* dw, int n_real, int k_real, void* queue, hipStream_t st) {
+    g.tiles_n = (int)cdiv(g.nblk, TNB);
+    g.tiles_k = (int)cdiv(g.nchunks, TKB);
+    g.tap_groups = (int)cdiv(g.KH, TA);
+    g.nsplit = 0;
+    const int relu_in = g.relu_in;
+    g.relu_in = 0;                           // travels per job, not in the shared geometry
+    WgradQueue* q = static_cast<WgradQueue*>(queue);
+    if (q && q->magic != WGRAD_QUEUE_MAGIC) return DAM_ERR_BAD_ARG;
+    if (q && q->batching) {
+        // record instead of launching: jobs of the same instantiation and geometry wait for each other until the queue is
+        // flushed (or another geometry arrives); the caller keeps X, dY, the affine and the slabs valid until then
+        PendingTile& p = q->pend;
+        constexpr int sig = TNB | TKB << 4 | TA << 8 | TB << 12;
+        if (p.njobs > 0 && (p.sig != sig || memcmp(&p.g, &g, sizeof(WgradGeo)) != 0 || p.njobs == WG_MAX_JOBS)) {
+            const int rc = p.launch(q, st);
+            if (rc != DAM_OK) return rc;
+        }
+        const int i = p.njobs++;
+        p.sig = sig; p.g = g; p.launch = &launch_pending_tile<TNB, TKB, TA, TB>;
+        p.jobs.X[i] = X; p.jobs.dY[i] = dY; p.jobs.sc[i] = sc; p.jobs.sh[i] = sh; p.jobs.partial[i] = partial;
+        p.jobs.relu_in[i] = relu_in;
+        p.dw[i] = dw; p.ws_floats[i] = ws_floats; p.n_real[i] = n_real; p.k_real[i] = k_real;
+        return DAM_OK;
+    }
+    WgradJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    jobs.X[0] = X; jobs.dY[0] = dY; jobs.sc[0] = sc; jobs.sh[0] = sh; jobs.partial[0] = partial; jobs.relu_in[0] = relu_in;
+    return launch_wgrad_jobs<TNB, TKB, TA, TB>(g, jobs, 1, ws_floats, &dw, &n_real, &k_real, queue, st);
 }
 
 }  // namespace
@@ -1282,19 +1362,33 @@ extern "C" int64_t dam_wgrad_queue_bytes(void) { return (int64_t)sizeof(dam::Wgr
 extern "C" int dam_wgrad_queue_init(void* queue) {
     if (!queue) return DAM_ERR_BAD_ARG;
     dam::WgradQueue* q = static_cast<dam::WgradQueue*>(queue);
+    const int batching = q->magic == dam::WGRAD_QUEUE_MAGIC ? q->batching : 0;      // re-initialising keeps the mode
+    memset(q, 0, sizeof(*q));
     q->magic = dam::WGRAD_QUEUE_MAGIC;
-    q->batch.njobs = 0;
+    q->batching = batching;
+    return DAM_OK;
+}
+
+extern "C" int dam_wgrad_queue_set_batching(void* queue, int on) {
+    dam::WgradQueue* q = static_cast<dam::WgradQueue*>(queue);
+    if (!q || q->magic != dam::WGRAD_QUEUE_MAGIC) return DAM_ERR_BAD_ARG;
+    if (q->pend.njobs > 0) return DAM_ERR_BAD_ARG;          // flush first
+    q->batching = on ? 1 : 0;
     return DAM_OK;
 }
 
 extern "C" int dam_wgrad_queue_pending(const void* queue) {
     const dam::WgradQueue* q = static_cast<const dam::WgradQueue*>(queue);
-    return q && q->magic == dam::WGRAD_QUEUE_MAGIC ? q->batch.njobs : -1;
+    return q && q->magic == dam::WGRAD_QUEUE_MAGIC ? q->batch.njobs + q->pend.njobs : -1;
 }
 
 extern "C" int dam_wgrad_queue_flush(void* queue, void* stream) {
     dam::WgradQueue* q = static_cast<dam::WgradQueue*>(queue);
     if (!q || q->magic != dam::WGRAD_QUEUE_MAGIC) return DAM_ERR_BAD_ARG;
+    if (q->pend.njobs > 0) {
+        const int rc = q->pend.launch(q, (hipStream_t)stream);
+        if (rc != DAM_OK) return rc;
+    }
     return dam::reduce_flush(q->batch, (hipStream_t)stream);
 }
 
@@ -1367,6 +1461,7 @@ extern "C" int dam_conv2d_wgrad_f32(const float* x, int B, int H, int W, int C, 
     }
 #undef DAM_WGD
     WgradGeo g;
+    memset(&g, 0, sizeof(g));               // (compared bytewise when launches of one geometry are batched)
     g.B = B; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.N = n_chan; g.s = stride; g.KH = kh; g.KW = kw;
     g.off_h = -pad; g.step_h = dil; g.off_w = -pad; g.step_w = dil;
     g.r0 = -pad; g.c0 = -pad;

@@ -380,6 +380,8 @@ def params_changed():
     PARAM_EPOCH += 1
 
 
+# The equal weight gradients of a deep stage as one launch (include/dam_hip.h: dam_wgrad_queue_set_batching); DAM_WGRAD_BATCH=0: A/B
+WGRAD_BATCH = os.environ.get('DAM_WGRAD_BATCH', '1') != '0'
 _wgrad_queues = {}      # device -> [ctypes buffer of the library's queue, calls recorded since the last flush]
 
 
@@ -390,7 +392,11 @@ def _wgrad_queue(device):
         L = _lib.lib()
         buf = ctypes.create_string_buffer(int(L.dam_wgrad_queue_bytes()))
         _lib.check(L.dam_wgrad_queue_init(ctypes.addressof(buf)), 'dam_wgrad_queue_init')
-        q = _wgrad_queues[key] = [buf, 0]
+        if WGRAD_BATCH:
+            _lib.check(L.dam_wgrad_queue_set_batching(ctypes.addressof(buf), 1), 'dam_wgrad_queue_set_batching')
+        # [the library's queue, calls recorded since the last flush, tensors those calls read (kept alive until the flush: with
+        #  batching a recorded call's slab kernel may not have been launched yet)]
+        q = _wgrad_queues[key] = [buf, 0, []]
     return q
 
 
@@ -401,6 +407,7 @@ def wgrad_abandon(device=None):
     for key, q in _wgrad_queues.items():
         if q[1] and (device is None or key == (device.type, device.index)):
             _lib.check(_lib.lib().dam_wgrad_queue_init(ctypes.addressof(q[0])), 'dam_wgrad_queue_init')
+            del q[2][:]
             q[1] = 0
 
 
@@ -411,6 +418,7 @@ def wgrad_flush(device=None):
         if q[1] and (device is None or key == (device.type, device.index)):
             _lib.check(_lib.lib().dam_wgrad_queue_flush(ctypes.addressof(q[0]), _lib.stream()), 'dam_wgrad_queue_flush')
             q[1] = 0
+            del q[2][:]
 
 
 def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, relu_in=False,
@@ -439,6 +447,7 @@ def conv2d_wgrad(x, dy, n_out, kh, kw, stride=1, pad=0, dil=1, in_scale=None, in
         q = _wgrad_queue(x.device)
         ws = _grow(_workspaces, (x.device.type, x.device.index, 'wgrad slabs', q[1]), x.device, floats)
         q[1] += 1
+        q[2].append((x, dy, in_scale, in_shift))
         queue = ctypes.addressof(q[0])
     else:
         ws, queue = _workspace(x.device, floats), None

@@ -50,7 +50,7 @@ struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 /* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
  * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
  * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
-#define DAM_ABI_VERSION 13
+#define DAM_ABI_VERSION 14
 const char* dam_arch(void);
 int dam_abi_version(void);
 
@@ -251,6 +251,15 @@ int64_t dam_wgrad_queue_bytes(void);
 int dam_wgrad_queue_init(void* queue);
 int dam_wgrad_queue_pending(const void* queue);     /* recorded, not yet flushed; -1: not an initialised queue */
 int dam_wgrad_queue_flush(void* queue, void* stream);
+/* Batched slab launches (ABI 14).  The deep ResNet stages (models/model_resnet.py:70-71: 128 / 256 channels on 65x9 / 33x5 pixels)
+ * have three weight gradients of ONE geometry each, 20-28 us launches of which ~13 us are launch + pipeline fill, and each split
+ * eight ways over the pixels to fill 256 CUs (eight 2.4 MB slabs for a 2.4 MB gradient).  With batching on, a queued
+ * dam_conv2d_wgrad_f32 that takes the tile kernel only RECORDS its launch; recorded launches of the same instantiation and geometry
+ * (at most 4) run as ONE launch (blockIdx.z = job) when another geometry arrives or at dam_wgrad_queue_flush -- with a third of
+ * the pixel splits, i.e. a third of the slab bytes the reduction reads back.  Off by default.
+ *   Contract while on: x, dy, in_scale / in_shift of a queued call must stay valid and unmodified until the flush as well
+ *   (not only its workspace and dw).  Switching needs an empty queue (DAM_ERR_BAD_ARG otherwise). */
+int dam_wgrad_queue_set_batching(void* queue, int on);
 
 /* Diagnostic builds of the library only (libdam_hip_diag.so: dam_conv_strip.hip compiled with -DDAM_STRIP_DIAG_TAGS): the row-ring
  * convolution's loader waves tag every geometry-table entry with the tile it describes and its compute waves check the tag of every

@@ -667,3 +667,53 @@ def test_strided_dgrad_takes_the_upstream_batchnorm_sums(ops, B, Ci, Co, H, W):
     b = ops.bn_backward(dx, None, u, gam, mean, invstd, True, mask_bits=bits)
     for t1, t2 in zip(a, b):
         close(t1, t2.cpu(), 2e-5)
+
+
+def test_wgrad_batched_tile_launches(ops):
+    """dam_wgrad_queue_set_batching (ABI 14): deferred weight gradients of ONE geometry that take the tile kernel -- the three
+    256-channel convolutions of the 33 x 5 stage, models/model_resnet.py:71 -- are recorded and run as ONE launch at the flush
+    (blockIdx.z = job), with the fused input affine of the conv2 form on some jobs; a job of another geometry in between
+    launches what is pending; five equal jobs split 4 + 1.  Every gradient against torch's float64 weight gradient."""
+    import ctypes
+    from deep_audio_mixer_amd import _lib
+    assert ops.WGRAD_BATCH
+    g = torch.Generator().manual_seed(77)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    def job(B, Ci, Co, H, W, affine):
+        x = torch.randn(B, Ci, H, W, generator=g)
+        dy = torch.randn(B, Co, H, W, generator=g)
+        sc = sh = None
+        xin = x
+        if affine:
+            sc, sh = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g)
+            xin = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        want = torch.nn.grad.conv2d_weight(xin.double(), (Co, Ci, 3, 3), dy.double(), 1, 1)
+        out = torch.full((Co, Ci, 3, 3), float('nan'), device=dev)
+        return dict(x=nhwc(x).cuda(), dy=nhwc(dy).cuda(), sc=None if sc is None else sc.cuda(), sh=None if sh is None else sh.cuda(),
+                    want=want, out=out, co=Co)
+    # geometry A x 3 (one with the affine -> it may not share a launch with the plain ones), geometry B, geometry A x 5
+    jobs = [job(8, 256, 256, 33, 5, False), job(8, 256, 256, 33, 5, False), job(8, 256, 256, 33, 5, True),
+            job(2, 128, 128, 12, 5, False)] + [job(8, 256, 256, 33, 5, False) for _ in range(5)]
+    q = ops._wgrad_queue(dev)
+    L = _lib.lib()
+    for j in jobs:
+        ops.conv2d_wgrad(j['x'], j['dy'], j['co'], 3, 3, 1, 1, 1, in_scale=j['sc'], in_shift=j['sh'], relu_in=j['sc'] is not None,
+                         out=j['out'], defer=True)
+    assert L.dam_wgrad_queue_pending(ctypes.addressof(q[0])) > 0
+    torch.cuda.synchronize()
+    assert all(bool(torch.isnan(j['out']).all()) for j in jobs)          # nothing has been reduced yet
+    ops.wgrad_flush(dev)
+    assert L.dam_wgrad_queue_pending(ctypes.addressof(q[0])) == 0 and q[2] == []
+    for j in jobs:
+        close(j['out'], j['want'], 5e-5)
+    # switching the mode needs an empty queue
+    ops.conv2d_wgrad(jobs[0]['x'], jobs[0]['dy'], 256, 3, 3, 1, 1, 1, out=jobs[0]['out'], defer=True)
+    assert L.dam_wgrad_queue_set_batching(ctypes.addressof(q[0]), 0) == -1
+    ops.wgrad_flush(dev)
+    assert L.dam_wgrad_queue_set_batching(ctypes.addressof(q[0]), 0) == 0
+    jobs[1]['out'].fill_(float('nan'))
+    ops.conv2d_wgrad(jobs[1]['x'], jobs[1]['dy'], 256, 3, 3, 1, 1, 1, out=jobs[1]['out'], defer=True)
+    ops.wgrad_flush(dev)
+    close(jobs[1]['out'], jobs[1]['want'], 5e-5)
+    assert L.dam_wgrad_queue_set_batching(ctypes.addressof(q[0]), 1) == 0
