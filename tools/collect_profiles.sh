@@ -39,5 +39,8 @@ python3 bench.py --config C1 --steps 10 > $out/bench_line_C1.json 2>> $out/bench
 python3 bench.py --via-trainer --steps 200 > $out/bench_line_via_trainer.json 2>> $out/bench.err
 python3 bench.py --via-trainer --steps 200 --pcm-loader > $out/bench_line_via_trainer_pcm_loader.json 2>> $out/bench.err
 python3 bench.py --ingest > $out/bench_line_ingest.json 2>> $out/bench.err
+python3 bench.py --via-trainer --dataloader-workers 6 --steps 96 > $out/bench_line_via_trainer_dataloader6.json 2>> $out/bench.err
+python3 bench.py --via-trainer --dataloader-workers 6 --epoch-repeat 8 --steps 768 > $out/bench_line_via_trainer_dataloader6_long_epochs.json 2>> $out/bench.err
+python3 bench.py --no-graph --steps 20 --no-cpu-baseline --no-roofline --no-host-stream > $out/bench_line_C3_eager_no_graph.json 2>> $out/bench.err
 DAM_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 10 --warmup 2 --breakdown --no-roofline --no-host-stream > $out/bench_line_ddp2_gloo_rehearsal.json 2>> $out/bench.err
 tail -c 600 $out/bench_line_C3.json
