@@ -57,16 +57,23 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int TNB, int TKB, int TA, int TB>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const WgradJobs jobs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// LW (loader waves; experiment of round 5, off by default -- see launch_wgrad_jobs): 512 threads -- waves 0-3 compute exactly as in
+// the plain form, waves 4-7 stage the NEXT tile's X patch and dY pixels into the other of two LDS images while the compute waves run
+// the MFMAs of this one (one barrier per tile).  The plain form stages and computes in turn and relies on a second co-resident
+// workgroup to fill the gaps: its matrix pipe was 58 % busy on the scalar models' 9x9 layer (0.585 of peak) and a 176-pixel tile of
+// the 33 x 5 stage cost 19 us for 5.3 us of MFMAs -- and still beats this form.
+template <int TNB, int TKB, int TA, int TB, bool LW>
+__global__ __launch_bounds__(LW ? 512 : 256) void wgrad_kernel(const WgradGeo g, const WgradJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const float* __restrict__ X = jobs.X[blockIdx.z];
     const float* __restrict__ dY = jobs.dY[blockIdx.z];
     const float* __restrict__ in_scale = jobs.sc[blockIdx.z];
     const float* __restrict__ in_shift = jobs.sh[blockIdx.z];
     float* __restrict__ partial = jobs.partial[blockIdx.z];
     constexpr int NBLK = TNB * TKB * TA * TB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) & 3;          // index inside the role
+    const bool loader = LW && __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) != 0;
     const int j = lane & 15, kq = lane >> 4;
     int xt = blockIdx.x;
     const int tg = xt % g.tap_groups; xt /= g.tap_groups;
@@ -76,31 +83,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const Wgra
     const int HoWo = g.Ho * g.Wo;
     const int chunk_bytes = g.PR * g.PWT * 64;
     const int TMW = g.TMW, WP = g.TMW >> 2;   // pixels per wave
-    unsigned char* dy_s = smem + TKB * chunk_bytes;        // [TNB][TMW][16] floats
+    const int img_bytes = TKB * chunk_bytes + TNB * TMW * 64;      // one LDS image: [TKB chunks of the X patch][TNB][TMW][16] floats of dY
 
     PatchGeo pg;
     pg.H = g.H; pg.W = g.W; pg.C = g.C; pg.s = g.s; pg.c0 = g.c0; pg.PR = g.PR; pg.PWin = g.PWin; pg.PWs = g.PWs;
     pg.PWT = g.PWT; pg.in_nchw = g.in_nchw; pg.relu_in = jobs.relu_in[blockIdx.z];
 
-    v4f acc[NBLK];
-#pragma unroll
-    for (int i = 0; i < NBLK; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    int toffs[TA * TB];                      // LDS byte offset of tap (ta, tb) relative to the lane's pixel of the staged patch
-#pragma unroll
-    for (int ta = 0; ta < TA; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < TB; ++tb) {
-            const int coff = g.off_w + tb * g.step_w - g.c0;
-            const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
-            toffs[ta * TB + tb] = (ta * g.step_h * g.PWT + slotoff) * 64;
-        }
     const size_t img_elems = (size_t)g.H * g.W * g.C;
-    for (int tile = blockIdx.y; tile < g.total_tiles; tile += g.nsplit) {
+    // stage tile `tile` into the LDS image at `smem` (all 256 threads of the staging role)
+    auto stage_tile = [&](int tile, unsigned char* smem) {
+        unsigned char* dy_s = smem + TKB * chunk_bytes;
         const int img = tile / g.tiles_m;
         const int p0 = (tile - img * g.tiles_m) * TMW;
         const int oh_first = p0 / g.Wo;
-        __syncthreads();
         // only the input rows the TA kernel rows of this tap group touch (a 1 x KW group needs no vertical halo at all)
         stage_patch(smem, chunk_bytes, X + (size_t)img * img_elems, pg, oh_first * g.s + g.off_h + a0 * g.step_h, tk * TKB, TKB,
                     in_scale, in_shift, tid);
@@ -125,8 +120,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const Wgra
                 }
             }
         }
-        __syncthreads();
+    };
+    if constexpr (LW) {
+        // ---- loader waves: their own loop with the SAME number of barriers as the compute waves' path below (one after the first
+        //      image, one per tile, five in the cross-wave reduction); the accumulators do not exist on this path
+        if (loader) {
+            int tile = blockIdx.y;
+            if (tile < g.total_tiles) stage_tile(tile, smem_all);
+            __syncthreads();
+            for (int k = 0; tile < g.total_tiles; tile += g.nsplit, ++k) {
+                if (tile + g.nsplit < g.total_tiles) stage_tile(tile + g.nsplit, smem_all + ((k + 1) & 1) * img_bytes);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) __syncthreads();
+            return;
+        }
+    }
+    v4f acc[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+    int toffs[TA * TB];                      // LDS byte offset of tap (ta, tb) relative to the lane's pixel of the staged patch
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            const int coff = g.off_w + tb * g.step_w - g.c0;
+            const int slotoff = g.s == 1 ? coff : (coff & 1) * g.PWs + (coff >> 1);
+            toffs[ta * TB + tb] = (ta * g.step_h * g.PWT + slotoff) * 64;
+        }
+    // the MFMAs of tile `tile` from the LDS image at `smem` (the four compute waves)
+    auto compute_tile = [&](int tile, const unsigned char* smem) {
+        const unsigned char* dy_s = smem + TKB * chunk_bytes;
+        const int img = tile / g.tiles_m;
+        const int p0 = (tile - img * g.tiles_m) * TMW;
+        const int oh_first = p0 / g.Wo;
+        (void)img;
         // this wave's WP pixels, 4 per MFMA step; lane group kq owns pixel 4*t + kq.  Two operand sets: the TNB + TA*TB*TKB
         // ds_read_b32 of step t + 1 are requested before the MFMAs of step t (one wave per SIMD here -- 80-odd KB of LDS per
         // workgroup -- so nothing else hides the LDS latency: the single-set loop ran the 9x9 / 64 -> 128 layer of the scalar
@@ -214,12 +244,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeo g, const Wgra
 #undef DAM_WG_LOAD
 #undef DAM_WG_MFMA
 #endif
+    };
+    if constexpr (LW) {
+        int tile = blockIdx.y;
+        __syncthreads();                                  // the loaders have staged the first tile
+        for (int k = 0; tile < g.total_tiles; tile += g.nsplit, ++k) {
+            compute_tile(tile, smem_all + (k & 1) * img_bytes);
+            __syncthreads();                              // image k & 1 may be refilled; image (k + 1) & 1 is complete
+        }
+    } else {
+        for (int tile = blockIdx.y; tile < g.total_tiles; tile += g.nsplit) {
+            __syncthreads();
+            stage_tile(tile, smem_all);
+            __syncthreads();
+            compute_tile(tile, smem_all);
+        }
     }
 
     // combine the 4 waves through LDS (sequential adds: fixed order), then one slab per workgroup
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    for (int w = 0; w < 4; ++w) {
+    float* red = reinterpret_cast<float*>(smem_all);
+    for (int w = 0; w < 4; ++w) {       // (five barriers from here to the end: the loader waves' path counts them)
         if (wave == w) {
 #pragma unroll
             for (int i = 0; i < NBLK; ++i) {
@@ -1257,49 +1302,76 @@ int launch_wgrad_jobs(WgradGeo g, const WgradJobs& jobs, int njobs, int64_t ws_f
                       const int* k_real, void* queue, hipStream_t st) {
     constexpr int NBLK = TNB * TKB * TA * TB;
     const int nx = g.tiles_n * g.tiles_k * g.tap_groups;
-    // Pixel split by MAKESPAN: every CU works through ceil(workgroups / 256) workgroups of ceil(total_tiles / nsplit) tiles each
-    // (co-resident workgroups share the matrix pipe, so it is the count per CU that matters).  The first rule -- at least 512
-    // workgroups -- gave the 9x9 / 64 -> 128 layer of the scalar models 72 x 8 = 576 workgroups of 40 tiles: a third round for a
-    // quarter of the chip (1.64 ms); 72 x 7 = 504 of 46 tiles is two rounds.  DAM_WG_NSPLIT_OLD keeps the first rule (A/B).
-    // Batched jobs multiply the workgroups, not the tiles of one: three jobs need a third of the splits -- and slabs.
-    int nsplit = (int)cdiv(512, (int64_t)nx * njobs);
-    if (nsplit > g.total_tiles) nsplit = g.total_tiles;
-    if (nsplit < 1) nsplit = 1;
-    static const bool old_rule = getenv("DAM_WG_NSPLIT_OLD") != nullptr;
-    if (!old_rule) {
-        // slots: two workgroups per CU where the LDS holds two (the small-patch layers: their staging phases overlap each
-        // other -- 256 workgroups of two tiles measured slower than 512 of one on the 33 x 5 stage), one otherwise
-        size_t lds0 = (size_t)TKB * g.PR * g.PWT * 64 + (size_t)TNB * g.TMW * 64;
-        if (lds0 < (size_t)NBLK * 1024) lds0 = (size_t)NBLK * 1024;
-        static const int slots_forced = [] { const char* e = getenv("DAM_WG_SLOTS"); return e ? atoi(e) : 0; }();      // A/B knob
-        const int64_t slots = slots_forced ? slots_forced : (lds0 * 2 <= 160 * 1024 ? 512 : 256);
+    size_t lds0 = (size_t)TKB * g.PR * g.PWT * 64 + (size_t)TNB * g.TMW * 64;
+    // Loader-wave form (two LDS images, one 8-wave workgroup per CU) where two images fit.  MEASURED SLOWER than two plain
+    // workgroups per CU (profiles/r05_wgrad_loader_waves_ab.txt: C2 5.28 -> 5.52 ms, C1 3.71 -> 3.86, C3 +8 us): one MFMA wave per
+    // SIMD beside a VALU-heavy staging wave hides LDS operand latency worse than two MFMA waves taking turns.  OFF by default;
+    // DAM_WG_LW=1 enables it for the big-tile instantiations, 2 for all (A/B).
+    static const int lw_env = [] { const char* e = getenv("DAM_WG_LW"); return e ? atoi(e) : 0; }();
+    // (default: the big-tile instantiations only -- 2x2 / 3x2 channel blocks hold 144+ accumulator registers, so at most two of
+    //  their plain workgroups share a CU; the one-block tiles run up to five waves per SIMD and overlap by themselves)
+    const bool lw_fits = lw_env != 0 && (TNB * TKB >= 4 || lw_env == 2) && 2 * lds0 <= 160 * 1024 && 2 * lds0 >= (size_t)NBLK * 1024;
+    auto split_for = [&](int64_t slots, double fixed) {
+        // Pixel split by MAKESPAN: every CU works through ceil(workgroups / slots) workgroups of ceil(total_tiles / nsplit) tiles
+        // each (co-resident workgroups share the matrix pipe, so it is the count per CU that matters).  The first rule -- at least
+        // 512 workgroups -- gave the 9x9 / 64 -> 128 layer of the scalar models 72 x 8 = 576 workgroups of 40 tiles: a third round
+        // for a quarter of the chip (1.64 ms); 72 x 7 = 504 of 46 tiles is two rounds.  Batched jobs multiply the workgroups, not the
+        // tiles of one: three jobs need a third of the splits -- and slabs.
+        int ns_best = 1;
         double best = 1e300;
-        // (up to 512 splits: a layer with ONE channel tile -- the scalar models' 4 -> 16 first convolution -- had 63 workgroups on 256 CUs
-        // under the former cap of 64: 170 us for 0.15 GFLOP)
+        // (up to 512 splits: a layer with ONE channel tile -- the scalar models' 4 -> 16 first convolution -- had 63 workgroups on
+        // 256 CUs under the former cap of 64: 170 us for 0.15 GFLOP)
         const int hi = g.total_tiles < 512 ? g.total_tiles : 512;
         for (int ns = 1; ns <= hi; ++ns) {
             const int64_t wgs = (int64_t)nx * ns * njobs;
             if ((int64_t)nx * ns * NBLK * 256 > ws_floats && ns > 1) break;
-            const double cost = (double)cdiv(wgs, slots) * ((double)cdiv(g.total_tiles, ns) + 1.0);   // + 1: per-workgroup fixed part
-            if (cost < best * 0.999) { best = cost; nsplit = ns; }
+            const double cost = (double)cdiv(wgs, slots) * ((double)cdiv(g.total_tiles, ns) + fixed);   // + fixed: per-workgroup part
+            if (cost < best * 0.999) { best = cost; ns_best = ns; }
+        }
+        return ns_best;
+    };
+    int nsplit;
+    bool lw = false;
+    static const bool old_rule = getenv("DAM_WG_NSPLIT_OLD") != nullptr;
+    if (old_rule) {                          // DAM_WG_NSPLIT_OLD: the first rule (A/B)
+        nsplit = (int)cdiv(512, (int64_t)nx * njobs);
+        if (nsplit > g.total_tiles) nsplit = g.total_tiles;
+        if (nsplit < 1) nsplit = 1;
+    } else {
+        // slots: two workgroups per CU where the LDS holds two (the small-patch layers: their staging phases overlap each
+        // other -- 256 workgroups of two tiles measured slower than 512 of one on the 33 x 5 stage), one otherwise
+        if (lds0 < (size_t)NBLK * 1024) lds0 = (size_t)NBLK * 1024;
+        static const int slots_forced = [] { const char* e = getenv("DAM_WG_SLOTS"); return e ? atoi(e) : 0; }();      // A/B knob
+        const int64_t slots = slots_forced ? slots_forced : (lds0 * 2 <= 160 * 1024 ? 512 : 256);
+        nsplit = split_for(slots, 1.0);
+        if (lw_fits) {
+            // the loader-wave form is one workgroup per CU and pays its staging only for the FIRST tile: worth it when a
+            // workgroup has several tiles to stream (lw_env 2 forces it)
+            const int ns_lw = split_for(256, 1.0);
+            if (cdiv(g.total_tiles, ns_lw) >= 2 || lw_env == 2) { lw = true; nsplit = ns_lw; }
         }
     }
     while (nsplit > 1 && (int64_t)nsplit * nx * NBLK * 256 > ws_floats) --nsplit;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
     g.nsplit = nsplit;
     size_t lds = (size_t)TKB * g.PR * g.PWT * 64 + (size_t)TNB * g.TMW * 64;
+    if (lw) lds *= 2;
     if (lds < (size_t)NBLK * 1024) lds = (size_t)NBLK * 1024;
     if (lds > 160 * 1024) return DAM_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        static PerDevice<bool> raised_pd; bool& raised = raised_pd();
+        static PerDevice<bool> raised_pd[2];
+        bool& raised = raised_pd[lw ? 1 : 0]();
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TNB, TKB, TA, TB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return DAM_ERR_LAUNCH;
+            const void* fn = lw ? reinterpret_cast<const void*>(&wgrad_kernel<TNB, TKB, TA, TB, true>)
+                                : reinterpret_cast<const void*>(&wgrad_kernel<TNB, TKB, TA, TB, false>);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DAM_ERR_LAUNCH;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((wgrad_kernel<TNB, TKB, TA, TB>), dim3(nx, nsplit, njobs), dim3(256), lds, st, g, jobs);
+    if (lw)
+        hipLaunchKernelGGL((wgrad_kernel<TNB, TKB, TA, TB, true>), dim3(nx, nsplit, njobs), dim3(512), lds, st, g, jobs);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<TNB, TKB, TA, TB, false>), dim3(nx, nsplit, njobs), dim3(256), lds, st, g, jobs);
     DAM_CHECK_LAUNCH();
     for (int i = 0; i < njobs; ++i) {
         const int rc = reduce_submit(queue, jobs.partial[i], dw[i], g.nsplit, nx, TNB, TKB, TA, TB, n_real[i], k_real[i], g.KH, g.KW,
