@@ -501,7 +501,8 @@ def run_train(name, cfg, args):
     opt = Adam(model.parameters(), weight_decay=1e-5, world_size=world)
     n_resident = 4 * B
     clips = synth_clips(n_resident, S, n, device, 1234 + rank)
-    step = TrainStep(model, opt, S, n, CHANNELS, B, N_FFT, hop, use_graph=not args.no_graph, overlap=not args.no_overlap)
+    step = TrainStep(model, opt, S, n, CHANNELS, B, N_FFT, hop, use_graph=not args.no_graph, overlap=not args.no_overlap,
+                     copy_mark=not args.no_copy_mark)
     step.load_clips(clips[:B])
     dog.phase('eager warm-up steps + graph capture')
     step.capture(warmup=2)
@@ -625,7 +626,7 @@ def run_train(name, cfg, args):
         for lo in range(0, n_host, n_resident):
             hi = min(lo + n_resident, n_host)
             host[lo:hi].copy_(synth_clips(hi - lo, S, n, device, 99 + rank + lo))
-        stager = staging.BatchStager(host, B, device)
+        stager = staging.BatchStager(host, B, device, gate=step.copy_mark)
 
         def run_streamed(k, first):
             for _ in range(k):
@@ -635,7 +636,9 @@ def run_train(name, cfg, args):
         dts = timed(run_streamed, args.steps, 0)
         result['pcie_inclusive'] = {'value': frames_per_step * args.steps / dts, 'ms_per_step': 1e3 * dts / args.steps,
                                     'host_clips_pinned': n_host, 'h2d_bytes_per_step': float(host[:B].numel() * 4),
-                                    'note': 'batch k+1 uploaded from page-locked host memory on a copy stream during step k'}
+                                    'copy_gate': ('step mark: the upload of batch k+1 starts when step k-1 reaches the backward '
+                                                  'pass of its shallow layers' if step.copy_mark is not None else 'end of step k-1'),
+                                    'note': 'batch k+1 uploaded from page-locked host memory on a copy stream beside the steps'}
         del host, stager
     dog.phase('roofline probe / cpu baseline (rank 0)')
     if rank == 0 and not args.no_roofline:
@@ -936,6 +939,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-host-stream', action='store_true')
+    ap.add_argument('--no-copy-mark', action='store_true', help='A/B: the streamed leg\'s uploads start at step ends (no step mark)')
     ap.add_argument('--host-clips', type=int, default=N_HOST_CLIPS)
     ap.add_argument('--breakdown', action='store_true', help='N > 1: add per-phase timings of the step (diagnostic)')
     ap.add_argument('--repeat', type=int, default=5, help='extra timed regions of --steps steps: median / min / max in the line')

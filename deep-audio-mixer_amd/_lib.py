@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('DAM_LIB_PATH') or os.path.join(_HERE, 'libdam_hip.so'
 # include/dam_hip.h: bumped whenever a C signature changes (together with dam_abi_version() in csrc/dam_api.hip and
 # DAM_ABI_VERSION in the header).  libdam_hip.so is git-ignored and travels prebuilt: a stale one would read device pointers
 # as streams, so lib() refuses it instead of launching.
-EXPECTED_ABI = 14
+EXPECTED_ABI = 15
 
 _STATUS = {0: 'DAM_OK', -1: 'DAM_ERR_BAD_ARG', -2: 'DAM_ERR_UNSUPPORTED', -3: 'DAM_ERR_LAUNCH',
            -4: 'DAM_ERR_WORKSPACE'}
@@ -25,6 +25,10 @@ SIGNATURES = {
     'dam_arch': (ctypes.c_char_p, []),
     'dam_abi_version': (c_i, []),
     'dam_host_dontfork_pinned': (c_i, [c_p, c_p]),
+    'dam_step_mark_create': (c_i, [c_p]),
+    'dam_step_mark_record': (c_i, [c_p, c_p]),
+    'dam_step_mark_wait': (c_i, [c_p, c_p]),
+    'dam_step_mark_destroy': (c_i, [c_p]),
     'dam_stft_twiddle_count': (c_i64, [c_i]),
     'dam_stft_fill_twiddles_host': (c_i, [c_i, c_p]),
     'dam_stft_logmag_f32': (c_i, [c_p, c_i, c_i64, c_i64, c_i, c_i64, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p, c_p]),

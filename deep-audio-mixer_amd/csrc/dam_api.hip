@@ -146,3 +146,55 @@ extern "C" int dam_host_dontfork_pinned(int64_t* n_mappings_host, int64_t* n_byt
     if (n_bytes_host) *n_bytes_host = bytes;
     return DAM_OK;
 }
+
+// ---- step marks (include/dam_hip.h, ABI 15): an event another stream can wait for, recorded INSIDE a captured step
+extern "C" int dam_step_mark_create(void** mark_host) {
+    if (!mark_host) return DAM_ERR_BAD_ARG;
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return DAM_ERR_LAUNCH;
+    }
+    *mark_host = ev;
+    return DAM_OK;
+}
+
+extern "C" int dam_step_mark_record(void* mark, void* stream) {
+    if (!mark) return DAM_ERR_BAD_ARG;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return DAM_ERR_LAUNCH;
+    }
+    // capturing: an event-record NODE that every replay executes; the event stays usable from streams outside the graph
+    const unsigned flags = st == hipStreamCaptureStatusActive ? hipEventRecordExternal : hipEventRecordDefault;
+    if (hipEventRecordWithFlags((hipEvent_t)mark, (hipStream_t)stream, flags) != hipSuccess) {
+        (void)hipGetLastError();
+        return DAM_ERR_LAUNCH;
+    }
+    return DAM_OK;
+}
+
+extern "C" int dam_step_mark_wait(void* mark, void* stream) {
+    if (!mark) return DAM_ERR_BAD_ARG;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return DAM_ERR_LAUNCH;
+    }
+    if (st != hipStreamCaptureStatusNone) return DAM_ERR_BAD_ARG;      // the waiter is a copy stream outside every graph
+    if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)mark, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return DAM_ERR_LAUNCH;
+    }
+    return DAM_OK;
+}
+
+extern "C" int dam_step_mark_destroy(void* mark) {
+    if (!mark) return DAM_ERR_BAD_ARG;
+    if (hipEventDestroy((hipEvent_t)mark) != hipSuccess) {
+        (void)hipGetLastError();
+        return DAM_ERR_LAUNCH;
+    }
+    return DAM_OK;
+}

@@ -32,13 +32,16 @@ from . import distributed, features, layers, ops
 class TrainStep:
     def __init__(self, model, optimizer, n_stems, n_samples=None, channels=2, batch=8, n_fft=2048, hop=1024,
                  use_graph=True, device=None, overlap=True, feature_shape=None, pcm_dtype=torch.float32, track_gains=False,
-                 normalize=False):
+                 normalize=False, copy_mark=False):
         """feature_shape=(F, T): the step starts from FEATURES instead of PCM (what a DataLoader over the reference's
         Dataset yields, model_trainer.py:31-33): no front-end launch in the step, `load_features(x, gt)` fills the static
         inputs.  pcm_dtype: float32, or int16 / int32 for integer PCM read by the front-end as decoded from the file
         (DAM_PCM_S16 / DAM_PCM_S32, include/dam_hip.h).  track_gains: the front-end multiplies every track by an entry of a
         static [B, S+1] table (data/dataset.py:164-168, 198-199: the augmentation draws; `bind_clips(clips, gain)` fills it,
-        ones otherwise).  normalize: the per-frame max-abs normalisation of data/dataset.py:159-160 (off at the reference HEAD)."""
+        ones otherwise).  normalize: the per-frame max-abs normalisation of data/dataset.py:159-160 (off at the reference HEAD).
+        copy_mark: the step records `self.copy_mark` (staging.StepMark) where backward crosses the model's bucket boundary
+        (ResNet: below layer5) -- the uploader of the NEXT batch waits for it (staging.BatchStager(gate=)): a host-to-device
+        copy beside the forward pass slows its latency-bound launches, beside the shallow layers' backward it does not."""
         self.model, self.opt = model, optimizer
         self.device = device or next(model.parameters()).device
         self.n_fft, self.hop, self.batch, self.n_stems = n_fft, hop, batch, n_stems
@@ -81,6 +84,10 @@ class TrainStep:
                 raise ValueError('ddp_late_parameters() must be the tail of the optimizer\'s parameter list')
             optimizer.set_bucket_boundaries([late[0]])
         self._stage = None
+        self.copy_mark = None
+        if copy_mark:
+            from . import staging
+            self.copy_mark = staging.StepMark()
         # gradients go straight from the backward kernels into the flat buckets (no .grad tensors, no gather launch).  The
         # binding changes the MODEL (its layers then return no .grad): close() -- or leaving the `with` block -- undoes it
         optimizer.bind_grad_slots()
@@ -136,7 +143,15 @@ class TrainStep:
     def _fwd_bwd(self):
         self._front_end()
         self.opt.zero_grad(set_to_none=True)
-        loss, self.masked, self.gains = self.model.forward_mse(self.x, self.gt)
+        if self.copy_mark is None:
+            loss, self.masked, self.gains = self.model.forward_mse(self.x, self.gt)
+        else:
+            tap = []
+            loss, self.masked, self.gains = self.model.forward_mse(self.x, self.gt, tap=tap)
+            if tap and tap[0].requires_grad:
+                tap[0].register_hook(self._mark_hook)       # runs when backward reaches the boundary activation
+            else:
+                self.copy_mark.record()                     # a model without a boundary: behind the forward pass
         loss.backward(self._unit_seed if loss.dim() == 0 else None)      # (no ones_like fill, no seed multiply: layers.UNIT_SEED)
         ops.side_stream_join(self.device)
         ops.wgrad_flush(self.device)                # every weight gradient's slab reduction, one launch
@@ -158,10 +173,16 @@ class TrainStep:
         self.opt.gather_grads(1, grads=grads)
         self._stage = (tap[0], dmid)
 
+    def _mark_hook(self, grad):
+        self.copy_mark.record()
+        return None
+
     def _stage2(self):
         """Backward from the boundary activation to the input; fills bucket 0."""
         mid, dmid = self._stage
         self._stage = None
+        if self.copy_mark is not None:
+            self.copy_mark.record()
         distributed.backward_early(mid, dmid, self.opt.bucket_params(0))
         ops.side_stream_join(self.device)
         ops.wgrad_flush(self.device)

@@ -130,6 +130,36 @@ def pipe_for(device):
     return _pipes[key]
 
 
+class StepMark:
+    """A point inside a (captured) training step that a copy stream can wait for: include/dam_hip.h, dam_step_mark_*.
+    ``record()`` on the current stream -- inside a capture it becomes an event-record node every replay executes;
+    ``wait(stream)`` makes a stream outside the graph wait for the latest record enqueued so far."""
+
+    def __init__(self):
+        from . import _lib
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().dam_step_mark_create(ctypes.byref(h)), 'dam_step_mark_create')
+        self._h, self.records = h, 0
+
+    def record(self):
+        from . import _lib
+        _lib.check(_lib.lib().dam_step_mark_record(self._h, _lib.stream()), 'dam_step_mark_record')
+        self.records += 1
+
+    def wait(self, stream):
+        from . import _lib
+        if self.records:
+            _lib.check(_lib.lib().dam_step_mark_wait(self._h, stream.cuda_stream), 'dam_step_mark_wait')
+
+    def __del__(self):
+        try:
+            from . import _lib
+            if self._h and _lib._lib is not None and not torch.cuda._is_in_bad_fork():
+                _lib._lib.dam_step_mark_destroy(self._h)
+        except Exception:        # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class BatchStager:
     """Feeds device batches from a page-locked host dataset [N, ...]: while the consumer works on batch k, batch k+1
     travels on a private copy stream into the other of two device buffers (the role the reference gives to
@@ -138,7 +168,11 @@ class BatchStager:
     ``next()`` returns the device tensor of the next batch; the caller must have enqueued everything that reads the
     previously returned tensor on the current stream before calling ``next()`` again."""
 
-    def __init__(self, host, batch, device):
+    def __init__(self, host, batch, device, gate=None):
+        """gate (a StepMark of the consuming TrainStep, ``step.copy_mark``): the upload of batch k+1 starts when the step
+        that was enqueued last has reached the mark -- its backward pass -- instead of when it has finished.  The mark lies
+        behind that step's front-end, the only reader of its staging buffer, so it also frees the buffer; the caller runs
+        exactly ONE step per ``next()``."""
         if not host.is_pinned():
             raise ValueError('BatchStager needs page-locked host memory (torch.empty(..., pin_memory=True))')
         self.host, self.batch, self.device = host, batch, torch.device(device)
@@ -149,14 +183,17 @@ class BatchStager:
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]
         self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
         self.stream = torch.cuda.Stream(device=self.device)
-        self.k = 0
+        self.k, self.gate = 0, gate
         self._issue(0)
 
     def _issue(self, k):
         b = k % 2
         lo = (k % self.n_batches) * self.batch
         with torch.cuda.stream(self.stream):
-            self.stream.wait_event(self.consumed[b])        # the reads of this buffer's previous batch are done
+            if self.gate is not None and k >= 2:
+                self.gate.wait(self.stream)                 # step k-2 (the last one enqueued) is past its front-end
+            else:
+                self.stream.wait_event(self.consumed[b])    # the reads of this buffer's previous batch are done
             self.bufs[b].copy_(self.host[lo:lo + self.batch], non_blocking=True)
             self.ready[b].record(self.stream)
 

@@ -50,7 +50,7 @@ struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 /* Library / build identification ("gfx950").  DAM_ABI_VERSION is bumped whenever a signature below changes; a binding
  * compares dam_abi_version() of the library it loaded with the version it was written against and refuses a stale one
  * (deep-audio-mixer_amd/_lib.py: EXPECTED_ABI). */
-#define DAM_ABI_VERSION 14
+#define DAM_ABI_VERSION 15
 const char* dam_arch(void);
 int dam_abi_version(void);
 
@@ -68,6 +68,26 @@ int dam_abi_version(void);
  * the runtime is initialised.
  *   n_mappings_host / n_bytes_host : optional outputs, ranges and bytes marked by this call (re-marking is harmless). */
 int dam_host_dontfork_pinned(int64_t* n_mappings_host, int64_t* n_bytes_host);
+
+/* Step marks (ABI 15): a point INSIDE a captured training step that another stream can wait for.  The reference uploads every
+ * batch on the training stream, `train_features.to(self.device)` at model_trainer.py:34 and `gt_features.to(...)` at :35, from
+ * the page-locked batches of DataLoader(pin_memory=True) (training.ipynb cell 6).  Here the step is ONE hipGraph and the upload
+ * of batch k+1 runs on a copy stream beside step k; measured (profiles/r05_pcie_trace.txt), a 1.3 ms host-to-device copy beside
+ * the FORWARD half of the step costs its latency-bound launches (the BatchNorm finalize kernels: 4.7 -> 7.7 us each) 0.13 ms per
+ * step, beside the shallow layers' backward it costs a third of that.  A mark is a HIP event recorded with
+ * hipEventRecordExternal while the step is being captured (an event-record node of the graph, re-recorded by every replay;
+ * outside a capture: an ordinary record), so the copy stream waits for "step k has reached its backward pass" -- the graph is
+ * not cut.  The front-end has read the step's PCM long before any mark of the step, so the same wait also says the previous
+ * staging buffer is free.
+ *   dam_step_mark_create : *mark_host receives the handle (timing disabled).
+ *   dam_step_mark_record : on `stream`; captured as an external event-record node when the stream is capturing.
+ *   dam_step_mark_wait   : makes `stream` (never a capturing one: DAM_ERR_BAD_ARG) wait for the latest record that has been
+ *                          enqueued -- directly or through a graph launch -- before this call; a no-op if there is none.
+ *   dam_step_mark_destroy: after the graphs that hold the mark are gone. */
+int dam_step_mark_create(void** mark_host);
+int dam_step_mark_record(void* mark, void* stream);
+int dam_step_mark_wait(void* mark, void* stream);
+int dam_step_mark_destroy(void* mark);
 
 /* ---------------------------------------------------------------------------------
  * Feature front-end.  Replaces data/dataset.py:132-162 (compute_features: torch.stft ->
