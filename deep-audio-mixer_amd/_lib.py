@@ -28,6 +28,7 @@ SIGNATURES = {
     'dam_step_mark_create': (c_i, [c_p]),
     'dam_step_mark_record': (c_i, [c_p, c_p]),
     'dam_step_mark_wait': (c_i, [c_p, c_p]),
+    'dam_step_mark_synchronize': (c_i, [c_p]),
     'dam_step_mark_destroy': (c_i, [c_p]),
     'dam_stft_twiddle_count': (c_i64, [c_i]),
     'dam_stft_fill_twiddles_host': (c_i, [c_i, c_p]),

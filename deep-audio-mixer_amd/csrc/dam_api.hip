@@ -151,7 +151,10 @@ extern "C" int dam_host_dontfork_pinned(int64_t* n_mappings_host, int64_t* n_byt
 extern "C" int dam_step_mark_create(void** mark_host) {
     if (!mark_host) return DAM_ERR_BAD_ARG;
     hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    // no system-scope fence: a mark orders streams of ONE device (kernel boundaries and copy completion carry the data); the
+    // default event's cache write-back + invalidate in front of every step cost the following kernels 0.1 ms per step
+    // (tools/sync_cost_probe.py, profiles/r05_sync_cost_probe.txt)
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         (void)hipGetLastError();
         return DAM_ERR_LAUNCH;
     }
@@ -167,8 +170,26 @@ extern "C" int dam_step_mark_record(void* mark, void* stream) {
         return DAM_ERR_LAUNCH;
     }
     // capturing: an event-record NODE that every replay executes; the event stays usable from streams outside the graph
-    const unsigned flags = st == hipStreamCaptureStatusActive ? hipEventRecordExternal : hipEventRecordDefault;
-    if (hipEventRecordWithFlags((hipEvent_t)mark, (hipStream_t)stream, flags) != hipSuccess) {
+    hipError_t e;
+    if (st != hipStreamCaptureStatusActive) {
+        e = hipEventRecord((hipEvent_t)mark, (hipStream_t)stream);
+    } else {
+        e = hipEventRecordWithFlags((hipEvent_t)mark, (hipStream_t)stream, hipEventRecordExternal);
+        if (e != hipSuccess) {
+            // the runtime torch ships answers "invalid argument" here: put the event-record node into the graph under capture by
+            // hand -- behind everything the stream has captured so far, and everything captured later behind it
+            (void)hipGetLastError();
+            hipGraph_t graph = nullptr;
+            const hipGraphNode_t* deps = nullptr;
+            size_t ndeps = 0;
+            hipGraphNode_t node = nullptr;
+            e = hipStreamGetCaptureInfo_v2((hipStream_t)stream, &st, nullptr, &graph, &deps, &ndeps);
+            if (e == hipSuccess) e = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, (hipEvent_t)mark);
+            if (e == hipSuccess) e = hipStreamUpdateCaptureDependencies((hipStream_t)stream, &node, 1, hipStreamSetCaptureDependencies);
+        }
+    }
+    if (e != hipSuccess) {
+        fprintf(stderr, "dam_step_mark_record: %s (capturing %d)\n", hipGetErrorString(e), (int)(st == hipStreamCaptureStatusActive));
         (void)hipGetLastError();
         return DAM_ERR_LAUNCH;
     }
@@ -184,6 +205,15 @@ extern "C" int dam_step_mark_wait(void* mark, void* stream) {
     }
     if (st != hipStreamCaptureStatusNone) return DAM_ERR_BAD_ARG;      // the waiter is a copy stream outside every graph
     if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)mark, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return DAM_ERR_LAUNCH;
+    }
+    return DAM_OK;
+}
+
+extern "C" int dam_step_mark_synchronize(void* mark) {
+    if (!mark) return DAM_ERR_BAD_ARG;
+    if (hipEventSynchronize((hipEvent_t)mark) != hipSuccess) {
         (void)hipGetLastError();
         return DAM_ERR_LAUNCH;
     }

@@ -283,8 +283,8 @@ class MultitrackAudioDataset(data.Dataset):
         cached_files_begin()
         uploaded = [torch.cuda.Event() for _ in range(NS)]
         # pcm=True: the consumer's step reads dev[slot] in place.  The HOST half of a slot is free as soon as its upload has left it
-        # (the feeder reads the next batch into it at once, as in feature mode); only the upload INTO dev[slot] waits -- on the
-        # device, not on the host -- for what the consumer enqueued on it: consumed[slot] is recorded when the consumer comes back
+        # (the feeder reads the next batch into it at once, as in feature mode); only the upload INTO dev[slot] waits -- in the
+        # feeder thread -- for what the consumer enqueued on it: consumed[slot] is recorded when the consumer comes back
         # for its next batch, and consumed_set[slot] tells the feeder that this recording has happened
         consumed = [torch.cuda.Event() for _ in range(NS)]
         consumed_set = [threading.Event() for _ in range(NS)]
@@ -340,11 +340,13 @@ class MultitrackAudioDataset(data.Dataset):
                             if stop.is_set():
                                 return
                         consumed_set[slot].clear()
+                        # the consumer's step read dev[slot] in place: it must be over before the upload overwrites it.  THIS
+                        # thread waits, not the copy stream: a stream that waits for an event of the training stream costs the
+                        # training stream 0.09 ms per step on this stack (profiles/r05_sync_cost_probe.txt), a host wait nothing
+                        consumed[slot].synchronize()
                     with staging.capture_guard, torch.cuda.device(self._device), torch.cuda.stream(copy_stream):
-                        if pcm:                                                     # the consumer's step read dev[slot] in place
-                            copy_stream.wait_event(consumed[slot])
-                        dev[slot][:B].copy_(host[slot][:B], non_blocking=True)      # (stream order: after the launch that
-                        uploaded[slot].record(copy_stream)                          # read dev[slot] NS batches ago)
+                        dev[slot][:B].copy_(host[slot][:B], non_blocking=True)
+                        uploaded[slot].record(copy_stream)
                         gain = None
                         if self._augment:
                             gain = features.augment_gains(self._aug_seed, K, items=self._aug_keys(group), device=self._device)

@@ -24,6 +24,8 @@ stay between them, on RCCL's own stream, so that the big bucket travels while th
 The cut uses autograd itself: stage 1 is torch.autograd.grad(loss, late parameters + [boundary activation]), stage 2
 torch.autograd.backward(boundary activation, its gradient, inputs=early parameters).
 """
+import os
+
 import torch
 
 from . import distributed, features, layers, ops
@@ -148,7 +150,7 @@ class TrainStep:
         else:
             tap = []
             loss, self.masked, self.gains = self.model.forward_mse(self.x, self.gt, tap=tap)
-            if tap and tap[0].requires_grad:
+            if tap and tap[0].requires_grad and os.environ.get('DAM_COPY_MARK_AT', 'boundary') == 'boundary':
                 tap[0].register_hook(self._mark_hook)       # runs when backward reaches the boundary activation
             else:
                 self.copy_mark.record()                     # a model without a boundary: behind the forward pass

@@ -233,8 +233,11 @@ class ModelTrainer:
         slot = st['k'] % self.PCM_SLOTS
         st['k'] += 1
         cur = torch.cuda.current_stream(dev)
+        # the step that read this slot's previous batch must be over: the HOST waits (already true when _run has read that
+        # step's loss, one batch late) -- a copy stream waiting for the training stream's event would cost the training stream
+        # 0.09 ms per step on this stack (profiles/r05_sync_cost_probe.txt)
+        st['consumed'][slot].synchronize()
         with torch.cuda.stream(st['stream']):
-            st['stream'].wait_event(st['consumed'][slot])        # the step that read this slot's previous batch has finished
             pcm = host.to_device(dev, out=st['bufs'][slot])
             st['ready'][slot].record(st['stream'])
         cur.wait_event(st['ready'][slot])

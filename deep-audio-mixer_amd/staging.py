@@ -151,6 +151,12 @@ class StepMark:
         if self.records:
             _lib.check(_lib.lib().dam_step_mark_wait(self._h, stream.cuda_stream), 'dam_step_mark_wait')
 
+    def synchronize(self):
+        """The host waits for the latest record enqueued so far (directly or through a graph launch)."""
+        from . import _lib
+        if self.records:
+            _lib.check(_lib.lib().dam_step_mark_synchronize(self._h), 'dam_step_mark_synchronize')
+
     def __del__(self):
         try:
             from . import _lib
@@ -162,49 +168,59 @@ class StepMark:
 
 class BatchStager:
     """Feeds device batches from a page-locked host dataset [N, ...]: while the consumer works on batch k, batch k+1
-    travels on a private copy stream into the other of two device buffers (the role the reference gives to
+    travels on a private copy stream into another of three device buffers (the role the reference gives to
     DataLoader(pin_memory=True) + ``.to(device)``, model_trainer.py:34 -- here without blocking the training stream).
 
-    ``next()`` returns the device tensor of the next batch; the caller must have enqueued everything that reads the
-    previously returned tensor on the current stream before calling ``next()`` again."""
+    ``next()`` returns the device tensor of the next batch; the caller enqueues exactly the work that reads it (one step)
+    on the current stream before calling ``next()`` again.
+
+    Who waits for whom (profiles/r05_sync_cost_probe.txt): the TRAINING stream waits for the copy stream's event on the
+    device -- that direction is free.  The other direction is not: a stream that waits for an event of the training stream
+    costs the training stream 0.09 ms per step on this stack, whatever the event's flags, while a HOST wait for the same
+    event costs nothing.  So the buffer a copy is about to overwrite is known free on the host: three buffers, and the host
+    waits for the step two batches back (``consumed``) -- the device always has the step in between to work on.
+
+    gate (the consuming TrainStep's ``copy_mark``): the host waits for the step enqueued last to reach its mark -- the
+    backward pass of the shallow layers -- before it enqueues the next upload: a 1.3 ms copy beside the forward pass slows the
+    forward's latency-bound launches (BatchNorm finalize kernels 113 -> 177 us per step, profiles/r05_pcie_trace.txt), beside
+    that part of backward it costs a third.  The next step is launched right behind, two milliseconds before the device needs it."""
+
+    N_BUFS = 3
 
     def __init__(self, host, batch, device, gate=None):
-        """gate (a StepMark of the consuming TrainStep, ``step.copy_mark``): the upload of batch k+1 starts when the step
-        that was enqueued last has reached the mark -- its backward pass -- instead of when it has finished.  The mark lies
-        behind that step's front-end, the only reader of its staging buffer, so it also frees the buffer; the caller runs
-        exactly ONE step per ``next()``."""
         if not host.is_pinned():
             raise ValueError('BatchStager needs page-locked host memory (torch.empty(..., pin_memory=True))')
         self.host, self.batch, self.device = host, batch, torch.device(device)
         self.n_batches = host.shape[0] // batch
         if self.n_batches < 1:
             raise ValueError('the host dataset holds less than one batch')
-        self.bufs = [torch.empty((batch,) + tuple(host.shape[1:]), dtype=host.dtype, device=self.device) for _ in range(2)]
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
-        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        n = self.N_BUFS
+        self.bufs = [torch.empty((batch,) + tuple(host.shape[1:]), dtype=host.dtype, device=self.device) for _ in range(n)]
+        self.ready = [torch.cuda.Event() for _ in range(n)]
+        self.consumed = [torch.cuda.Event() for _ in range(n)]
         self.stream = torch.cuda.Stream(device=self.device)
         self.k, self.gate = 0, gate
         self._issue(0)
 
     def _issue(self, k):
-        b = k % 2
+        b = k % self.N_BUFS
         lo = (k % self.n_batches) * self.batch
         with torch.cuda.stream(self.stream):
-            if self.gate is not None and k >= 2:
-                self.gate.wait(self.stream)                 # step k-2 (the last one enqueued) is past its front-end
-            else:
-                self.stream.wait_event(self.consumed[b])    # the reads of this buffer's previous batch are done
             self.bufs[b].copy_(self.host[lo:lo + self.batch], non_blocking=True)
             self.ready[b].record(self.stream)
 
     def next(self):
-        k, cur = self.k, torch.cuda.current_stream(self.device)
+        k, cur, n = self.k, torch.cuda.current_stream(self.device), self.N_BUFS
         if k > 0:
-            self.consumed[(k - 1) % 2].record(cur)          # everything enqueued so far has read batch k-1's buffer
-        cur.wait_event(self.ready[k % 2])
-        self._issue(k + 1)                                  # travels while the caller's step k runs
+            self.consumed[(k - 1) % n].record(cur)          # everything enqueued so far has read batch k-1's buffer
+        cur.wait_event(self.ready[k % n])
+        if k + 1 >= n:                                      # batch k+1 goes where batch k-2 was: that step must be over
+            self.consumed[(k - 2) % n].synchronize()        # (the device still has step k-1 to work on)
+        if self.gate is not None and k > 0:
+            self.gate.synchronize()                         # ... and step k-1 has reached its backward pass
+        self._issue(k + 1)
         self.k = k + 1
-        return self.bufs[k % 2]
+        return self.bufs[k % n]
 
 
 # ---- fork guard (include/dam_hip.h: dam_host_dontfork_pinned) ---------------------------------------------------------------

@@ -83,10 +83,17 @@ int dam_host_dontfork_pinned(int64_t* n_mappings_host, int64_t* n_bytes_host);
  *   dam_step_mark_record : on `stream`; captured as an external event-record node when the stream is capturing.
  *   dam_step_mark_wait   : makes `stream` (never a capturing one: DAM_ERR_BAD_ARG) wait for the latest record that has been
  *                          enqueued -- directly or through a graph launch -- before this call; a no-op if there is none.
+ *   dam_step_mark_synchronize: the HOST waits for that record.  This is the form the uploader uses: measured on this stack
+ *                          (profiles/r05_sync_cost_probe.txt), ANY stream that waits for an event of the training stream costs
+ *                          the training stream 0.09 ms per step (4.125 -> 4.212 ms; event flags make no difference), a host
+ *                          wait costs nothing (4.138-4.143 against 4.139-4.145 ms) -- so the host waits for the mark and then
+ *                          enqueues the copy, and only the cheap direction (the training stream waiting for the copy stream's
+ *                          event) stays on the device.
  *   dam_step_mark_destroy: after the graphs that hold the mark are gone. */
 int dam_step_mark_create(void** mark_host);
 int dam_step_mark_record(void* mark, void* stream);
 int dam_step_mark_wait(void* mark, void* stream);
+int dam_step_mark_synchronize(void* mark);
 int dam_step_mark_destroy(void* mark);
 
 /* ---------------------------------------------------------------------------------

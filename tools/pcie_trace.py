@@ -62,3 +62,21 @@ if len(idx_s) > 1:
         s, e = int(c['Start_Timestamp']), int(c['End_Timestamp'])
         if s >= t0:
             print('  copy %9.1f .. %9.1f  (%.1f us)' % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))
+
+# where in the step does each copy start?  (kernel running at that time, index within its step)
+if len(idx_s) > 1 and big:
+    print('--- kernel running when each copy starts / ends')
+    for c in big:
+        s0, e0 = int(c['Start_Timestamp']), int(c['End_Timestamp'])
+        for a, b in zip(idx_s[:-1], idx_s[1:]):
+            if int(rows[a]['Start_Timestamp']) <= s0 < int(rows[b]['Start_Timestamp']):
+                for j in range(a, b):
+                    if int(rows[j]['Start_Timestamp']) <= s0 and (j + 1 == b or int(rows[j + 1]['Start_Timestamp']) > s0):
+                        print('  copy starts in kernel %3d of its step (%s, started %.1f us earlier)'
+                              % (j - a, short(rows[j]['Kernel_Name']), (s0 - int(rows[j]['Start_Timestamp'])) / 1e3))
+    a, b = idx_s[-2], idx_s[-1]
+    print('--- gaps > 3 us between consecutive kernels of the last streamed step')
+    for j in range(a + 1, b):
+        gap = (int(rows[j]['Start_Timestamp']) - int(rows[j - 1]['End_Timestamp'])) / 1e3
+        if gap > 3:
+            print('  before kernel %3d (%s): %.1f us' % (j - a, short(rows[j]['Kernel_Name']), gap))

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""tools/sync_cost_probe.py: what does each piece of the streamed leg's per-step stream synchronisation cost the captured C3 step?
+Wall clock over 40 graph replays (HBM-resident clips in every variant, so no upload travels), the pieces added one by one between
+the replays: an event record on the training stream, a wait for an event recorded on a copy stream, a tiny copy on that stream --
+with torch's events (system-scope fence at every record) and with step marks (include/dam_hip.h: no system-scope fence)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch  # noqa: E402
+import bench  # noqa: E402
+import deep_audio_mixer_amd  # noqa: E402,F401
+from deep_audio_mixer_amd import staging  # noqa: E402
+from deep_audio_mixer_amd.engine import TrainStep  # noqa: E402
+from deep_audio_mixer_amd.optim import Adam  # noqa: E402
+
+cfg = bench.CONFIGS['C3']
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+S, B, hop = cfg['n_stems'], cfg['batch'], cfg['hop']
+n = cfg['sr'] * cfg['seconds']
+model = bench.build_model(cfg, dev)
+opt = Adam(model.parameters(), weight_decay=1e-5)
+step = TrainStep(model, opt, S, n, bench.CHANNELS, B, bench.N_FFT, hop, copy_mark=True)
+clips = bench.synth_clips(2 * B, S, n, dev, 7)
+bufs = [clips[:B], clips[B:]]
+step.load_clips(bufs[0])
+step.capture(warmup=2)
+side = torch.cuda.Stream(device=dev)
+host_word = torch.zeros(1024, dtype=torch.float32, pin_memory=True)
+dev_word = torch.zeros(1024, dtype=torch.float32, device=dev)
+
+
+class TorchEv:
+    def __init__(self):
+        self.e = torch.cuda.Event()
+
+    def record(self, stream):
+        self.e.record(stream)
+
+    def wait(self, stream):
+        stream.wait_event(self.e)
+
+
+class MarkEv:
+    def __init__(self):
+        self.m = staging.StepMark()
+
+    def record(self, stream):
+        with torch.cuda.stream(stream):
+            self.m.record()
+
+    def wait(self, stream):
+        self.m.wait(stream)
+
+
+def region(kind, ev, k_steps=40):
+    consumed, ready = [ev(), ev()], [ev(), ev()]
+
+    def one(k):
+        cur = torch.cuda.current_stream(dev)
+        if 'record' in kind:
+            consumed[k % 2].record(cur)
+        if 'cross' in kind:                       # the copy stream waits for the training stream's event (buffer free)
+            consumed[k % 2].wait(side)
+        if 'wait' in kind:
+            if 'copy' in kind:
+                with torch.cuda.stream(side):
+                    dev_word.copy_(host_word, non_blocking=True)
+            ready[k % 2].record(side)
+            ready[k % 2].wait(cur)
+        step.bind_clips(bufs[k % 2])
+        step()
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(k_steps):
+        one(k)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / k_steps
+
+
+for rep in range(2):
+    for kind in ('plain', 'record', 'wait', 'record+wait', 'record+wait+copy'):
+        for name, ev in (('torch events', TorchEv), ('step marks', MarkEv)):
+            if kind == 'plain' and name != 'torch events':
+                continue
+            print('%-18s %-13s %.4f ms per step' % (kind, '' if kind == 'plain' else name, region(kind, ev)), flush=True)
+
+# ---- the real stager, piece by piece (where do the streamed leg's 0.1 ms come from?)
+n_host = 4 * B
+host = torch.empty((n_host, S + 1, n, bench.CHANNELS), dtype=torch.float32, pin_memory=True)
+host.copy_(bench.synth_clips(n_host, S, n, dev, 9))
+
+
+def stager_region(kind, k_steps=40):
+    st = staging.BatchStager(host, B, dev, gate=step.copy_mark if 'gate' in kind else None)
+    if 'ownbufs' in kind:          # the step reads the probe's old buffers, the stager only synchronises
+        st.bufs = [torch.empty_like(b) for b in bufs]
+    if 'tiny' in kind:
+        def tiny_issue(k):
+            b = k % 2
+            with torch.cuda.stream(st.stream):
+                if st.gate is not None and k >= 2:
+                    st.gate.wait(st.stream)
+                else:
+                    st.stream.wait_event(st.consumed[b])
+                st.bufs[b][:1, :1, :1024].copy_(st.host[:1, :1, :1024], non_blocking=True)
+                st.ready[b].record(st.stream)
+        st._issue = tiny_issue
+
+    def one(k):
+        got = st.next()
+        step.bind_clips(bufs[k % 2] if 'ownbufs' in kind else got)
+        step()
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(k_steps):
+        one(k)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / k_steps
+
+
+def hostsync_region(lag, k_steps=40):
+    """The HOST waits for the event behind step k - lag before it launches step k (no stream waits for the training stream)."""
+    evs = [torch.cuda.Event() for _ in range(k_steps + 8)]
+
+    def one(k):
+        if k >= lag:
+            evs[k - lag].synchronize()
+        step.bind_clips(bufs[k % 2])
+        step()
+        evs[k].record()
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(4, 4 + k_steps):
+        one(k)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / k_steps
+
+
+for rep in range(2):
+    for lag in (1, 2, 3):
+        print('host waits for step k-%d before launching step k: %.4f ms per step' % (lag, hostsync_region(lag)), flush=True)
+for rep in range(0):
+    for kind in ('record+cross', 'record+cross+wait', 'record+cross+wait+copy'):
+        for name, ev in (('torch events', TorchEv), ('step marks', MarkEv)):
+            print('%-22s %-13s %.4f ms per step' % (kind, name, region(kind, ev)), flush=True)
+for rep in range(0):
+    for kind in ('tiny', 'tiny+gate', 'tiny+ownbufs', 'full', 'full+gate', 'full+ownbufs', 'full+gate+ownbufs'):
+        print('stager %-18s %.4f ms per step' % (kind, stager_region(kind)), flush=True)
+    print('plain again        %.4f ms per step' % region('plain', TorchEv), flush=True)
