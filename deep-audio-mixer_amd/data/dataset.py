@@ -59,6 +59,10 @@ class MultitrackAudioDataset(data.Dataset):
         self._base_path = base_path
         self._chunk_length = chunk_length
         self._normalize = normalize
+        # staging.StepMark of the training step that consumes iter_batches (ModelTrainer arms it once its step is captured): the
+        # feeder enqueues an upload only when the step enqueued last has reached its backward pass -- a host-to-device copy
+        # beside the forward pass slows the forward's latency-bound launches (profiles/r05_pcie_trace.txt)
+        self.upload_gate = None
         self._compute_features = compute_features
         self._augment = augment_data
         self._sr = sr
@@ -344,6 +348,9 @@ class MultitrackAudioDataset(data.Dataset):
                         # thread waits, not the copy stream: a stream that waits for an event of the training stream costs the
                         # training stream 0.09 ms per step on this stack (profiles/r05_sync_cost_probe.txt), a host wait nothing
                         consumed[slot].synchronize()
+                    gate = self.upload_gate
+                    if gate is not None:
+                        gate.synchronize()          # (a step enqueued BEFORE this batch was handed over: it cannot wait for us)
                     with staging.capture_guard, torch.cuda.device(self._device), torch.cuda.stream(copy_stream):
                         dev[slot][:B].copy_(host[slot][:B], non_blocking=True)
                         uploaded[slot].record(copy_stream)

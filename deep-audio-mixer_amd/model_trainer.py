@@ -35,6 +35,7 @@ import warnings
 
 import torch
 
+_COPY_MARK = os.environ.get('DAM_TRAINER_COPY_MARK', '1') != '0'     # A/B switch: uploads timed by the step mark
 _LOG_EVERY = 10                                   # model_trainer.py:39
 _CKPT_PATTERN = 'mixmodel_{}_1s_{:04d}_{:.4f}.pt'  # model_trainer.py:64
 
@@ -107,6 +108,13 @@ class ModelTrainer:
                           RuntimeWarning, stacklevel=2)
         self._step = self._shape = None
         self._seen = 0
+        # With the fused optimizer the backward kernels write into its flat gradient bucket from the FIRST batch on (what
+        # engine.TrainStep binds for the captured step): the eager batches -- the first EAGER_BATCHES, a ragged last one, every
+        # batch with graph=False -- then run the same launches as the captured ones (queued weight gradients, the equal ones of
+        # a deep stage batched: another pixel split, i.e. another summation order, than the unqueued form), so the loss list
+        # of a run does not depend on which batches happened to be captured.  close() gives the model back to plain autograd.
+        if self._fused and isinstance(self.optimizer, Adam):
+            self.optimizer.bind_grad_slots()
         self.graph_steps = self.eager_steps = 0       # diagnostic: how the training batches were run
         # diagnostic: where the HOST spent a training epoch's wall time (seconds, summed over fit()): waiting for the loader,
         # enqueuing the batch's work, waiting for the previous batch's loss; 'epoch_start' = the part of 'loader' before an epoch's
@@ -189,10 +197,11 @@ class ModelTrainer:
         if pcm is not None:
             B, K, n, ch = pcm.clips.shape
             step = TrainStep(model, opt, K - 1, n, ch, B, pcm.n_fft, pcm.hop, use_graph=True, device=pcm.clips.device,
-                             pcm_dtype=pcm.clips.dtype, track_gains=pcm.gain is not None, normalize=pcm.normalize)
+                             pcm_dtype=pcm.clips.dtype, track_gains=pcm.gain is not None, normalize=pcm.normalize,
+                             copy_mark=_COPY_MARK)
         else:
             B, S, F, T = feats.shape
-            step = TrainStep(model, opt, S, batch=B, feature_shape=(F, T), use_graph=True, device=feats.device)
+            step = TrainStep(model, opt, S, batch=B, feature_shape=(F, T), use_graph=True, device=feats.device, copy_mark=_COPY_MARK)
         keep = [t.clone() for t in (opt._flat, opt._exp_avg, opt._exp_avg_sq, opt._step)]
         bufs = [(b, b.clone()) for b in model.buffers()]
         training = model.training
@@ -237,6 +246,8 @@ class ModelTrainer:
         # step's loss, one batch late) -- a copy stream waiting for the training stream's event would cost the training stream
         # 0.09 ms per step on this stack (profiles/r05_sync_cost_probe.txt)
         st['consumed'][slot].synchronize()
+        # (not timed by the step mark: this loop is host-bound -- the workers' batches arrive every 5.7 ms -- and a blocking wait
+        #  here takes the slack it has: 5.74 -> 5.88 ms per step measured; the feeder THREAD of batch_loader() does wait for it)
         with torch.cuda.stream(st['stream']):
             pcm = host.to_device(dev, out=st['bufs'][slot])
             st['ready'][slot].record(st['stream'])
@@ -252,6 +263,16 @@ class ModelTrainer:
         if st is not None and st.get('busy') is not None:
             st['consumed'][st['busy']].record(torch.cuda.current_stream(torch.device(self.device)))
             st['busy'] = None
+
+    def _arm_gate(self, loader=None):
+        """Times the loader's uploads by the captured step's mark (engine.TrainStep.copy_mark): a MultitrackAudioDataset's
+        feeder thread (``upload_gate``) waits for the step enqueued last to reach its backward pass before it enqueues a
+        host-to-device copy -- beside the forward pass the copy slows the latency-bound launches."""
+        if loader is not None:
+            self._loader = loader
+        ds = getattr(getattr(self, '_loader', None), 'dataset', None)
+        if ds is not None and hasattr(ds, 'upload_gate'):
+            ds.upload_gate = self._step.copy_mark if self._step is not None else None
 
     def _train_batch(self, batch):
         if hasattr(batch, 'to_device'):                        # data.dataset.HostPcmBatch: decoded clips in host memory
@@ -275,6 +296,7 @@ class ModelTrainer:
             if self._step is None:
                 self._resync_adopted()
                 self._step = self._capture(feats, target, pcm)
+                self._arm_gate()
             if pcm is not None:
                 self._step.bind_clips(pcm.clips, pcm.gain)       # an 8-byte address word (+ the gain table): no PCM / feature copy
             else:
@@ -297,6 +319,9 @@ class ModelTrainer:
         if self._step is not None:
             self._step.close()
             self._step = None
+            self._arm_gate()
+        elif getattr(self.optimizer, 'slots_bound', False):
+            self.optimizer.unbind_grad_slots()
         self._push_adopted_state()
 
     # ---- one batch -> loss tensor (on the device)
@@ -339,6 +364,7 @@ class ModelTrainer:
             total += value
 
         step = 0
+        self._arm_gate(loader if train else None)
         ht, clock = self.host_times, time.perf_counter
         t0 = clock()
         it = iter(loader)                 # (a DataLoader with num_workers > 0 forks its workers here, every epoch)

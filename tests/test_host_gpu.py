@@ -296,6 +296,71 @@ def test_train_step_bind_clips_reads_resident_batches_in_place(dam):
         step.bind_clips(pool[:2].cpu())
 
 
+def test_step_mark_orders_a_copy_stream_inside_a_captured_step(dam):
+    """include/dam_hip.h, dam_step_mark_*: (a) a mark recorded inside a captured graph is re-recorded by every replay and a stream
+    outside the graph that waits for it runs BETWEEN the kernels around the mark (never before: 0); (b) TrainStep(copy_mark=True)
+    fed by BatchStager(gate=step.copy_mark) -- uploads from page-locked memory timed by the mark, three staging buffers, host-side
+    waits -- gives bitwise the losses of the same batches read HBM-resident, and the mark does not change the step."""
+    from deep_audio_mixer_amd import staging
+    from deep_audio_mixer_amd.engine import TrainStep
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    a = torch.zeros(1 << 26, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    seen = torch.zeros(6, dtype=torch.int32, device='cuda')
+    mark = staging.StepMark()
+
+    def body():
+        a.add_(1.0)
+        flag.fill_(1)
+        mark.record()
+        for _ in range(8):
+            a.add_(1.0)
+        flag.fill_(2)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    side = torch.cuda.Stream()
+    for k in range(6):
+        flag.zero_()
+        g.replay()
+        with torch.cuda.stream(side):
+            mark.wait(side)
+            seen[k:k + 1].copy_(flag)
+        torch.cuda.current_stream().wait_stream(side)
+    mark.synchronize()
+    torch.cuda.synchronize()
+    got = seen.tolist()
+    assert got[0] in (1, 2) and all(v == 1 for v in got[1:]), got      # (a fresh graph's first replay may hold the waiter longer)
+
+    g2 = torch.Generator(device='cuda').manual_seed(5)
+    pool = 0.1 * torch.randn((8, 3, 16 * 1024, 2), generator=g2, device='cuda')      # four batches of two clips, mix last
+    pool[:, 2] = pool[:, :2].sum(1)
+    host = torch.empty(pool.shape, dtype=pool.dtype, pin_memory=True)
+    host.copy_(pool)
+    losses = []
+    for kind in ('resident', 'resident+mark', 'streamed', 'streamed+mark'):
+        torch.manual_seed(1)
+        model = ResNet18(n_stems=2, input_shape=(1025, 17)).cuda().train()
+        step = TrainStep(model, Adam(model.parameters(), weight_decay=1e-5), 2, 16 * 1024, 2, batch=2, use_graph=True,
+                         copy_mark='mark' in kind)
+        assert (step.copy_mark is not None) == ('mark' in kind)
+        step.load_clips(pool[:2])
+        step.capture(warmup=2)
+        st = staging.BatchStager(host, 2, 'cuda', gate=step.copy_mark) if 'streamed' in kind else None
+        out = []
+        for k in range(9):
+            step.bind_clips(st.next() if st is not None else pool[2 * (k % 4):2 * (k % 4) + 2])
+            out.append(step().clone())      # (the loss tensor is the graph's own: one address)
+        losses.append([float(v) for v in torch.stack(out).cpu()])
+        step.close()
+    assert losses[0] == losses[1] == losses[2] == losses[3]
+
+
 def test_mix_song_smooth_matches_oracle(dam):
     from deep_audio_mixer_amd.data.dataset import MultitrackAudioDataset
     from deep_audio_mixer_amd.inference_utils import mix_song_smooth
