@@ -507,10 +507,16 @@ def run_train(name, cfg, args):
     dog.phase('eager warm-up steps + graph capture')
     step.capture(warmup=2)
 
+    resident = [clips[j:j + B] for j in range(0, n_resident, B)]
+    if not args.bind_per_step:
+        # inputs stay where they are in HBM: the front-end walks a device table of the resident batches with the optimizer's
+        # device-side step count (DAM_PCM_ROTATE) -- nothing is launched between the graph replays
+        step.bind_rotation(resident)
+
     def run(k, first):
         for i in range(k):
-            j = ((first + i) % (n_resident // B)) * B
-            step.bind_clips(clips[j:j + B])      # inputs stay where they are in HBM: the front-end's address word is re-pointed
+            if args.bind_per_step:               # A/B: the address word re-pointed per step (a fill launch between the replays)
+                step.bind_clips(resident[(first + i) % len(resident)])
             step()
 
     def timed(fn, k, first):
@@ -628,9 +634,15 @@ def run_train(name, cfg, args):
             host[lo:hi].copy_(synth_clips(hi - lo, S, n, device, 99 + rank + lo))
         stager = staging.BatchStager(host, B, device, gate=step.copy_mark)
 
+        if not args.bind_per_step:
+            # the staging buffers are walked by the same device table: buffer stager.k % 3 is the next one to be read
+            step.bind_rotation(stager.bufs, first=stager.k % len(stager.bufs))
+
         def run_streamed(k, first):
             for _ in range(k):
-                step.bind_clips(stager.next())   # the staging buffer the upload landed in is read in place
+                got = stager.next()              # the staging buffer the upload landed in is read in place
+                if args.bind_per_step:
+                    step.bind_clips(got)
                 step()
         run_streamed(max(2, args.warmup), 0)
         dts = timed(run_streamed, args.steps, 0)
@@ -939,6 +951,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-host-stream', action='store_true')
+    ap.add_argument('--bind-per-step', action='store_true', help='A/B: re-point the front-end per step instead of the device-side rotation')
     ap.add_argument('--no-copy-mark', action='store_true', help='A/B: the streamed leg\'s uploads start at step ends (no step mark)')
     ap.add_argument('--host-clips', type=int, default=N_HOST_CLIPS)
     ap.add_argument('--breakdown', action='store_true', help='N > 1: add per-phase timings of the step (diagnostic)')

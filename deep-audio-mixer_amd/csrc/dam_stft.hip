@@ -127,6 +127,19 @@ constexpr int TF2 = 8;                 // frames (= waves) per workgroup tile
 constexpr int TROW = NBINS + 3;        // tile row pitch in floats (1028: rows stay 16-byte aligned)
 constexpr int PLANE = 16 * ROW;        // floats of one exchange plane (1088 >= 1024)
 
+// indirect: 0 = `pcm` is the batch; 1 = DAM_PCM_INDIRECT, a device word holding its address; 2 = DAM_PCM_ROTATE, a device table
+// {address of an int64 step counter, n, offset, addr[0..n)}: the batch is addr[(counter + offset) % n] (include/dam_hip.h)
+template <typename PCM>
+__device__ __forceinline__ const PCM* resolve_pcm(const PCM* pcm, int indirect) {
+    if (indirect == 2) {
+        const long long* t = reinterpret_cast<const long long*>(pcm);
+        const long long c = *reinterpret_cast<const long long*>(t[0]) + t[2];
+        return reinterpret_cast<const PCM*>(t[3 + (c % t[1])]);
+    }
+    if (indirect) return *reinterpret_cast<const PCM* const*>(pcm);
+    return pcm;
+}
+
 template <typename PCM, int CH, bool PLANAR>
 __global__ __launch_bounds__(TF2* WAVE, 4) void stft2048_kernel(
     const PCM* __restrict__ pcm, int64_t n_samples, int64_t outer_stride, int n_inner, int64_t inner_stride, int64_t cs,
@@ -134,8 +147,9 @@ __global__ __launch_bounds__(TF2* WAVE, 4) void stft2048_kernel(
     int n_frames, int tiles_per_track, int n_tiles, float amin, float floor_db, int normalize, float* __restrict__ out,
     float* __restrict__ out_tail, int n_tail, int indirect) {
     // DAM_PCM_INDIRECT: `pcm` is a device word that holds the batch's address (a captured launch then follows whichever
-    // resident batch the word points at: no copy into a fixed input buffer)
-    if (indirect) pcm = *reinterpret_cast<const PCM* const*>(pcm);
+    // resident batch the word points at: no copy into a fixed input buffer); DAM_PCM_ROTATE: a table of batches walked by a
+    // device-side step counter
+    pcm = resolve_pcm(pcm, indirect);
     __shared__ __attribute__((aligned(16))) float2 tw1s[16 * 64];      // [k1][lane]  W_1024^(lane*k1)
     __shared__ __attribute__((aligned(16))) float2 tw2s[16 * 4];       // [c][b]      W_64^(b*c)
     __shared__ __attribute__((aligned(16))) float planes[TF2 * PLANE];
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(
     const float* __restrict__ window, const float2* __restrict__ tw /* W_nfft^k */, const float* __restrict__ gain, int n_fft,
     int hop, int n_frames, float amin, float floor_db, int normalize, float* __restrict__ out, float* __restrict__ out_tail,
     int n_tail, int indirect) {
-    if (indirect) pcm = *reinterpret_cast<const PCM* const*>(pcm);
+    pcm = resolve_pcm(pcm, indirect);
     extern __shared__ __attribute__((aligned(16))) float2 buf[];      // [2][M]
     __shared__ float red[256];
     const int tid = threadIdx.x;
@@ -486,10 +500,11 @@ extern "C" int dam_stft_logmag_strided_f32(const void* pcm, int pcm_dtype, int64
     bool fast = n_fft == NFFT && !(hop & 1);               // the tuned 2048-point kernel; else any power of two 64..4096
     // 16-bit mono tracks at an odd sample stride start on odd 2-byte boundaries: the tuned kernel's 4-byte point loads would
     // be misaligned, the generic kernel reads sample by sample
-    if ((pcm_dtype & ~DAM_PCM_INDIRECT) == DAM_PCM_S16 && channels == 1 && ((outer_stride | inner_stride) & 1)) fast = false;
+    if ((pcm_dtype & ~(DAM_PCM_INDIRECT | DAM_PCM_ROTATE)) == DAM_PCM_S16 && channels == 1 && ((outer_stride | inner_stride) & 1)) fast = false;
     if (!fast && (n_fft < 64 || n_fft > 16384 || (n_fft & (n_fft - 1)))) return DAM_ERR_UNSUPPORTED;    // (two LDS buffers of n_fft/2 points: 128 KB at 16384)
-    const int indirect = (pcm_dtype & DAM_PCM_INDIRECT) ? 1 : 0;
-    pcm_dtype &= ~DAM_PCM_INDIRECT;
+    if ((pcm_dtype & DAM_PCM_INDIRECT) && (pcm_dtype & DAM_PCM_ROTATE)) return DAM_ERR_BAD_ARG;
+    const int indirect = (pcm_dtype & DAM_PCM_ROTATE) ? 2 : (pcm_dtype & DAM_PCM_INDIRECT) ? 1 : 0;
+    pcm_dtype &= ~(DAM_PCM_INDIRECT | DAM_PCM_ROTATE);
     if (pcm_dtype != DAM_PCM_F32 && pcm_dtype != DAM_PCM_F64 && pcm_dtype != DAM_PCM_S16 && pcm_dtype != DAM_PCM_S32)
         return DAM_ERR_UNSUPPORTED;
     const int64_t n_tracks = n_outer * n_inner;

@@ -32,6 +32,8 @@ from . import distributed, features, layers, ops
 
 
 class TrainStep:
+    MAX_ROTATION = 64
+
     def __init__(self, model, optimizer, n_stems, n_samples=None, channels=2, batch=8, n_fft=2048, hop=1024,
                  use_graph=True, device=None, overlap=True, feature_shape=None, pcm_dtype=torch.float32, track_gains=False,
                  normalize=False, copy_mark=False):
@@ -51,14 +53,19 @@ class TrainStep:
         self.from_features = feature_shape is not None
         if self.from_features:
             f, t = feature_shape
-            self.pcm = self.pcm_word = self._bound = None
+            self.pcm = self.pcm_word = self.pcm_table = self._bound = None
         else:
             f, t = n_fft // 2 + 1, features.num_frames(n_samples, hop)
             # stems and mix of a batch live in ONE buffer ([B, S+1, n, ch], mix last): the front-end is one launch
             self.pcm = torch.zeros((batch, n_stems + 1, n_samples, channels), dtype=pcm_dtype, device=dev)
-            # the front-end reads the batch THROUGH this device word (DAM_PCM_INDIRECT): it points at self.pcm unless
-            # bind_clips() re-pointed it at another resident batch -- a graph replay then reads that batch in place, no copy
-            self.pcm_word = torch.full((1,), self.pcm.data_ptr(), dtype=torch.int64, device=dev)
+            # the front-end reads the batch THROUGH this device table (DAM_PCM_ROTATE: {address of the optimizer's step count, n,
+            # offset, addr[0..n)} -> addr[(count + offset) % n]): one entry pointing at self.pcm unless bind_clips() re-pointed
+            # it at another resident batch, or bind_rotation() filled it with n batches the replays then walk by themselves --
+            # a graph replay reads its batch in place, no copy, and with a rotation nothing is launched between the replays
+            self.pcm_table = torch.zeros(3 + self.MAX_ROTATION, dtype=torch.int64, device=dev)
+            self.pcm_table[:4] = torch.tensor([optimizer._step.data_ptr(), 1, 0, self.pcm.data_ptr()], dtype=torch.int64)
+            self.pcm_word = self.pcm_table[3:4]        # (the single-batch form re-points entry 0)
+            self._rotation = 1
             self._bound = self.pcm
         self.gain = torch.ones((batch, n_stems + 1), dtype=torch.float32, device=dev) if track_gains and not self.from_features else None
         self.normalize = bool(normalize)
@@ -140,7 +147,7 @@ class TrainStep:
         if self.from_features:
             return
         features.stft_logmag_clips(self.pcm, self.n_fft, self.hop, gain=self.gain, normalize=self.normalize, out_stems=self.x,
-                                   out_mix=self.gt, pcm_word=self.pcm_word)
+                                   out_mix=self.gt, pcm_table=self.pcm_table)
 
     def _fwd_bwd(self):
         self._front_end()
@@ -221,9 +228,33 @@ class TrainStep:
 
     # -- public ---------------------------------------------------------------------------------
     def _point_at(self, t):
+        if self._rotation != 1:
+            self.pcm_table[1:3].zero_()
+            self.pcm_table[1:2].fill_(1)
+            self._rotation, self._bound = 1, None
         if self._bound is not t or self._bound_ptr != t.data_ptr():
             self.pcm_word.fill_(t.data_ptr())       # one tiny launch on the current stream, ordered with the steps around it
             self._bound, self._bound_ptr = t, t.data_ptr()
+
+    def bind_rotation(self, batches, first=0):
+        """The next steps read batches[first], batches[first + 1], ... (cyclically) IN PLACE, one per step, with nothing launched
+        between the replays: the front-end indexes a device table of the n addresses with the optimizer's device-side step
+        count (DAM_PCM_ROTATE).  batches: 1..MAX_ROTATION contiguous tensors like ``self.pcm`` on this device (resident
+        batches, or the staging buffers of an uploader); the caller keeps them valid.  Synchronises once (reads the step
+        count); ``bind_clips`` / ``load_*`` return to the single-batch form."""
+        n = len(batches)
+        if not 1 <= n <= self.MAX_ROTATION:
+            raise ValueError('bind_rotation: 1..%d batches' % self.MAX_ROTATION)
+        for t in batches:
+            if t.device != self.pcm.device or t.dtype != self.pcm.dtype or tuple(t.shape) != tuple(self.pcm.shape) \
+                    or not t.is_contiguous():
+                raise ValueError('bind_rotation: contiguous %s %s tensors on %s' % (self.pcm.dtype, tuple(self.pcm.shape), self.pcm.device))
+        if self.gain is not None:
+            self.gain.fill_(1.0)
+        now = int(self.opt._step.item())
+        words = [self.opt._step.data_ptr(), n, (first - now) % n] + [t.data_ptr() for t in batches]
+        self.pcm_table[:len(words)].copy_(torch.tensor(words, dtype=torch.int64))
+        self._rotation, self._bound, self._bound_ptr = n, list(batches), None
 
     _bound_ptr = None
 

@@ -99,13 +99,17 @@ def stft_logmag_song_chunks(pcm, n_chunks, chunk_samples, n_fft=2048, hop=1024, 
     return out
 
 
-def stft_logmag_clips(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out_stems=None, out_mix=None, pcm_word=None):
+def stft_logmag_clips(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out_stems=None, out_mix=None, pcm_word=None,
+                      pcm_table=None):
     """pcm: CUDA [B, S+1, n, channels] (or [B, S+1, n]) float32/float64 -- a batch of clips, every clip's S stems
     followed by its mix, interleaved channels (what data/dataset.py:192-196 reads per item).  ONE launch for all
     B*(S+1) tracks; returns (x [B, S, F, T], gt [B, F, T]) float32 dB -- the collated (train_features, gt_features) of
     data/dataset.py:207-210.  gain: optional [B, S+1] augmentation draws (data/dataset.py:198-199, the mix included).
     pcm_word: optional CUDA int64[1] holding the ADDRESS of the batch to read (DAM_PCM_INDIRECT, include/dam_hip.h); `pcm`
-    then only describes shape and dtype -- a captured launch follows the word (engine.TrainStep.bind_clips)."""
+    then only describes shape and dtype -- a captured launch follows the word.  pcm_table: optional CUDA int64 table
+    {address of a step counter, n, offset, addr[0..n)} (DAM_PCM_ROTATE): the launch reads addr[(counter + offset) % n] -- a
+    captured step walks n batches without anything being re-pointed between the replays (engine.TrainStep.bind_clips /
+    bind_rotation)."""
     _lib.require_cuda(pcm, gain, out_stems, out_mix)
     if pcm.dim() == 3:
         pcm = pcm.unsqueeze(-1)
@@ -135,6 +139,11 @@ def stft_logmag_clips(pcm, n_fft=2048, hop=1024, gain=None, normalize=False, out
         if pcm_word.dtype != torch.int64 or pcm_word.numel() != 1:
             raise ValueError('pcm_word: one int64 on the device')
         src, flag = _lib.ptr(pcm_word), 0x100
+    if pcm_table is not None:
+        _lib.require_cuda(pcm_table)
+        if pcm_word is not None or pcm_table.dtype != torch.int64 or pcm_table.numel() < 4 or not pcm_table.is_contiguous():
+            raise ValueError('pcm_table: a contiguous int64 table on the device (and no pcm_word beside it)')
+        src, flag = _lib.ptr(pcm_table), 0x200
     st = _lib.lib().dam_stft_logmag_strided_f32(src, code | flag, B, K * n * ch, K,
                                                 n * ch, n, ch, ch, 1, _lib.ptr(win), _lib.ptr(tw), _lib.ptr(gain), n_fft,
                                                 hop, AMIN, 1 if normalize else 0, _lib.ptr(out_stems), _lib.ptr(out_mix), 1,

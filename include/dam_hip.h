@@ -44,6 +44,12 @@ typedef enum dam_pcm_dtype { DAM_PCM_F32 = 0, DAM_PCM_F64 = 1, DAM_PCM_S16 = 2, 
  * starts.  A launch captured in a hipGraph then follows whichever resident batch the word points at -- the caller re-points
  * the word (8 bytes) instead of copying a batch into the graph's fixed input buffer.  Layout arguments describe the pointee. */
 #define DAM_PCM_INDIRECT 0x100
+/* OR-ed into pcm_dtype instead: `pcm` is a DEVICE table of int64 words {address of an int64 step counter, n, offset, addr[0] ...
+ * addr[n-1]} and the launch reads the batch at addr[(counter + offset) % n].  With the optimizer's device-side step count as the
+ * counter (dam_adam_l2_step_f32 advances it inside the captured step) a replayed step walks n resident batches -- or the n
+ * staging buffers of an uploader -- with NO launch between the replays: re-pointing the DAM_PCM_INDIRECT word was a 4.8 us fill
+ * launch behind an 8 us gap per step (profiles/r05_C3_step_timeline.txt, the last line).  n >= 1, counter + offset >= 0. */
+#define DAM_PCM_ROTATE 0x200
 struct dam_bn_fin;      /* defined in the BatchNorm section */
 struct dam_bn_bwd_sums; /* defined in the BatchNorm section */
 

@@ -296,6 +296,44 @@ def test_train_step_bind_clips_reads_resident_batches_in_place(dam):
         step.bind_clips(pool[:2].cpu())
 
 
+def test_train_step_bind_rotation_walks_resident_batches(dam):
+    """bind_rotation(): the captured front-end indexes a device table of batch addresses with the optimizer's device-side step
+    count (DAM_PCM_ROTATE) -- nothing is re-pointed between the replays; bitwise the losses of bind_clips() per step, from any
+    starting entry, and bind_clips() afterwards returns to the single-batch form."""
+    from deep_audio_mixer_amd.engine import TrainStep
+    from deep_audio_mixer_amd.models.model_resnet import ResNet18
+    from deep_audio_mixer_amd.optim import Adam
+    g = torch.Generator(device='cuda').manual_seed(6)
+    pool = 0.1 * torch.randn((6, 3, 16 * 1024, 2), generator=g, device='cuda')      # three batches of two clips, mix last
+    pool[:, 2] = pool[:, :2].sum(1)
+    batches = [pool[0:2], pool[2:4], pool[4:6]]
+    order = [1, 2, 0, 1, 2, 0, 1] + [2, 2]
+    losses = []
+    for rotate in (False, True):
+        torch.manual_seed(1)
+        model = ResNet18(n_stems=2, input_shape=(1025, 17)).cuda().train()
+        step = TrainStep(model, Adam(model.parameters(), weight_decay=1e-5), 2, 16 * 1024, 2, batch=2, use_graph=True)
+        step.load_clips(batches[0])
+        step.capture(warmup=2)
+        out = []
+        if rotate:
+            step.bind_rotation(batches, first=1)
+        for k in order[:7]:
+            if not rotate:
+                step.bind_clips(batches[k])
+            out.append(step().item())
+        for k in order[7:]:                       # back to the single-batch form
+            step.bind_clips(batches[k])
+            out.append(step().item())
+        losses.append(out)
+        step.close()
+    assert losses[0] == losses[1]
+    with pytest.raises(ValueError):
+        step.bind_rotation([])
+    with pytest.raises(ValueError):
+        step.bind_rotation([pool[0:2].double()])
+
+
 def test_step_mark_orders_a_copy_stream_inside_a_captured_step(dam):
     """include/dam_hip.h, dam_step_mark_*: (a) a mark recorded inside a captured graph is re-recorded by every replay and a stream
     outside the graph that waits for it runs BETWEEN the kernels around the mark (never before: 0); (b) TrainStep(copy_mark=True)
