@@ -543,6 +543,25 @@ def run_train(name, cfg, args):
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
+    # N > 1: how should the staged step exchange its buckets ON THIS NODE?  'overlapped' hides the big bucket's all-reduce behind
+    # graph A2 but makes RCCL's stream wait for an event of the training stream (0.10-0.13 ms per step for the event traffic alone,
+    # measured with one rank: profiles/r05_nccl_sync_probe.txt) and puts RCCL's kernels beside A2's 248-workgroup kernels; 'inline'
+    # runs synchronous collectives on the training stream (nothing waits across streams, nothing overlaps).  Both are timed over
+    # the same three graphs before the warm-up; every rank sees the same (max-over-ranks) times and keeps the faster one.
+    reduce_cal = None
+    three_graphs = world > 1 and step.staged and step._graphs is not None and len(step._graphs) == 3
+    if three_graphs:
+        dog.phase('reduce-mode calibration')
+        if args.reduce_mode == 'auto':
+            reduce_cal, n_cal = {}, max(5, args.steps // 2)
+            for mode in ('overlapped', 'inline'):
+                step.reduce_mode = mode
+                run(2, 0)
+                reduce_cal[mode] = 1e3 * timed(run, n_cal, 0) / n_cal
+            step.reduce_mode = min(reduce_cal, key=reduce_cal.get)
+        else:
+            step.reduce_mode = args.reduce_mode
+    chosen_mode = step.reduce_mode if three_graphs else None
     dog.phase('warm-up steps')
     run(args.warmup, 0)
     step.measure_exposed = world > 1
@@ -569,10 +588,11 @@ def run_train(name, cfg, args):
     # the SAME three graphs: the all-reduces beside A2 (as `value` was measured) and both started only after A2, each with
     # HIP events around graph A2.  One SCALE record then says which schedule the node prefers and what the overlap cost A2.
     overlap_ab = None
-    if world > 1 and step.staged and step._graphs is not None and len(step._graphs) == 3:
+    if three_graphs:
         dog.phase('overlap A/B regions')
         ab = {}
-        for label, ov in (('overlapped', True), ('serialized', False)):
+        for label, ov in (('overlapped', True), ('serialized', False), ('inline', True)):
+            step.reduce_mode = 'inline' if label == 'inline' else 'overlapped'
             step.overlap_reduce, step.measure_a2, step.measure_exposed = ov, True, True
             d = timed(run, args.steps, args.warmup)
             a2, ex = step.a2_ms(), step.exposed_wait_ms()
@@ -581,11 +601,15 @@ def run_train(name, cfg, args):
             ab[label] = {'ms_per_step': 1e3 * d / args.steps, 'graph_A2_ms': [g[0] for g in got],
                          'exposed_allreduce_wait_ms': [g[1] for g in got]}
         step.overlap_reduce, step.measure_a2, step.measure_exposed = True, False, False
+        step.reduce_mode = chosen_mode
         a2o, a2s = max(ab['overlapped']['graph_A2_ms']), max(ab['serialized']['graph_A2_ms'])
-        overlap_ab = dict(ab, overlap_pays=bool(ab['overlapped']['ms_per_step'] < ab['serialized']['ms_per_step']),
+        overlap_ab = dict(ab, overlap_pays=bool(ab['overlapped']['ms_per_step'] < min(ab['serialized']['ms_per_step'],
+                                                                                      ab['inline']['ms_per_step'])),
                           graph_A2_slowdown_from_overlap=(a2o / a2s if a2s else None),
-                          note='same three graphs; "serialized" starts both all-reduces after graph A2 has been enqueued; '
-                               'graph_A2_ms = HIP events around graph A2 per rank (events are recorded in these two regions only)')
+                          note='same three graphs; "serialized" starts both asynchronous all-reduces after graph A2 has been '
+                               'enqueued; "inline" runs synchronous all-reduces on the training stream (no stream waits for the '
+                               'training stream; exposed_allreduce_wait_ms is then the small bucket\'s whole exchange); '
+                               'graph_A2_ms = HIP events around graph A2 per rank (events are recorded in these regions only)')
     dog.phase('replica sync proof')
     sync = replica_sync_proof(model, opt, device, dev_index, world)
 
@@ -597,7 +621,9 @@ def run_train(name, cfg, args):
                    'hip_graph': not args.no_graph, 'final_loss': loss, 'world_size': world, 'device_index': dev_index,
                    'dist_backend': (backend if world > 1 else None),
                    'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == 'nccl' else None,
-                   'grad_buckets': opt.n_buckets, 'allreduce_overlap': bool(step.staged),
+                   'grad_buckets': opt.n_buckets, 'allreduce_overlap': bool(step.staged) and chosen_mode != 'inline',
+                   # how `value` exchanged its gradient buckets, and the calibration that chose it (ms per step, max over ranks)
+                   'reduce_mode': chosen_mode, 'reduce_mode_calibration_ms': reduce_cal,
                    # N > 1: proof that the ranks were N distinct devices and that the all-reduce averaged -- replicas that
                    # each saw DIFFERENT clips hold bit-identical parameters after the timed steps (None on one rank)
                    'replicas_in_sync': sync['replicas_in_sync'], 'replica_checksums': sync['checksums'],
@@ -948,6 +974,8 @@ def main():
     ap.add_argument('--config', choices=sorted(CONFIGS), default='C3')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='N > 1: one un-overlapped all-reduce of the whole flat buffer')
+    ap.add_argument('--reduce-mode', choices=('auto', 'overlapped', 'inline'), default='auto',
+                    help='N > 1: all-reduces beside backward on RCCL\'s stream, on the training stream, or whichever is faster here')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-host-stream', action='store_true')

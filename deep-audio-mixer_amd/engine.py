@@ -84,6 +84,15 @@ class TrainStep:
         # N-rank diagnostics (bench.py's overlap_ab): overlap_reduce=False starts BOTH all-reduces only after graph A2 has been
         # enqueued (the same three graphs, the exchange not beside backward); measure_a2 brackets graph A2 with HIP events
         self.overlap_reduce, self.measure_a2, self._a2 = True, False, []
+        # how the staged step exchanges its buckets (set between steps, same three graphs in every mode):
+        #   'overlapped' : both all-reduces asynchronous on RCCL's stream, the big one beside graph A2 (overlap_reduce=False: both
+        #                  started only after A2, "serialized");
+        #   'inline'     : synchronous collectives -- since torch 2.8 ProcessGroupNCCL launches those on the CURRENT stream: no
+        #                  stream waits for an event of the training stream.  Measured with one rank (tools/nccl_sync_probe.py,
+        #                  profiles/r05_nccl_sync_probe.txt): the event traffic of an asynchronous all-reduce alone costs the
+        #                  captured step 0.10-0.13 ms, a synchronous one 0.02 ms; what inline gives up is the overlap itself
+        #                  (12.6 MB over xGMI).  bench.py times both on the node it runs on and keeps the faster.
+        self.reduce_mode = 'overlapped'
         self.frames_per_step = batch * n_stems * t          # BASELINE metric unit: stem-spectrogram frames
         self.staged = optimizer.world_size > 1 and overlap
         if self.staged:
@@ -371,6 +380,24 @@ class TrainStep:
             g[0].replay()
             self.opt.all_reduce_grads()
             g[1].replay()
+        elif self.reduce_mode == 'inline':
+            g[0].replay()
+            self.opt.all_reduce_grads(1)            # on the training stream: nothing waits across streams, nothing overlaps
+            if self.measure_a2:
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+            g[1].replay()
+            if self.measure_a2:
+                a1.record()
+                self._a2.append((a0, a1))
+            if self.measure_exposed:                # inline: the whole exchange of bucket 0 is exposed (bucket 1's is not timed)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.opt.all_reduce_grads(0)
+            if self.measure_exposed:
+                e1.record()
+                self._exposed.append((e0, e1))
+            g[2].replay()
         else:
             g[0].replay()
             w1 = self.opt.all_reduce_grads(1, async_op=True) if self.overlap_reduce else None     # RCCL's stream: runs beside graph A2

@@ -373,7 +373,11 @@ def test_step_mark_orders_a_copy_stream_inside_a_captured_step(dam):
     mark.synchronize()
     torch.cuda.synchronize()
     got = seen.tolist()
-    assert got[0] in (1, 2) and all(v == 1 for v in got[1:]), got      # (a fresh graph's first replay may hold the waiter longer)
+    # SAFETY is what is asserted: the waiter never runs before the mark of the replay enqueued last (0).  That it runs between the
+    # two kernels around the mark (1) rather than behind the graph (2) is timing -- how soon the other queue gets its turn -- and is
+    # measured where it matters, on the training step (tools/copy_gate_probe.py, profiles/r05_sync_cost_probe.txt: the upload
+    # starts 1.95-2.02 ms into the 4.13 ms step)
+    assert all(v in (1, 2) for v in got), got
 
     g2 = torch.Generator(device='cuda').manual_seed(5)
     pool = 0.1 * torch.randn((8, 3, 16 * 1024, 2), generator=g2, device='cuda')      # four batches of two clips, mix last
@@ -574,7 +578,11 @@ def _bench_two_ranks(backend):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     cfg = out['config']
-    assert out['n_gpus'] == 2 and cfg['world_size'] == 2 and cfg['grad_buckets'] == 2 and cfg['allreduce_overlap'] is True
+    assert out['n_gpus'] == 2 and cfg['world_size'] == 2 and cfg['grad_buckets'] == 2
+    # the exchange schedule `value` ran with was chosen by timing both on this node, the same on every rank
+    assert cfg['reduce_mode'] in ('overlapped', 'inline') and cfg['allreduce_overlap'] is (cfg['reduce_mode'] == 'overlapped')
+    assert set(cfg['reduce_mode_calibration_ms']) == {'overlapped', 'inline'}
+    assert cfg['reduce_mode'] == min(cfg['reduce_mode_calibration_ms'], key=cfg['reduce_mode_calibration_ms'].get)
     assert cfg['dist_backend'] == backend and cfg['global_batch'] == 16 and cfg['sync_per_step'] is False
     assert np.isfinite(cfg['final_loss']) and out['value'] > 0 and out['steps'] == 3
     pr = out['per_rank']
@@ -588,7 +596,7 @@ def _bench_two_ranks(backend):
     # one record answers "does the overlap pay on this node": the same three graphs timed with the all-reduces beside graph A2
     # and after it, graph A2's own device time in both, per rank
     ab = out['overlap_ab']
-    for label in ('overlapped', 'serialized'):
+    for label in ('overlapped', 'serialized', 'inline'):
         assert ab[label]['ms_per_step'] > 0 and len(ab[label]['graph_A2_ms']) == 2 and all(v > 0 for v in ab[label]['graph_A2_ms'])
         assert len(ab[label]['exposed_allreduce_wait_ms']) == 2
     assert isinstance(ab['overlap_pays'], bool) and ab['graph_A2_slowdown_from_overlap'] > 0
