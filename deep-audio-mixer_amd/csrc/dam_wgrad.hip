@@ -52,6 +52,15 @@ struct WgradJobs {
     int relu_in[WG_MAX_JOBS];             // per job (with sc): a block's conv2 reads relu(bn1(c1)), its conv1 the plain block input
 };
 
+// Jobs of a batched launch of the direct kernel (see wgrad_direct_batch_kernel): each with its own geometry and grid share.
+constexpr int WD_MAX_JOBS = 8;
+struct DirectJob {
+    const float* X; const float* dY; float* partial;
+    int rows, Ho, Wo, H, W, C, N, s, pad, dil, tiles_k;
+    int nx, nsplit, wg0;                     // the job's (nx, nsplit) grid and its first workgroup in the flat launch
+};
+struct DirectJobs { DirectJob job[WD_MAX_JOBS]; int njobs; };
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -372,11 +381,20 @@ struct PendingTile {
     int n_real[WG_MAX_JOBS], k_real[WG_MAX_JOBS];
     int (*launch)(WgradQueue*, hipStream_t);
 };
+// direct-kernel launches of one instantiation recorded, not yet launched (any geometry: every job carries its own)
+struct PendingDirect {
+    int sig;                                 // TNB | TKB << 4 | KH << 8 | KW << 12
+    DirectJobs jobs;                         // jobs.njobs == 0: nothing pending
+    float* dw[WD_MAX_JOBS];
+    int n_real[WD_MAX_JOBS], k_real[WD_MAX_JOBS];
+    int (*launch)(WgradQueue*, hipStream_t);
+};
 struct WgradQueue {
     unsigned magic;
     int batching;                            // 1: same-geometry tile launches may wait for each other until the flush
     ReduceBatch batch;
     PendingTile pend;
+    PendingDirect pend_direct;
 };
 constexpr unsigned WGRAD_QUEUE_MAGIC = 0x57475251u;     // "WGRQ"
 
@@ -1198,15 +1216,16 @@ int launch_wgrad_rows_s2(int B, int H, int W, int C, int Ho, int Wo, int N, cons
 //   1x1: the strided shortcut of a down-sampling block (models/model_resnet.py:18-21) -- a skinny memory-bound GEMM;
 //   3x3: the strided first convolution of those blocks (a staged patch would hold both column parities of every row).
 // Output: the same partial slabs + reduce kernel as the other variants.
+// (bx, by) of a (gx, gy) grid: the launch's own block indices, or a job's share of a batched launch
 template <int TNB, int TKB, int KH, int KW>
-__global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restrict__ X, const float* __restrict__ dY, int rows,
-                                                           int Ho, int Wo, int H, int W, int C, int N, int s, int pad, int dil,
-                                                           int tiles_k, float* __restrict__ partial) {
+__device__ __forceinline__ void wgrad_direct_body(const float* __restrict__ X, const float* __restrict__ dY, int rows, int Ho, int Wo,
+                                                  int H, int W, int C, int N, int s, int pad, int dil, int tiles_k,
+                                                  float* __restrict__ partial, int bx, int by, int gx, int gy) {
     constexpr int NBLK = TNB * TKB * KH * KW, U = KH * KW == 1 ? 8 : 4;
     __shared__ float4 red[NBLK * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    const int tn = bx / tiles_k, tk = bx - tn * tiles_k;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY), 0, 0x7fffffff, 0x00020000);
     v4f acc[NBLK];
@@ -1215,7 +1234,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
     const int steps = (Wo + 3) >> 2;
     const int lane_x = (kq * s * C + tk * TKB * 16 + j) * 4, lane_d = (kq * N + tn * TNB * 16 + j) * 4;   // bytes
     const int step_x = 4 * s * C * 4, step_d = 4 * N * 4;
-    for (int row = blockIdx.y * 4 + wave; row < rows; row += gridDim.y * 4) {        // row = (image, output row)
+    for (int row = by * 4 + wave; row < rows; row += gy * 4) {        // row = (image, output row)
         const int img = row / Ho, oh = row - img * Ho;
         const int ds = (int)(((int64_t)row * Wo) * N * 4);                           // scalar byte offsets (< 2^31: host check)
         for (int t0 = 0; t0 < steps; t0 += U) {
@@ -1272,8 +1291,63 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
         }
         __syncthreads();
     }
-    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NBLK * 64;
+    float4* out = reinterpret_cast<float4*>(partial) + ((size_t)by * gx + bx) * NBLK * 64;
     for (int e = tid; e < NBLK * 64; e += 256) out[e] = red[e];
+}
+
+template <int TNB, int TKB, int KH, int KW>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restrict__ X, const float* __restrict__ dY, int rows,
+                                                           int Ho, int Wo, int H, int W, int C, int N, int s, int pad, int dil,
+                                                           int tiles_k, float* __restrict__ partial) {
+    wgrad_direct_body<TNB, TKB, KH, KW>(X, dY, rows, Ho, Wo, H, W, C, N, s, pad, dil, tiles_k, partial, blockIdx.x, blockIdx.y,
+                                        gridDim.x, gridDim.y);
+}
+
+// Direct launches of ONE instantiation and DIFFERENT geometries in one launch (round 5): the 1x1 shortcut convolutions of the
+// four 32 -> 256-channel down-sampling blocks (models/model_resnet.py:18-21) are 11-16 us launches of a memory- and latency-bound
+// kernel, leaves of the backward pass; recorded in a batching queue they run as one flat grid at the flush (a workgroup finds its
+// job by the prefix sums `wg0`), the jobs sharing the chip's workgroup slots (launch_pending_direct).
+template <int TNB, int TKB, int KH, int KW>
+__global__ __launch_bounds__(256) void wgrad_direct_batch_kernel(const DirectJobs jobs) {
+    int ji = 0;
+    while (ji + 1 < jobs.njobs && (int)blockIdx.x >= jobs.job[ji + 1].wg0) ++ji;
+    const DirectJob& j = jobs.job[ji];
+    const int li = (int)blockIdx.x - j.wg0;
+    wgrad_direct_body<TNB, TKB, KH, KW>(j.X, j.dY, j.rows, j.Ho, j.Wo, j.H, j.W, j.C, j.N, j.s, j.pad, j.dil, j.tiles_k, j.partial,
+                                        li % j.nx, li / j.nx, j.nx, j.nsplit);
+}
+
+template <int TNB, int TKB, int KH, int KW>
+int launch_pending_direct(WgradQueue* q, hipStream_t st) {
+    PendingDirect& p = q->pend_direct;
+    const int n = p.jobs.njobs;
+    p.jobs.njobs = 0;
+    if (n <= 0) return DAM_OK;
+    // Pixel splits: alone, a launch wants 3-4 workgroups per CU (`nsplit` as recorded); n jobs in one launch fill the chip
+    // together, so each takes its share -- a quarter of the slabs to write and to reduce, four times the rows per wave (the
+    // 129 x 17 shortcut had ONE 17-pixel row per wave: 40 us for the four jobs, 8.4 MB of slabs for a 32 KB gradient).  A batch of
+    // one keeps the split of the plain launch (bitwise the same slabs).
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        DirectJob& j = p.jobs.job[i];
+        if (n > 1) {
+            const int share = (int)cdiv(1536, (int64_t)n * j.nx);
+            if (share < j.nsplit) j.nsplit = share < 1 ? 1 : share;
+        }
+        j.wg0 = total;
+        total += j.nx * j.nsplit;
+    }
+    DirectJobs jobs = p.jobs;
+    jobs.njobs = n;
+    hipLaunchKernelGGL((wgrad_direct_batch_kernel<TNB, TKB, KH, KW>), dim3(total), dim3(256), 0, st, jobs);
+    DAM_CHECK_LAUNCH();
+    for (int i = 0; i < n; ++i) {
+        const DirectJob& j = jobs.job[i];
+        const int rc = reduce_submit(q, j.partial, p.dw[i], j.nsplit, j.nx, TNB, TKB, KH, KW, p.n_real[i], p.k_real[i], KH, KW, 1,
+                                     j.tiles_k, st);
+        if (rc != DAM_OK) return rc;
+    }
+    return DAM_OK;
 }
 
 template <int TNB, int TKB, int KH, int KW>
@@ -1290,6 +1364,26 @@ int launch_wgrad_direct(int B, int H, int W, int C, int Ho, int Wo, int N, int s
     if (nsplit > (int)cdiv(rows, 4)) nsplit = (int)cdiv(rows, 4);
     while (nsplit > 1 && (int64_t)nsplit * nx * NBLK * 256 > ws_floats) --nsplit;
     if ((int64_t)nsplit * nx * NBLK * 256 > ws_floats) return DAM_ERR_WORKSPACE;
+    WgradQueue* q = static_cast<WgradQueue*>(queue);
+    if (q && q->magic != WGRAD_QUEUE_MAGIC) return DAM_ERR_BAD_ARG;
+    static const bool no_batch = getenv("DAM_WG_DIRECT_NO_BATCH") != nullptr;      // A/B switch
+    if (q && q->batching && !no_batch) {
+        // record instead of launching: launches of this instantiation wait for each other until the queue is flushed (the caller
+        // keeps X, dY and the slabs valid until then: the batching contract of include/dam_hip.h)
+        PendingDirect& p = q->pend_direct;
+        constexpr int sig = TNB | TKB << 4 | KH << 8 | KW << 12;
+        if (p.jobs.njobs > 0 && (p.sig != sig || p.jobs.njobs == WD_MAX_JOBS)) {
+            const int rc = p.launch(q, st);
+            if (rc != DAM_OK) return rc;
+        }
+        const int i = p.jobs.njobs++;
+        p.sig = sig; p.launch = &launch_pending_direct<TNB, TKB, KH, KW>;
+        DirectJob& j = p.jobs.job[i];
+        j.X = X; j.dY = dY; j.partial = partial; j.rows = rows; j.Ho = Ho; j.Wo = Wo; j.H = H; j.W = W; j.C = C; j.N = N; j.s = s;
+        j.pad = pad; j.dil = dil; j.tiles_k = tiles_k; j.nx = nx; j.nsplit = nsplit; j.wg0 = 0;
+        p.dw[i] = dw; p.n_real[i] = n_real; p.k_real[i] = k_real;
+        return DAM_OK;
+    }
     hipLaunchKernelGGL((wgrad_direct_kernel<TNB, TKB, KH, KW>), dim3(nx, nsplit), dim3(256), 0, st, X, dY, rows, Ho, Wo, H, W, C,
                        N, s, pad, dil, tiles_k, partial);
     DAM_CHECK_LAUNCH();
@@ -1444,14 +1538,14 @@ extern "C" int dam_wgrad_queue_init(void* queue) {
 extern "C" int dam_wgrad_queue_set_batching(void* queue, int on) {
     dam::WgradQueue* q = static_cast<dam::WgradQueue*>(queue);
     if (!q || q->magic != dam::WGRAD_QUEUE_MAGIC) return DAM_ERR_BAD_ARG;
-    if (q->pend.njobs > 0) return DAM_ERR_BAD_ARG;          // flush first
+    if (q->pend.njobs > 0 || q->pend_direct.jobs.njobs > 0) return DAM_ERR_BAD_ARG;          // flush first
     q->batching = on ? 1 : 0;
     return DAM_OK;
 }
 
 extern "C" int dam_wgrad_queue_pending(const void* queue) {
     const dam::WgradQueue* q = static_cast<const dam::WgradQueue*>(queue);
-    return q && q->magic == dam::WGRAD_QUEUE_MAGIC ? q->batch.njobs + q->pend.njobs : -1;
+    return q && q->magic == dam::WGRAD_QUEUE_MAGIC ? q->batch.njobs + q->pend.njobs + q->pend_direct.jobs.njobs : -1;
 }
 
 extern "C" int dam_wgrad_queue_flush(void* queue, void* stream) {
@@ -1459,6 +1553,10 @@ extern "C" int dam_wgrad_queue_flush(void* queue, void* stream) {
     if (!q || q->magic != dam::WGRAD_QUEUE_MAGIC) return DAM_ERR_BAD_ARG;
     if (q->pend.njobs > 0) {
         const int rc = q->pend.launch(q, (hipStream_t)stream);
+        if (rc != DAM_OK) return rc;
+    }
+    if (q->pend_direct.jobs.njobs > 0) {
+        const int rc = q->pend_direct.launch(q, (hipStream_t)stream);
         if (rc != DAM_OK) return rc;
     }
     return dam::reduce_flush(q->batch, (hipStream_t)stream);

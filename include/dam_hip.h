@@ -289,7 +289,10 @@ int dam_wgrad_queue_flush(void* queue, void* stream);
  * eight ways over the pixels to fill 256 CUs (eight 2.4 MB slabs for a 2.4 MB gradient).  With batching on, a queued
  * dam_conv2d_wgrad_f32 that takes the tile kernel only RECORDS its launch; recorded launches of the same instantiation and geometry
  * (at most 4) run as ONE launch (blockIdx.z = job) when another geometry arrives or at dam_wgrad_queue_flush -- with a third of
- * the pixel splits, i.e. a third of the slab bytes the reduction reads back.  Off by default.
+ * the pixel splits, i.e. a third of the slab bytes the reduction reads back.  Calls that take the DIRECT kernel (the 1x1 / stride-2
+ * shortcut convolutions, models/model_resnet.py:18-21: 11-16 us launches of a latency-bound kernel) are recorded too and run, up
+ * to 8 of one instantiation with whatever geometries, as one flat launch whose jobs share the chip (each a fraction of the pixel
+ * splits it would take alone).  Off by default.
  *   Contract while on: x, dy, in_scale / in_shift of a queued call must stay valid and unmodified until the flush as well
  *   (not only its workspace and dw).  Switching needs an empty queue (DAM_ERR_BAD_ARG otherwise). */
 int dam_wgrad_queue_set_batching(void* queue, int on);
