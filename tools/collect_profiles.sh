@@ -10,7 +10,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 root=$(pwd)
-run() { ( cd /tmp && rocprofv3 "$@" ) > $out/last.log 2>&1 || { tail -5 $out/last.log; exit 1; }; }
+run() { ( cd /tmp && timeout -k 10 300 rocprofv3 "$@" ) > $out/last.log 2>&1 || { tail -5 $out/last.log; exit 1; }; }   # (the guard: profiles/README.md, the counter-set hang)
 for cfg in C3 C2 C1; do
   run --kernel-trace --stats --output-format csv -d $root/$out/trace_$cfg -- python3 $root/bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-host-stream
   python3 tools/trace_summary.py $out/trace_$cfg 5 70 > $out/${cfg}_kernel_trace_summary.txt
@@ -42,5 +42,6 @@ python3 bench.py --ingest > $out/bench_line_ingest.json 2>> $out/bench.err
 python3 bench.py --via-trainer --dataloader-workers 6 --steps 96 > $out/bench_line_via_trainer_dataloader6.json 2>> $out/bench.err
 python3 bench.py --via-trainer --dataloader-workers 6 --epoch-repeat 8 --steps 768 > $out/bench_line_via_trainer_dataloader6_long_epochs.json 2>> $out/bench.err
 python3 bench.py --no-graph --steps 20 --no-cpu-baseline --no-roofline --no-host-stream > $out/bench_line_C3_eager_no_graph.json 2>> $out/bench.err
-DAM_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 10 --warmup 2 --breakdown --no-roofline --no-host-stream > $out/bench_line_ddp2_gloo_rehearsal.json 2>> $out/bench.err
+DAM_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 10 --warmup 2 --breakdown --no-roofline --no-host-stream 2>> $out/bench.err | grep '^{' > $out/bench_line_ddp2_gloo_rehearsal.json
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-copy-mark > $out/bench_line_C3_no_copy_mark.json 2>> $out/bench.err
 tail -c 600 $out/bench_line_C3.json
