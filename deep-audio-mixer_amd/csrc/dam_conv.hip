@@ -329,6 +329,7 @@ int conv_pack_dispatch(const ConvGeoPack& pk, const ConvLaunchRec& r, hipStream_
 #define DAM_CONV_PCASE(M_, N_) \
     if (r.MB == M_ && r.NB == N_) return launch_conv_pack<M_, N_>(pk, r.lds, r.X, r.Wp, r.bias, r.sc, r.sh, r.Y, r.res, r.res_mask, r.ws, st)
     DAM_CONV_PCASE(4, 4); DAM_CONV_PCASE(4, 2); DAM_CONV_PCASE(4, 1);
+    DAM_CONV_PCASE(4, 3); DAM_CONV_PCASE(2, 3); DAM_CONV_PCASE(1, 3);
     DAM_CONV_PCASE(2, 4); DAM_CONV_PCASE(2, 2); DAM_CONV_PCASE(2, 1);
     DAM_CONV_PCASE(1, 4); DAM_CONV_PCASE(1, 2); DAM_CONV_PCASE(1, 1);
 #undef DAM_CONV_PCASE
@@ -720,7 +721,10 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
     // the tile) and get the workgroup count from split-K over channel groups; otherwise shrink tiles to fill the chip.
     const int64_t npix = (int64_t)Ho * Wo;
     const int nblk = n_out / 16;
-    int MB = 4, NB = nblk % 4 == 0 ? 4 : (nblk % 2 == 0 ? 2 : 1);   // NB must divide the block count
+    // NB must divide the block count.  Three-block tiles for the 48-channel layers of the scalar models (models/model_scalar_2s.py:
+    // 64-77: the 7x7 data gradient 64 -> 48 ran the one-block tile, every LDS operand feeding ONE MFMA group: 371 us = 0.50 of peak)
+    static const bool no_nb3 = getenv("DAM_CONV_NO_NB3") != nullptr;      // A/B switch
+    int MB = 4, NB = nblk % 4 == 0 ? 4 : (nblk % 3 == 0 && !no_nb3 ? 3 : (nblk % 2 == 0 ? 2 : 1));
     auto wgs = [&](int mb, int nb) { return cdiv(npix, 64 * mb) * cdiv(nblk, nb) * B; };
     const bool can_split = workspace && out_stride == 1 && Ho == OHt && Wo == OWt && out_off_h == 0 && out_off_w == 0 &&
                            k_chunks >= 4;
@@ -797,6 +801,7 @@ extern "C" int dam_conv2d_tapgrid_f32(const float* x, int B, int H, int W, int C
 #define DAM_CONV_CASE(M_, N_) \
     if (MB == M_ && NB == N_) return launch_conv<M_, N_>(g, lds, x, w_packed, bias, in_scale, in_shift, y, res, res_mask, workspace, st)
     DAM_CONV_CASE(4, 4); DAM_CONV_CASE(4, 2); DAM_CONV_CASE(4, 1);
+    DAM_CONV_CASE(4, 3); DAM_CONV_CASE(2, 3); DAM_CONV_CASE(1, 3);
     DAM_CONV_CASE(2, 4); DAM_CONV_CASE(2, 2); DAM_CONV_CASE(2, 1);
     DAM_CONV_CASE(1, 4); DAM_CONV_CASE(1, 2); DAM_CONV_CASE(1, 1);
 #undef DAM_CONV_CASE
