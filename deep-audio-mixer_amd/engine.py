@@ -169,7 +169,7 @@ class TrainStep:
             if tap and tap[0].requires_grad and os.environ.get('DAM_COPY_MARK_AT', 'boundary') == 'boundary':
                 tap[0].register_hook(self._mark_hook)       # runs when backward reaches the boundary activation
             else:
-                self.copy_mark.record()                     # a model without a boundary: behind the forward pass
+                self._record_mark()                         # a model without a boundary: behind the forward pass
         loss.backward(self._unit_seed if loss.dim() == 0 else None)      # (no ones_like fill, no seed multiply: layers.UNIT_SEED)
         ops.side_stream_join(self.device)
         ops.wgrad_flush(self.device)                # every weight gradient's slab reduction, one launch
@@ -191,8 +191,20 @@ class TrainStep:
         self.opt.gather_grads(1, grads=grads)
         self._stage = (tap[0], dmid)
 
+    def _record_mark(self):
+        """The mark is a timing aid, never a reason to fail a step or a capture: if the runtime refuses the record (the
+        event-record node of a capture is added through the capture-info API, include/dam_hip.h), the step goes on without
+        it -- waiters then find the last successful record (or none) and simply do not wait."""
+        try:
+            self.copy_mark.record()
+        except RuntimeError as e:
+            if not getattr(self, '_mark_warned', False):
+                import warnings
+                warnings.warn('TrainStep: the step mark could not be recorded (%s); uploads are not timed by it' % e, RuntimeWarning)
+                self._mark_warned = True
+
     def _mark_hook(self, grad):
-        self.copy_mark.record()
+        self._record_mark()
         return None
 
     def _stage2(self):
@@ -200,7 +212,7 @@ class TrainStep:
         mid, dmid = self._stage
         self._stage = None
         if self.copy_mark is not None:
-            self.copy_mark.record()
+            self._record_mark()
         distributed.backward_early(mid, dmid, self.opt.bucket_params(0))
         ops.side_stream_join(self.device)
         ops.wgrad_flush(self.device)
