@@ -694,6 +694,28 @@ def collate_pcm_items(batch, *, collate_fn_map=None):
                         first.normalize, first.device)
 
 
+# The workers' re-usable shared blocks (MultitrackAudioDataset._worker_block) arrive in the main process as tensors rebuilt from a
+# file descriptor: torch maps the block anew unless a storage of the same block is still ALIVE here (reductions.shared_cache holds
+# weak references).  The batch object is dropped as soon as it has been copied into page-locked memory, so every batch was a fresh
+# 38 MB mapping whose 9,300 pages the pin thread's copy then faulted in one by one -- 5 ms per batch in the loader's single pin
+# thread, i.e. DataLoader(num_workers=6, pin_memory=True) delivered a batch every 4.8-6.3 ms (1.2 ms with pin_memory=False) to a
+# step that takes 4.2 (tools/dl_worker_probe.py, profiles/r05_dataloader_pin_thread.txt).  Holding the last few dozen block tensors
+# keeps their mappings (and page tables) alive: the next batch in the same block is found in torch's cache.  Bounded: blocks of
+# finished epochs' workers fall out as new ones arrive (18 live blocks with six workers; a block is 38 MB of shared memory).
+_SHM_KEEP_MAX = 48
+_shm_keep = {}
+
+
+def _keep_shared_mapping(t):
+    if not t.is_shared():
+        return
+    key = t.untyped_storage().data_ptr()
+    _shm_keep.pop(key, None)
+    _shm_keep[key] = t                              # (insertion order = recency)
+    while len(_shm_keep) > _SHM_KEEP_MAX:
+        _shm_keep.pop(next(iter(_shm_keep)))
+
+
 class HostPcmBatch:
     """One batch of decoded clips in HOST memory, as it comes out of ``DataLoader(dataset, num_workers>0)``: `clips`
     [B, S+1, n, ch] (mix last), `items` int64 [B] global item indices.  ``pin_memory()`` is what the loader's pin thread
@@ -726,6 +748,7 @@ class HostPcmBatch:
         if self.clips.is_pinned():
             return self
         src = self.clips.contiguous()
+        _keep_shared_mapping(src)
         dst = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
         staging._host_copy(dst.view(-1).view(torch.uint8), src.view(-1).view(torch.uint8))
         if self.release is not None:

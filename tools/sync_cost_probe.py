@@ -156,3 +156,38 @@ for rep in range(0):
     for kind in ('tiny', 'tiny+gate', 'tiny+ownbufs', 'full', 'full+gate', 'full+ownbufs', 'full+gate+ownbufs'):
         print('stager %-18s %.4f ms per step' % (kind, stager_region(kind)), flush=True)
     print('plain again        %.4f ms per step' % region('plain', TorchEv), flush=True)
+
+
+# ---- the reference loop's per-batch loss read (model_trainer.py:41,43), one batch late: what does the 4-byte D2H copy + event cost?
+def loss_region(kind, k_steps=40):
+    host = torch.zeros(2, dtype=torch.float32, pin_memory=True)
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    state = {'pending': None}
+
+    def one(k):
+        step.bind_clips(bufs[k % 2])
+        loss = step()
+        if kind == 'd2h+event':
+            host[k % 2:k % 2 + 1].copy_(loss.detach().reshape(1), non_blocking=True)
+            evs[k % 2].record()
+            if state['pending'] is not None:
+                evs[state['pending']].synchronize()
+            state['pending'] = k % 2
+        elif kind == 'event only':
+            evs[k % 2].record()
+            if state['pending'] is not None:
+                evs[state['pending']].synchronize()
+            state['pending'] = k % 2
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(4, 4 + k_steps):
+        one(k)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / k_steps
+
+
+for rep in range(2):
+    for kind in ('plain', 'event only', 'd2h+event'):
+        print('loss read one batch late, %-11s %.4f ms per step' % (kind, loss_region(kind)), flush=True)
