@@ -89,75 +89,6 @@ for rep in range(2):
                 continue
             print('%-18s %-13s %.4f ms per step' % (kind, '' if kind == 'plain' else name, region(kind, ev)), flush=True)
 
-# ---- the real stager, piece by piece (where do the streamed leg's 0.1 ms come from?)
-n_host = 4 * B
-host = torch.empty((n_host, S + 1, n, bench.CHANNELS), dtype=torch.float32, pin_memory=True)
-host.copy_(bench.synth_clips(n_host, S, n, dev, 9))
-
-
-def stager_region(kind, k_steps=40):
-    st = staging.BatchStager(host, B, dev, gate=step.copy_mark if 'gate' in kind else None)
-    if 'ownbufs' in kind:          # the step reads the probe's old buffers, the stager only synchronises
-        st.bufs = [torch.empty_like(b) for b in bufs]
-    if 'tiny' in kind:
-        def tiny_issue(k):
-            b = k % 2
-            with torch.cuda.stream(st.stream):
-                if st.gate is not None and k >= 2:
-                    st.gate.wait(st.stream)
-                else:
-                    st.stream.wait_event(st.consumed[b])
-                st.bufs[b][:1, :1, :1024].copy_(st.host[:1, :1, :1024], non_blocking=True)
-                st.ready[b].record(st.stream)
-        st._issue = tiny_issue
-
-    def one(k):
-        got = st.next()
-        step.bind_clips(bufs[k % 2] if 'ownbufs' in kind else got)
-        step()
-    for k in range(4):
-        one(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(k_steps):
-        one(k)
-    torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0) / k_steps
-
-
-def hostsync_region(lag, k_steps=40):
-    """The HOST waits for the event behind step k - lag before it launches step k (no stream waits for the training stream)."""
-    evs = [torch.cuda.Event() for _ in range(k_steps + 8)]
-
-    def one(k):
-        if k >= lag:
-            evs[k - lag].synchronize()
-        step.bind_clips(bufs[k % 2])
-        step()
-        evs[k].record()
-    for k in range(4):
-        one(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(4, 4 + k_steps):
-        one(k)
-    torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0) / k_steps
-
-
-for rep in range(2):
-    for lag in (1, 2, 3):
-        print('host waits for step k-%d before launching step k: %.4f ms per step' % (lag, hostsync_region(lag)), flush=True)
-for rep in range(0):
-    for kind in ('record+cross', 'record+cross+wait', 'record+cross+wait+copy'):
-        for name, ev in (('torch events', TorchEv), ('step marks', MarkEv)):
-            print('%-22s %-13s %.4f ms per step' % (kind, name, region(kind, ev)), flush=True)
-for rep in range(0):
-    for kind in ('tiny', 'tiny+gate', 'tiny+ownbufs', 'full', 'full+gate', 'full+ownbufs', 'full+gate+ownbufs'):
-        print('stager %-18s %.4f ms per step' % (kind, stager_region(kind)), flush=True)
-    print('plain again        %.4f ms per step' % region('plain', TorchEv), flush=True)
-
-
 # ---- the reference loop's per-batch loss read (model_trainer.py:41,43), one batch late: what does the 4-byte D2H copy + event cost?
 def loss_region(kind, k_steps=40):
     host = torch.zeros(2, dtype=torch.float32, pin_memory=True)
