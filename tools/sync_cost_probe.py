@@ -89,6 +89,38 @@ for rep in range(2):
                 continue
             print('%-18s %-13s %.4f ms per step' % (kind, '' if kind == 'plain' else name, region(kind, ev)), flush=True)
 
+# ---- the other direction: a COPY stream waiting for an event of the TRAINING stream ("this staging buffer is free")
+for rep in range(2):
+    for kind in ('record+cross', 'record+cross+wait', 'record+cross+wait+copy'):
+        for name, ev in (('torch events', TorchEv), ('step marks', MarkEv)):
+            print('%-22s %-13s %.4f ms per step' % (kind, name, region(kind, ev)), flush=True)
+
+
+# ---- ... against the HOST waiting for the training stream's event (no stream waits for the training stream)
+def hostsync_region(lag, k_steps=40):
+    evs = [torch.cuda.Event() for _ in range(k_steps + 8)]
+
+    def one(k):
+        if k >= lag:
+            evs[k - lag].synchronize()
+        step.bind_clips(bufs[k % 2])
+        step()
+        evs[k].record()
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(4, 4 + k_steps):
+        one(k)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / k_steps
+
+
+for rep in range(2):
+    for lag in (1, 2, 3):
+        print('host waits for step k-%d before launching step k: %.4f ms per step' % (lag, hostsync_region(lag)), flush=True)
+
+
 # ---- the reference loop's per-batch loss read (model_trainer.py:41,43), one batch late: what does the 4-byte D2H copy + event cost?
 def loss_region(kind, k_steps=40):
     host = torch.zeros(2, dtype=torch.float32, pin_memory=True)
