@@ -797,6 +797,19 @@ def run_via_trainer(name, cfg, args):
         epoch_s.append(time.perf_counter() - t0)
         return out
     trainer._train_epoch = timed_epoch
+    # steady state: a timing event in front of every training step; the median distance between consecutive steps of the TIMED
+    # epochs is what the loop costs once an epoch's loader has started (ms_per_step spreads each epoch's start-up -- with worker
+    # processes: twelve forks and the first batch -- over its batches)
+    step_ev = []
+    inner_tdb = trainer._train_device_batch
+
+    def marked_tdb(batch):
+        if len(epoch_s) >= 1:                  # (epoch 0 holds the eager batches and the capture)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            step_ev.append((len(epoch_s), e))
+        return inner_tdb(batch)
+    trainer._train_device_batch = marked_tdb
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
         os.chdir(tmp)
@@ -815,11 +828,15 @@ def run_via_trainer(name, cfg, args):
             os.chdir(cwd)
     steps = n_epochs * len(train)
     train_s = sum(epoch_s[1:])
+    gaps = sorted(a[1].elapsed_time(b[1]) for a, b in zip(step_ev[:-1], step_ev[1:]) if a[0] == b[0])
+    steady_ms = gaps[len(gaps) // 2] if gaps else None
     t_frames = 1 + cfg['sr'] * cfg['seconds'] // cfg['hop']
     frames = B * S * t_frames
     print(json.dumps({
         'metric': 'stem-spectrogram-frames/sec (train, via ModelTrainer.fit)', 'value': frames * steps / train_s,
         'unit': 'stem-spectrogram-frames/s', 'n_gpus': 1, 'steps': steps, 'ms_per_step': 1e3 * train_s / steps,
+        # median device-side distance between consecutive steps inside the timed epochs (HIP events in front of every step)
+        'steady_state_ms_per_step': steady_ms,
         'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic', 'diagnostic': True,
         'config': {'workload': cfg['workload'] + ' -- through ModelTrainer.fit(%s) from in-memory songs (%s)' % (
                        'torch DataLoader(num_workers=%d, pin_memory=True)' % args.dataloader_workers if args.dataloader_workers
